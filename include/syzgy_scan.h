@@ -1,0 +1,171 @@
+/*
+ * syzgy_scan.h -- C ABI of the MI355X-native brute-force scan that drops in
+ * behind SyzgyDB's Collection.Search (Precision "exact").
+ *
+ * The reference (smhanov/syzgydb, Go) has no FFI seam today; the seam this
+ * library replaces is the block
+ *     collection.go:672-684   (IterateRecords + consider(), the HOT LOOP)
+ * together with the per-record work it calls:
+ *     collection.go:583-629   consider(): filter, distance, top-k / radius
+ *     collection.go:768-794   decodeVector     quantization.go:25-36 dequantize
+ *     collection.go:812-832   euclideanDistance / angularDistance
+ *     collection.go:536-564   resultPriorityQueue (container/heap)
+ * The Go side keeps SearchArgs / SearchResults / SearchResult
+ * (collection.go:115-158) unchanged; go/syzgy_gpu.go shows the cgo binding and
+ * INTEGRATION.md the edit to Collection.Search.
+ *
+ * Conventions: extern "C", plain pointers and explicit sizes, no exceptions
+ * cross the boundary.  Every function returns SZG_OK (0) or a negative
+ * SZG_E_* code.  All in/out buffers are caller-owned and only borrowed for the
+ * duration of the call (cgo rule: no Go pointer is retained).  A handle may
+ * be used by any number of threads concurrently for szg_search_* (the
+ * reference runs Searches concurrently under RLock, collection.go:570);
+ * load/append/tombstone/overwrite need exclusive access (the reference's
+ * write lock, collection.go:428, :512).
+ *
+ * Rows are addressed by their position in the VISIT ORDER the caller loaded
+ * them in (spanfile.go:521-560); the caller keeps the row -> document-id table.
+ */
+#ifndef SYZGY_SCAN_H
+#define SYZGY_SCAN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SZG_ABI_VERSION 1
+
+/* DistanceMethod, collection.go:186-189 */
+#define SZG_EUCLIDEAN 0
+#define SZG_COSINE 1
+
+#define SZG_OK 0
+#define SZG_E_INVALID (-1)    /* bad argument (dim, quantization, metric, k, null pointer) */
+#define SZG_E_NOMEM (-2)      /* host or device allocation failed */
+#define SZG_E_DEVICE (-3)     /* HIP runtime error; szg_last_error() has the text */
+#define SZG_E_TRUNCATED (-4)  /* radius search: more hits than `capacity`; *out_total says how many */
+#define SZG_E_NODEVICE (-5)   /* no usable gfx950 device / HIP kernels not loadable */
+#define SZG_E_RANGE (-6)      /* row index out of range */
+#define SZG_E_UNSUPPORTED (-7)/* valid in the reference but outside this build's limits */
+
+typedef struct szg_index szg_index;
+
+/*
+ * One handle per Collection (created where NewCollection pages the corpus,
+ * collection.go:297-311; destroyed in Collection.Close, :408-421).
+ *   dim         CollectionOptions.DimensionCount
+ *   quant_bits  CollectionOptions.Quantization: 4, 8, 16, 32 or 64 (collection.go:796-811)
+ *   metric      SZG_EUCLIDEAN or SZG_COSINE (collection.go:275-283)
+ *   devices     HIP device ordinals to shard the rows over (contiguous row
+ *               ranges, one per entry); NULL / n_devices==0 = current device.
+ */
+int szg_index_create(szg_index **out, int dim, int quant_bits, int metric,
+                     const int *devices, int n_devices);
+void szg_index_destroy(szg_index *ix);
+
+/* Row byte size = getVectorSize(quant_bits, dim), collection.go:796-811; <0 on error. */
+int64_t szg_row_bytes(int quant_bits, int dim);
+
+/*
+ * Replace the mirror's content with n_rows packed vectors in the reference's
+ * on-disk element encoding (stream 1 of each span: 4-bit high-nibble-first,
+ * 8-bit bytes, big-endian 16/32/64-bit; collection.go:713-743).  Copies.
+ */
+int szg_index_load(szg_index *ix, const uint8_t *rows, uint64_t n_rows);
+
+/* AddDocument (collection.go:427-457): rows go to the end of the visit order. */
+int szg_index_append(szg_index *ix, const uint8_t *rows, uint64_t n_rows);
+
+/* AddDocument on an existing id rewrites the record: replace one row in place. */
+int szg_index_overwrite(szg_index *ix, uint64_t row, const uint8_t *row_bytes);
+
+/* removeDocument (collection.go:511-521): the row is skipped by every later scan. */
+int szg_index_tombstone(szg_index *ix, uint64_t row);
+
+/* rows loaded (tombstoned ones included) / rows still live */
+uint64_t szg_index_rows(const szg_index *ix);
+uint64_t szg_index_live_rows(const szg_index *ix);
+
+/* Read rows back in the reference encoding (inverse of the page-in transform). */
+int szg_index_read_rows(szg_index *ix, uint64_t first_row, uint64_t n_rows, uint8_t *out);
+
+/*
+ * Exact top-k, i.e. Search{Precision:"exact", K:k, Radius:0}
+ * (collection.go:606-619, :672-684, :694-697) for n_queries independent
+ * queries.
+ *   queries     n_queries x dim float64, SearchArgs.Vector (never quantized)
+ *   allow_bits  NULL, or n_queries(!) x ceil(rows/64) words: bit r of query
+ *               q's mask = args.Filter(id(r), metadata(r)) (collection.go:592)
+ *   out_rows    n_queries x k row indices, ascending distance (:694-697)
+ *   out_dist    n_queries x k float64 distances, the reference's own values
+ *   out_count   n_queries result counts (<= k; fewer when fewer rows qualify)
+ * Unused tail entries of out_rows are UINT64_MAX.
+ */
+int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
+                    const uint64_t *allow_bits, uint64_t *out_rows, double *out_dist,
+                    int32_t *out_count);
+
+/*
+ * Radius search, i.e. Search{Precision:"exact", Radius:radius>0} (K ignored,
+ * collection.go:598-605).  Writes the min(total, capacity) closest hits in
+ * ascending distance; *out_total is the full hit count.  Returns
+ * SZG_E_TRUNCATED when total > capacity (retry with a larger buffer).
+ */
+int szg_search_radius(szg_index *ix, const double *query, double radius,
+                      const uint64_t *allow_bits, uint64_t *out_rows, double *out_dist,
+                      uint64_t capacity, uint64_t *out_total);
+
+/* ---- diagnostics -------------------------------------------------------- */
+
+const char *szg_strerror(int code);
+/* Text of the last error raised on the calling thread ("" if none). */
+const char *szg_last_error(void);
+int szg_abi_version(void);
+
+typedef struct szg_stats {
+    uint64_t queries;          /* top-k + radius queries served */
+    uint64_t scan_launches;    /* launches of the fused scan kernel */
+    uint64_t escalations;      /* top-k queries whose first pass could not be certified */
+    uint64_t scan_bytes;       /* algorithmic bytes swept: sum over launches of rows x row_bytes */
+    double scan_ms;            /* HIP-event time of the scan kernel launches (timing on) */
+    double total_ms;           /* HIP-event time of the whole per-query pipeline (timing on) */
+    uint64_t timed_launches;   /* launches included in scan_ms */
+    uint64_t full_replays;     /* top-k queries answered by the exact full-history replay
+                                  (equal distances or NaN among the best k+1 candidates) */
+} szg_stats;
+
+/* Per-kernel HIP-event timing on the library's own streams (off by default). */
+int szg_set_timing(szg_index *ix, int enabled);
+int szg_get_stats(szg_index *ix, szg_stats *out);
+int szg_reset_stats(szg_index *ix);
+
+/*
+ * Tunables: "slack" (extra candidates kept beyond k), "blocks_per_cu",
+ * "block_threads", "tie_mode" (0 = default: when two of the best k+1 distances
+ * are exactly equal, or one is NaN, the reference's output depends on its whole
+ * heap history, so the query is re-answered by an exact replay over every row;
+ * 1 = keep the fast answer, which is a valid top-k whose order among equal
+ * distances may differ from the reference's), "force_escalate" (tests).
+ */
+int szg_set_option(szg_index *ix, const char *name, int64_t value);
+
+/* ---- bench / test utilities (not part of the drop-in surface) ----------- */
+
+/*
+ * Fill the mirror with n_rows synthetic vectors generated on the device:
+ * element e of row r = U[-1,1) from splitmix64(seed + (first_row + r)*dim + e),
+ * quantized and packed exactly as encodeDocument would (collection.go:713-743,
+ * quantization.go:5-23).  Byte-identical to oracle/orc_synth_rows.
+ */
+int szg_index_synth(szg_index *ix, uint64_t n_rows, uint64_t seed, uint64_t first_row);
+
+/* Global row index of this handle's row 0 (multi-process sharding); rows
+ * returned by szg_search_* are local + base. */
+int szg_index_set_row_base(szg_index *ix, uint64_t base);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYZGY_SCAN_H */

@@ -1,0 +1,224 @@
+"""ctypes wrapper over oracle/libsyzgy_oracle.so (the CPU parity oracle).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from syzgydb_amd/.  See syzgy_oracle.h for
+the parity-pinning status and the reference lines each function restates.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsyzgy_oracle.so")
+
+EUCLIDEAN = 0  # collection.go:186-189
+COSINE = 1
+
+
+def build(force=False):
+    """Compile the oracle with gcc (no reference sources involved)."""
+    src = os.path.join(_HERE, "syzgy_oracle.c")
+    if (force or not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", _HERE, "libsyzgy_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        f64p = ctypes.POINTER(ctypes.c_double)
+        L.orc_quantize.restype = ctypes.c_uint64
+        L.orc_quantize.argtypes = [ctypes.c_double, ctypes.c_int]
+        L.orc_dequantize.restype = ctypes.c_double
+        L.orc_dequantize.argtypes = [ctypes.c_uint64, ctypes.c_int]
+        L.orc_vector_size.restype = ctypes.c_int64
+        L.orc_vector_size.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.orc_encode_vector.restype = None
+        L.orc_encode_vector.argtypes = [f64p, ctypes.c_int, ctypes.c_int, u8p]
+        L.orc_decode_vector.restype = None
+        L.orc_decode_vector.argtypes = [u8p, ctypes.c_int, ctypes.c_int, f64p]
+        L.orc_euclidean.restype = ctypes.c_double
+        L.orc_euclidean.argtypes = [f64p, f64p, ctypes.c_int]
+        L.orc_angular.restype = ctypes.c_double
+        L.orc_angular.argtypes = [f64p, f64p, ctypes.c_int]
+        L.orc_go_acos.restype = ctypes.c_double
+        L.orc_go_acos.argtypes = [ctypes.c_double]
+        L.orc_search_exact.restype = ctypes.c_int64
+        L.orc_search_exact.argtypes = [u8p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, f64p, ctypes.c_int, ctypes.c_double,
+                                       u8p, u64p, f64p, ctypes.c_uint64, u64p]
+        L.orc_all_distances.restype = None
+        L.orc_all_distances.argtypes = [u8p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, f64p, f64p]
+        L.orc_distances_for_rows.restype = None
+        L.orc_distances_for_rows.argtypes = [u8p, u64p, ctypes.c_uint64, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, f64p, f64p]
+        L.orc_sorted_id_order.restype = None
+        L.orc_sorted_id_order.argtypes = [u64p, ctypes.c_uint64, u64p]
+        L.orc_splitmix64.restype = ctypes.c_uint64
+        L.orc_splitmix64.argtypes = [ctypes.c_uint64]
+        L.orc_synth_value.restype = ctypes.c_double
+        L.orc_synth_value.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
+        L.orc_synth_vectors.restype = None
+        L.orc_synth_vectors.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                        ctypes.c_int, f64p]
+        L.orc_synth_rows.restype = None
+        L.orc_synth_rows.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                     ctypes.c_int, ctypes.c_int, u8p]
+        L.orc_bench_topk.restype = ctypes.c_double
+        L.orc_bench_topk.argtypes = [u8p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, f64p, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, u64p]
+        _lib = L
+    return _lib
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def quantize(value, bits):
+    return int(lib().orc_quantize(float(value), int(bits)))
+
+
+def dequantize(value, bits):
+    return float(lib().orc_dequantize(int(value), int(bits)))
+
+
+def vector_size(bits, dim):
+    return int(lib().orc_vector_size(int(bits), int(dim)))
+
+
+def encode_vector(vec, bits):
+    v = _f64(vec)
+    out = np.zeros(max(vector_size(bits, v.size), 0), dtype=np.uint8)
+    lib().orc_encode_vector(_p(v, ctypes.c_double), v.size, bits, _p(out, ctypes.c_uint8))
+    return out
+
+
+def encode_rows(vectors, bits):
+    V = _f64(vectors)
+    n, dim = V.shape
+    rb = vector_size(bits, dim)
+    out = np.zeros((n, rb), dtype=np.uint8)
+    for i in range(n):
+        lib().orc_encode_vector(_p(V[i], ctypes.c_double), dim, bits,
+                                out[i].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    return out
+
+
+def decode_vector(data, dim, bits):
+    d = np.ascontiguousarray(data, dtype=np.uint8)
+    out = np.zeros(dim, dtype=np.float64)
+    lib().orc_decode_vector(_p(d, ctypes.c_uint8), dim, bits, _p(out, ctypes.c_double))
+    return out
+
+
+def euclidean(a, b):
+    a, b = _f64(a), _f64(b)
+    return float(lib().orc_euclidean(_p(a, ctypes.c_double), _p(b, ctypes.c_double), a.size))
+
+
+def angular(a, b):
+    a, b = _f64(a), _f64(b)
+    return float(lib().orc_angular(_p(a, ctypes.c_double), _p(b, ctypes.c_double), a.size))
+
+
+def go_acos(x):
+    return float(lib().orc_go_acos(float(x)))
+
+
+def search_exact(rows, dim, bits, metric, query, k=0, radius=0.0, allow=None, capacity=None):
+    """Reference Search{Precision:"exact"} over packed rows in visit order.
+
+    Returns (row_indices uint64[], distances float64[], points_searched).
+    """
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    rb = vector_size(bits, dim)
+    n_rows = rows.size // rb if rb > 0 else 0
+    q = _f64(query)
+    if capacity is None:
+        capacity = n_rows if radius > 0 else min(max(k, 0), n_rows)
+    capacity = max(int(capacity), 1)
+    out_rows = np.zeros(capacity, dtype=np.uint64)
+    out_dist = np.zeros(capacity, dtype=np.float64)
+    searched = ctypes.c_uint64(0)
+    allow_p = None
+    if allow is not None:
+        allow = np.ascontiguousarray(allow, dtype=np.uint8)
+        assert allow.size == n_rows
+        allow_p = _p(allow, ctypes.c_uint8)
+    n = lib().orc_search_exact(_p(rows, ctypes.c_uint8) if rows.size else None, n_rows, dim,
+                               bits, metric, _p(q, ctypes.c_double), int(k), float(radius),
+                               allow_p, _p(out_rows, ctypes.c_uint64),
+                               _p(out_dist, ctypes.c_double), capacity, ctypes.byref(searched))
+    if n < 0:
+        raise ValueError("orc_search_exact: bad arguments")
+    m = min(int(n), capacity)
+    return out_rows[:m].copy(), out_dist[:m].copy(), int(searched.value)
+
+
+def all_distances(rows, dim, bits, metric, query):
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    rb = vector_size(bits, dim)
+    n_rows = rows.size // rb
+    q = _f64(query)
+    out = np.zeros(n_rows, dtype=np.float64)
+    lib().orc_all_distances(_p(rows, ctypes.c_uint8), n_rows, dim, bits, metric,
+                            _p(q, ctypes.c_double), _p(out, ctypes.c_double))
+    return out
+
+
+def sorted_id_order(ids):
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    perm = np.zeros(ids.size, dtype=np.uint64)
+    lib().orc_sorted_id_order(_p(ids, ctypes.c_uint64), ids.size, _p(perm, ctypes.c_uint64))
+    return perm
+
+
+def splitmix64(x):
+    return int(lib().orc_splitmix64(int(x) & 0xFFFFFFFFFFFFFFFF))
+
+
+def synth_vectors(seed, first_row, n_rows, dim):
+    out = np.zeros((n_rows, dim), dtype=np.float64)
+    lib().orc_synth_vectors(int(seed), int(first_row), int(n_rows), int(dim),
+                            _p(out, ctypes.c_double))
+    return out
+
+
+def synth_rows(seed, first_row, n_rows, dim, bits):
+    rb = vector_size(bits, dim)
+    out = np.zeros((n_rows, rb), dtype=np.uint8)
+    lib().orc_synth_rows(int(seed), int(first_row), int(n_rows), int(dim), int(bits),
+                         _p(out, ctypes.c_uint8))
+    return out
+
+
+def bench_topk(rows, dim, bits, metric, queries, k, threads):
+    """Time n_queries exact top-k searches; returns (seconds, rows[n_queries,k])."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    rb = vector_size(bits, dim)
+    n_rows = rows.size // rb
+    Q = _f64(queries).reshape(-1, dim)
+    out = np.zeros((Q.shape[0], k), dtype=np.uint64)
+    secs = lib().orc_bench_topk(_p(rows, ctypes.c_uint8), n_rows, dim, bits, metric,
+                                _p(Q, ctypes.c_double), Q.shape[0], k, int(threads),
+                                _p(out, ctypes.c_uint64))
+    return float(secs), out

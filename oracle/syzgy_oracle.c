@@ -1,0 +1,498 @@
+/*
+ * syzgy_oracle.c -- CPU restatement of SyzgyDB's brute-force scan
+ * (Collection.Search, Precision "exact") in plain C.
+ *
+ * TEST INFRASTRUCTURE ONLY -- see syzgy_oracle.h for who may use it and for
+ * the parity-pinning status.  Every function cites the reference lines
+ * (/root/reference/<file>:<lines>) it restates.  float64 everywhere,
+ * sequential left-to-right sums, no FMA contraction (-ffp-contract=off).
+ */
+#include "syzgy_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <time.h>
+
+/* ---------------------------------------------------------------- quantizer */
+
+/* quantization.go:5-23 */
+uint64_t orc_quantize(double value, int bits)
+{
+    if (bits == 32) {
+        float f = (float)value; /* float32(value): round-to-nearest-even */
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        return (uint64_t)u;
+    }
+    if (bits == 64) {
+        uint64_t u;
+        memcpy(&u, &value, 8);
+        return u;
+    }
+    if (value < -1) {
+        value = -1;
+    } else if (value > 1) {
+        value = 1;
+    }
+    int64_t maxInt = ((int64_t)1 << bits) - 1;
+    double q = (value + 1) / 2 * (double)maxInt;
+    return (uint64_t)round(q); /* math.Round: half away from zero */
+}
+
+/* quantization.go:25-36 */
+double orc_dequantize(uint64_t value, int bits)
+{
+    if (bits == 32) {
+        uint32_t u = (uint32_t)value;
+        float f;
+        memcpy(&f, &u, 4);
+        return (double)f;
+    }
+    if (bits == 64) {
+        double d;
+        memcpy(&d, &value, 8);
+        return d;
+    }
+    int64_t maxInt = ((int64_t)1 << bits) - 1;
+    return ((double)value / (double)maxInt) * 2 - 1;
+}
+
+/* collection.go:796-811 */
+int64_t orc_vector_size(int bits, int dim)
+{
+    switch (bits) {
+    case 4: return ((int64_t)dim + 1) / 2;
+    case 8: return dim;
+    case 16: return (int64_t)dim * 2;
+    case 32: return (int64_t)dim * 4;
+    case 64: return (int64_t)dim * 8;
+    default: return -1; /* reference panics */
+    }
+}
+
+/* collection.go:713-743; binary.BigEndian puts */
+void orc_encode_vector(const double *vec, int dim, int bits, uint8_t *out)
+{
+    int64_t size = orc_vector_size(bits, dim);
+    if (size < 0) return;
+    memset(out, 0, (size_t)size);
+    for (int i = 0; i < dim; i++) {
+        uint64_t q = orc_quantize(vec[i], bits);
+        switch (bits) {
+        case 4:
+            if (i % 2 == 0) {
+                out[i / 2] = (uint8_t)(q << 4);
+            } else {
+                out[i / 2] |= (uint8_t)(q & 0x0F);
+            }
+            break;
+        case 8: out[i] = (uint8_t)q; break;
+        case 16:
+            out[i * 2] = (uint8_t)(q >> 8);
+            out[i * 2 + 1] = (uint8_t)q;
+            break;
+        case 32:
+            for (int b = 0; b < 4; b++) out[i * 4 + b] = (uint8_t)(q >> (24 - 8 * b));
+            break;
+        case 64:
+            for (int b = 0; b < 8; b++) out[i * 8 + b] = (uint8_t)(q >> (56 - 8 * b));
+            break;
+        }
+    }
+}
+
+/* collection.go:768-794 */
+void orc_decode_vector(const uint8_t *data, int dim, int bits, double *out)
+{
+    for (int i = 0; i < dim; i++) {
+        uint64_t q = 0;
+        switch (bits) {
+        case 4:
+            if (i % 2 == 0) {
+                q = (uint64_t)(data[i / 2] >> 4);
+            } else {
+                q = (uint64_t)(data[i / 2] & 0x0F);
+            }
+            break;
+        case 8: q = data[i]; break;
+        case 16: q = ((uint64_t)data[i * 2] << 8) | data[i * 2 + 1]; break;
+        case 32:
+            for (int b = 0; b < 4; b++) q = (q << 8) | data[i * 4 + b];
+            break;
+        case 64:
+            for (int b = 0; b < 8; b++) q = (q << 8) | data[i * 8 + b];
+            break;
+        }
+        out[i] = orc_dequantize(q, bits);
+    }
+}
+
+/* ---------------------------------------------------------------- distances */
+
+/* collection.go:812-819 */
+double orc_euclidean(const double *a, const double *b, int n)
+{
+    double sum = 0.0;
+    for (int i = 0; i < n; i++) {
+        double diff = a[i] - b[i];
+        sum += diff * diff;
+    }
+    return sqrt(sum); /* math.Sqrt = SQRTSD, correctly rounded */
+}
+
+/*
+ * Go stdlib math/atan.go (xatan, satan) and math/asin.go (Asin, Acos).  The
+ * amd64 port has no assembly for these; the pure-Go Cephes code runs.
+ */
+static double go_xatan(double x)
+{
+    const double P0 = -8.750608600031904122785e-01;
+    const double P1 = -1.615753718733365076637e+01;
+    const double P2 = -7.500855792314704667340e+01;
+    const double P3 = -1.228866684490136173410e+02;
+    const double P4 = -6.485021904942025371773e+01;
+    const double Q0 = +2.485846490142306297962e+01;
+    const double Q1 = +1.650270098316988542046e+02;
+    const double Q2 = +4.328810604912902668951e+02;
+    const double Q3 = +4.853903996359136964868e+02;
+    const double Q4 = +1.945506571482613964425e+02;
+    double z = x * x;
+    z = z * ((((P0 * z + P1) * z + P2) * z + P3) * z + P4) /
+        (((((z + Q0) * z + Q1) * z + Q2) * z + Q3) * z + Q4);
+    z = x * z + x;
+    return z;
+}
+
+static double go_satan(double x)
+{
+    const double Morebits = 6.123233995736765886130e-17; /* pi/2 = PIO2 + Morebits */
+    const double Tan3pio8 = 2.41421356237309504880;      /* tan(3*pi/8) */
+    if (x <= 0.66) {
+        return go_xatan(x);
+    }
+    if (x > Tan3pio8) {
+        return M_PI / 2 - go_xatan(1 / x) + Morebits;
+    }
+    return M_PI / 4 + go_xatan((x - 1) / (x + 1)) + 0.5 * Morebits;
+}
+
+static double go_asin(double x)
+{
+    if (x == 0) {
+        return x;
+    }
+    int sign = 0;
+    if (x < 0) {
+        x = -x;
+        sign = 1;
+    }
+    if (x > 1) {
+        return NAN;
+    }
+    double temp = sqrt(1 - x * x);
+    if (x > 0.7) {
+        temp = M_PI / 2 - go_satan(temp / x);
+    } else {
+        temp = go_satan(x / temp);
+    }
+    if (sign) {
+        temp = -temp;
+    }
+    return temp;
+}
+
+double orc_go_acos(double x)
+{
+    return M_PI / 2 - go_asin(x);
+}
+
+/* collection.go:821-832 ("Cosine" is the angular distance acos(cos)/pi) */
+double orc_angular(const double *a, const double *b, int n)
+{
+    double dot = 0.0, m1 = 0.0, m2 = 0.0;
+    for (int i = 0; i < n; i++) {
+        dot += a[i] * b[i];
+        m1 += a[i] * a[i];
+        m2 += b[i] * b[i];
+    }
+    if (m1 == 0 || m2 == 0) {
+        return 1.0;
+    }
+    return orc_go_acos(dot / (sqrt(m1) * sqrt(m2))) / M_PI;
+}
+
+static double distance_fn(int metric, const double *q, const double *d, int n)
+{
+    return metric == ORC_COSINE ? orc_angular(q, d, n) : orc_euclidean(q, d, n);
+}
+
+/* --------------------------------------------------- container/heap restated */
+
+typedef struct {
+    uint64_t row;
+    double priority; /* = distance (collection.go:600, 611) */
+} orc_item;
+
+typedef struct {
+    orc_item *a;
+    int64_t len, cap;
+} orc_pq;
+
+/* collection.go:545-547: max-heap on distance */
+static int pq_less(const orc_pq *h, int64_t i, int64_t j)
+{
+    return h->a[i].priority > h->a[j].priority;
+}
+
+static void pq_swap(orc_pq *h, int64_t i, int64_t j)
+{
+    orc_item t = h->a[i];
+    h->a[i] = h->a[j];
+    h->a[j] = t;
+}
+
+/* container/heap.up */
+static void heap_up(orc_pq *h, int64_t j)
+{
+    for (;;) {
+        int64_t i = (j - 1) / 2; /* parent; (0-1)/2 == 0 like Go */
+        if (i == j || !pq_less(h, j, i)) break;
+        pq_swap(h, i, j);
+        j = i;
+    }
+}
+
+/* container/heap.down */
+static void heap_down(orc_pq *h, int64_t i0, int64_t n)
+{
+    int64_t i = i0;
+    for (;;) {
+        int64_t j1 = 2 * i + 1;
+        if (j1 >= n || j1 < 0) break;
+        int64_t j = j1;
+        int64_t j2 = j1 + 1;
+        if (j2 < n && pq_less(h, j2, j1)) j = j2;
+        if (!pq_less(h, j, i)) break;
+        pq_swap(h, i, j);
+        i = j;
+    }
+}
+
+/* heap.Push = append (collection.go:553-556) + up */
+static void heap_push(orc_pq *h, orc_item it)
+{
+    if (h->len == h->cap) {
+        h->cap = h->cap ? h->cap * 2 : 64;
+        h->a = (orc_item *)realloc(h->a, (size_t)h->cap * sizeof(orc_item));
+    }
+    h->a[h->len++] = it;
+    heap_up(h, h->len - 1);
+}
+
+/* heap.Pop = swap(0,n-1); down(0,n-1); remove last (collection.go:558-564) */
+static orc_item heap_pop(orc_pq *h)
+{
+    int64_t n = h->len - 1;
+    pq_swap(h, 0, n);
+    heap_down(h, 0, n);
+    orc_item it = h->a[n];
+    h->len = n;
+    return it;
+}
+
+/* ------------------------------------------------------------------- search */
+
+int64_t orc_search_exact(const uint8_t *rows, uint64_t n_rows, int dim, int bits,
+                         int metric, const double *query, int k, double radius,
+                         const uint8_t *allow, uint64_t *out_rows, double *out_dist,
+                         uint64_t capacity, uint64_t *points_searched)
+{
+    int64_t row_bytes = orc_vector_size(bits, dim);
+    if (row_bytes < 0 || dim <= 0 || (metric != ORC_EUCLIDEAN && metric != ORC_COSINE)) return -1;
+    orc_pq pq = {0, 0, 0};
+    uint64_t searched = 0;
+    double *vec = (double *)malloc(sizeof(double) * (size_t)dim);
+
+    if (!(radius == 0 && k == 0)) { /* listing mode (:633-669) computes no distances */
+        for (uint64_t r = 0; r < n_rows; r++) {
+            /* consider(), collection.go:583-629 */
+            orc_decode_vector(rows + r * (uint64_t)row_bytes, dim, bits, vec); /* :584 */
+            searched++;                                                        /* :589 */
+            if (allow && !allow[r]) continue;                                  /* :592-594 */
+            double distance = distance_fn(metric, query, vec, dim);            /* :596 */
+            if (radius > 0 && distance <= radius) {                            /* :598-603 */
+                orc_item it = {r, distance};
+                heap_push(&pq, it);
+            } else if (radius > 0) {                                           /* :604-605 */
+                continue;
+            } else if (k > 0) {                                                /* :606-619 */
+                if (pq.len <= k) {
+                    if (pq.len < k || pq.a[0].priority > distance) {
+                        orc_item it = {r, distance};
+                        heap_push(&pq, it);
+                        if (pq.len > k) heap_pop(&pq);
+                    }
+                }
+            }
+        }
+    }
+    /* :694-697: fill from the end => ascending */
+    int64_t n = pq.len;
+    for (int64_t i = n - 1; i >= 0; i--) {
+        orc_item it = heap_pop(&pq);
+        if ((uint64_t)i < capacity) {
+            if (out_rows) out_rows[i] = it.row;
+            if (out_dist) out_dist[i] = it.priority;
+        }
+    }
+    if (points_searched) *points_searched = searched;
+    free(vec);
+    free(pq.a);
+    return n;
+}
+
+void orc_all_distances(const uint8_t *rows, uint64_t n_rows, int dim, int bits,
+                       int metric, const double *query, double *out_dist)
+{
+    int64_t row_bytes = orc_vector_size(bits, dim);
+    if (row_bytes < 0) return;
+    double *vec = (double *)malloc(sizeof(double) * (size_t)dim);
+    for (uint64_t r = 0; r < n_rows; r++) {
+        orc_decode_vector(rows + r * (uint64_t)row_bytes, dim, bits, vec);
+        out_dist[r] = distance_fn(metric, query, vec, dim);
+    }
+    free(vec);
+}
+
+void orc_distances_for_rows(const uint8_t *rows, const uint64_t *row_ids, uint64_t n_ids,
+                            int dim, int bits, int metric, const double *query,
+                            double *out_dist)
+{
+    int64_t row_bytes = orc_vector_size(bits, dim);
+    if (row_bytes < 0) return;
+    double *vec = (double *)malloc(sizeof(double) * (size_t)dim);
+    for (uint64_t i = 0; i < n_ids; i++) {
+        orc_decode_vector(rows + row_ids[i] * (uint64_t)row_bytes, dim, bits, vec);
+        out_dist[i] = distance_fn(metric, query, vec, dim);
+    }
+    free(vec);
+}
+
+/* ------------------------------------------------------------- visit order */
+
+typedef struct {
+    char s[24];
+    uint64_t idx;
+} orc_idstr;
+
+static int idstr_cmp(const void *a, const void *b)
+{
+    return strcmp(((const orc_idstr *)a)->s, ((const orc_idstr *)b)->s);
+}
+
+/* spanfile.go:540-560: sort.Strings over fmt.Sprintf("%d", id) (collection.go:450) */
+void orc_sorted_id_order(const uint64_t *ids, uint64_t n, uint64_t *perm)
+{
+    orc_idstr *v = (orc_idstr *)malloc(sizeof(orc_idstr) * (size_t)(n ? n : 1));
+    for (uint64_t i = 0; i < n; i++) {
+        snprintf(v[i].s, sizeof(v[i].s), "%llu", (unsigned long long)ids[i]);
+        v[i].idx = i;
+    }
+    qsort(v, (size_t)n, sizeof(orc_idstr), idstr_cmp);
+    for (uint64_t i = 0; i < n; i++) perm[i] = v[i].idx;
+    free(v);
+}
+
+/* ---------------------------------------------------------- synthetic data */
+
+uint64_t orc_splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+double orc_synth_value(uint64_t seed, uint64_t index)
+{
+    uint64_t m = orc_splitmix64(seed + index) >> 11;       /* 53 bits */
+    return (double)m * (1.0 / 4503599627370496.0) - 1.0;   /* m * 2^-52 - 1, exact */
+}
+
+void orc_synth_vectors(uint64_t seed, uint64_t first_row, uint64_t n_rows, int dim, double *out)
+{
+    for (uint64_t r = 0; r < n_rows; r++)
+        for (int i = 0; i < dim; i++)
+            out[r * (uint64_t)dim + (uint64_t)i] =
+                orc_synth_value(seed, (first_row + r) * (uint64_t)dim + (uint64_t)i);
+}
+
+void orc_synth_rows(uint64_t seed, uint64_t first_row, uint64_t n_rows, int dim, int bits,
+                    uint8_t *out)
+{
+    int64_t row_bytes = orc_vector_size(bits, dim);
+    if (row_bytes < 0) return;
+    double *vec = (double *)malloc(sizeof(double) * (size_t)dim);
+    for (uint64_t r = 0; r < n_rows; r++) {
+        orc_synth_vectors(seed, first_row + r, 1, dim, vec);
+        orc_encode_vector(vec, dim, bits, out + r * (uint64_t)row_bytes);
+    }
+    free(vec);
+}
+
+/* ------------------------------------------------------------ CPU baseline */
+
+typedef struct {
+    const uint8_t *rows;
+    uint64_t n_rows;
+    int dim, bits, metric, k, n_queries;
+    const double *queries;
+    uint64_t *out_rows;
+    int next; /* guarded by mu */
+    pthread_mutex_t *mu;
+} bench_ctx;
+
+static void *bench_worker(void *p)
+{
+    bench_ctx *c = (bench_ctx *)p;
+    uint64_t *rows_out = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)c->k);
+    double *dist_out = (double *)malloc(sizeof(double) * (size_t)c->k);
+    for (;;) {
+        pthread_mutex_lock(c->mu);
+        int q = c->next++;
+        pthread_mutex_unlock(c->mu);
+        if (q >= c->n_queries) break;
+        uint64_t searched;
+        int64_t n = orc_search_exact(c->rows, c->n_rows, c->dim, c->bits, c->metric,
+                                     c->queries + (size_t)q * (size_t)c->dim, c->k, 0.0, NULL,
+                                     rows_out, dist_out, (uint64_t)c->k, &searched);
+        if (c->out_rows) {
+            for (int i = 0; i < c->k; i++)
+                c->out_rows[(size_t)q * (size_t)c->k + (size_t)i] =
+                    i < n ? rows_out[i] : UINT64_MAX;
+        }
+    }
+    free(rows_out);
+    free(dist_out);
+    return NULL;
+}
+
+double orc_bench_topk(const uint8_t *rows, uint64_t n_rows, int dim, int bits, int metric,
+                      const double *queries, int n_queries, int k, int threads,
+                      uint64_t *out_rows)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    bench_ctx c = {rows, n_rows, dim, bits, metric, k, n_queries, queries, out_rows, 0, &mu};
+    pthread_t th[256];
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, bench_worker, &c);
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

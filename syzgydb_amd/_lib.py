@@ -1,0 +1,133 @@
+"""ctypes binding of syzgydb_amd/libsyzgy_scan.so (include/syzgy_scan.h).
+
+The library is the product; this module only loads it and declares the
+prototypes.  There is no Python or CPU fallback: if the shared object is
+missing, loading fails loudly with the build command to run.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsyzgy_scan.so")
+
+SZG_EUCLIDEAN = 0
+SZG_COSINE = 1
+
+SZG_OK = 0
+SZG_E_INVALID = -1
+SZG_E_NOMEM = -2
+SZG_E_DEVICE = -3
+SZG_E_TRUNCATED = -4
+SZG_E_NODEVICE = -5
+SZG_E_RANGE = -6
+SZG_E_UNSUPPORTED = -7
+
+# every symbol include/syzgy_scan.h declares (tests check the .so exports them all)
+EXPORTS = [
+    "szg_index_create", "szg_index_destroy", "szg_row_bytes", "szg_index_load",
+    "szg_index_append", "szg_index_overwrite", "szg_index_tombstone", "szg_index_rows",
+    "szg_index_live_rows", "szg_index_read_rows", "szg_search_topk", "szg_search_radius",
+    "szg_strerror", "szg_last_error", "szg_abi_version", "szg_set_timing", "szg_get_stats",
+    "szg_reset_stats", "szg_set_option", "szg_index_synth", "szg_index_set_row_base",
+]
+
+
+class SzgStats(ctypes.Structure):
+    _fields_ = [
+        ("queries", ctypes.c_uint64),
+        ("scan_launches", ctypes.c_uint64),
+        ("escalations", ctypes.c_uint64),
+        ("scan_bytes", ctypes.c_uint64),
+        ("scan_ms", ctypes.c_double),
+        ("total_ms", ctypes.c_double),
+        ("timed_launches", ctypes.c_uint64),
+        ("full_replays", ctypes.c_uint64),
+    ]
+
+
+class SzgError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        msg = "%s failed: %d" % (where, code)
+        if detail:
+            msg += " (%s)" % detail
+        super().__init__(msg)
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "syzgydb_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C syzgydb_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp = ctypes.c_void_p
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    f64p = ctypes.POINTER(ctypes.c_double)
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    intp = ctypes.POINTER(ctypes.c_int)
+
+    L.szg_abi_version.restype = ctypes.c_int
+    L.szg_abi_version.argtypes = []
+    L.szg_strerror.restype = ctypes.c_char_p
+    L.szg_strerror.argtypes = [ctypes.c_int]
+    L.szg_last_error.restype = ctypes.c_char_p
+    L.szg_last_error.argtypes = []
+    L.szg_row_bytes.restype = ctypes.c_int64
+    L.szg_row_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.szg_index_create.restype = ctypes.c_int
+    L.szg_index_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   intp, ctypes.c_int]
+    L.szg_index_destroy.restype = None
+    L.szg_index_destroy.argtypes = [vp]
+    L.szg_index_load.restype = ctypes.c_int
+    L.szg_index_load.argtypes = [vp, u8p, ctypes.c_uint64]
+    L.szg_index_append.restype = ctypes.c_int
+    L.szg_index_append.argtypes = [vp, u8p, ctypes.c_uint64]
+    L.szg_index_overwrite.restype = ctypes.c_int
+    L.szg_index_overwrite.argtypes = [vp, ctypes.c_uint64, u8p]
+    L.szg_index_tombstone.restype = ctypes.c_int
+    L.szg_index_tombstone.argtypes = [vp, ctypes.c_uint64]
+    L.szg_index_rows.restype = ctypes.c_uint64
+    L.szg_index_rows.argtypes = [vp]
+    L.szg_index_live_rows.restype = ctypes.c_uint64
+    L.szg_index_live_rows.argtypes = [vp]
+    L.szg_index_read_rows.restype = ctypes.c_int
+    L.szg_index_read_rows.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, u8p]
+    L.szg_search_topk.restype = ctypes.c_int
+    L.szg_search_topk.argtypes = [vp, f64p, ctypes.c_int, ctypes.c_int, u64p, u64p, f64p, i32p]
+    L.szg_search_radius.restype = ctypes.c_int
+    L.szg_search_radius.argtypes = [vp, f64p, ctypes.c_double, u64p, u64p, f64p, ctypes.c_uint64,
+                                    u64p]
+    L.szg_set_timing.restype = ctypes.c_int
+    L.szg_set_timing.argtypes = [vp, ctypes.c_int]
+    L.szg_get_stats.restype = ctypes.c_int
+    L.szg_get_stats.argtypes = [vp, ctypes.POINTER(SzgStats)]
+    L.szg_reset_stats.restype = ctypes.c_int
+    L.szg_reset_stats.argtypes = [vp]
+    L.szg_set_option.restype = ctypes.c_int
+    L.szg_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
+    L.szg_index_synth.restype = ctypes.c_int
+    L.szg_index_synth.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
+    L.szg_index_set_row_base.restype = ctypes.c_int
+    L.szg_index_set_row_base.argtypes = [vp, ctypes.c_uint64]
+    L.szg_debug_f64_probe.restype = ctypes.c_int
+    L.szg_debug_f64_probe.argtypes = [ctypes.c_int, f64p, f64p, f64p, ctypes.c_uint64]
+    _lib = L
+    return L
+
+
+def check(code, where):
+    if code != SZG_OK:
+        L = load()
+        detail = L.szg_last_error().decode("utf-8", "replace")
+        if not detail:
+            detail = L.szg_strerror(code).decode()
+        raise SzgError(code, where, detail)

@@ -1,0 +1,201 @@
+"""Host-side mirror of the reference's Collection API for the search path.
+
+Same names, argument meaning and error behaviour as collection.go:
+CollectionOptions (:31-48), Document (:100-110), SearchArgs (:140-158),
+SearchResult/SearchResults (:115-135), Collection.AddDocument (:427-457),
+GetDocument (:463-484), UpdateDocument (:490-509), removeDocument (:511-521),
+Search (:569-711).  What differs is only WHERE the exact scan runs: the HOT
+LOOP (:672-684) is one call through the C ABI into the HIP library.
+
+Storage, the LSH index, REST, and the filter language stay in the reference
+and are out of scope here: documents live in host memory, and any Precision
+is answered by the exact scan (the reference's LSH path is unchanged Go code).
+"""
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from . import codec
+from .index import ScanIndex, pack_allow_bits
+
+Euclidean = 0  # collection.go:186-189
+Cosine = 1
+
+
+@dataclass
+class CollectionOptions:
+    """collection.go:31-48."""
+    Name: str = ""
+    DistanceMethod: int = Euclidean
+    DimensionCount: int = 0
+    Quantization: int = 0  # 0 -> 64, as NewCollection does (collection.go:254-256)
+
+
+@dataclass
+class Document:
+    ID: int
+    Vector: np.ndarray
+    Metadata: bytes
+
+
+@dataclass
+class SearchResult:
+    ID: int
+    Metadata: bytes
+    Distance: float = 0.0
+
+
+@dataclass
+class SearchResults:
+    Results: List[SearchResult] = field(default_factory=list)
+    PercentSearched: float = 0.0
+
+
+@dataclass
+class SearchArgs:
+    """collection.go:140-158."""
+    Vector: Optional[np.ndarray] = None
+    Filter: Optional[Callable[[int, bytes], bool]] = None
+    K: int = 0
+    Radius: float = 0.0
+    Offset: int = 0
+    Limit: int = 0
+    Precision: str = ""
+
+
+class Collection:
+    def __init__(self, options: CollectionOptions, devices=None):
+        if options.Quantization == 0:
+            options.Quantization = 64  # collection.go:254-256
+        if options.DistanceMethod not in (Euclidean, Cosine):
+            raise ValueError("unsupported distance method")  # collection.go:282
+        codec.vector_size(options.Quantization, options.DimensionCount)  # panics like :809
+        self.options = options
+        self.DimensionCount = options.DimensionCount
+        self.Quantization = options.Quantization
+        self.DistanceMethod = options.DistanceMethod
+        self._index = ScanIndex(self.DimensionCount, self.Quantization, self.DistanceMethod,
+                                devices=devices)
+        self._row_of = {}    # id -> row
+        self._id_of = []     # row -> id (None once tombstoned)
+        self._meta = []      # row -> metadata bytes
+        self._closed = False
+
+    # -- CRUD (host bookkeeping + mirror maintenance) ---------------------------
+    def AddDocument(self, id: int, vector, metadata: bytes = b""):
+        v = np.asarray(vector, dtype=np.float64).reshape(-1)
+        if v.size != self.DimensionCount:
+            # log.Panicf in the reference (collection.go:432-434)
+            raise ValueError("vector size does not match the expected number of dimensions: "
+                             "expected %d, got %d" % (self.DimensionCount, v.size))
+        row_bytes = codec.encode_rows(v.reshape(1, -1), self.Quantization)
+        id = int(id)
+        if id in self._row_of:  # WriteRecord of an existing id replaces the record
+            row = self._row_of[id]
+            self._index.overwrite(row, row_bytes)
+            self._meta[row] = bytes(metadata)
+        else:
+            self._index.append(row_bytes)
+            self._row_of[id] = len(self._id_of)
+            self._id_of.append(id)
+            self._meta.append(bytes(metadata))
+
+    def AddDocuments(self, ids, vectors, metadatas=None):
+        """Bulk ingest (not in the reference; same effect as AddDocument in a loop for new ids)."""
+        V = np.atleast_2d(np.asarray(vectors, dtype=np.float64))
+        if V.shape[1] != self.DimensionCount:
+            raise ValueError("vector size does not match the expected number of dimensions")
+        ids = [int(i) for i in ids]
+        if any(i in self._row_of for i in ids) or len(set(ids)) != len(ids):
+            for j, i in enumerate(ids):
+                self.AddDocument(i, V[j], metadatas[j] if metadatas else b"")
+            return
+        self._index.append(codec.encode_rows(V, self.Quantization))
+        for j, i in enumerate(ids):
+            self._row_of[i] = len(self._id_of)
+            self._id_of.append(i)
+            self._meta.append(bytes(metadatas[j]) if metadatas else b"")
+
+    def GetDocument(self, id: int) -> Document:
+        row = self._row_of.get(int(id))
+        if row is None:
+            raise KeyError("record not found")  # spanfile.go:516
+        data = self._index.read_rows(row, 1)
+        vec = codec.decode_rows(data, self.DimensionCount, self.Quantization)[0]
+        return Document(ID=int(id), Vector=vec, Metadata=self._meta[row])
+
+    def UpdateDocument(self, id: int, new_metadata: bytes):
+        row = self._row_of.get(int(id))
+        if row is None:
+            raise KeyError("record not found")
+        self._meta[row] = bytes(new_metadata)
+
+    def removeDocument(self, id: int):
+        row = self._row_of.pop(int(id), None)
+        if row is None:
+            raise KeyError("record not found")
+        self._index.tombstone(row)
+        self._id_of[row] = None
+        self._meta[row] = b""
+
+    def GetDocumentCount(self) -> int:
+        return len(self._row_of)
+
+    def GetAllIDs(self):
+        return sorted(self._row_of)
+
+    def Close(self):
+        if not self._closed:
+            self._index.close()
+            self._closed = True
+
+    # -- Search ---------------------------------------------------------------
+    def _allow_mask(self, flt):
+        if flt is None:
+            return None
+        mask = np.zeros(len(self._id_of), dtype=bool)
+        for row, id in enumerate(self._id_of):
+            if id is not None:
+                mask[row] = bool(flt(id, self._meta[row]))
+        return pack_allow_bits(mask)
+
+    def Search(self, args: SearchArgs) -> SearchResults:
+        """collection.go:569-711."""
+        n_records = len(self._row_of)
+        results: List[SearchResult] = []
+        points_searched = 0
+
+        if args.Radius == 0 and args.K == 0:
+            # listing mode (collection.go:633-669): sorted *string* id order
+            for id in sorted(self._row_of, key=lambda i: str(i)):
+                row = self._row_of[id]
+                if args.Filter is not None and not args.Filter(id, self._meta[row]):
+                    continue
+                points_searched += 1
+                if args.Offset > 0 and points_searched <= args.Offset:
+                    continue
+                results.append(SearchResult(ID=id, Metadata=self._meta[row]))
+                if args.Limit > 0 and len(results) >= args.Limit:
+                    break
+        else:
+            q = np.asarray(args.Vector, dtype=np.float64).reshape(-1)
+            if q.size != self.DimensionCount:
+                # undefined in the reference (collection.go:814, :823); rejected here
+                raise ValueError("query length %d != dimension %d" % (q.size, self.DimensionCount))
+            allow = self._allow_mask(args.Filter) if n_records else None
+            if n_records == 0:
+                rows, dist = [], []
+            elif args.Radius > 0:  # K is ignored (collection.go:598-605)
+                rows, dist = self._index.search_radius(q, args.Radius, allow=allow)
+            else:
+                r, d, c = self._index.search_topk(q, args.K, allow=allow)
+                rows, dist = r[0, : c[0]], d[0, : c[0]]
+            for row, dd in zip(rows, dist):
+                row = int(row)
+                results.append(SearchResult(ID=self._id_of[row], Metadata=self._meta[row],
+                                            Distance=float(dd)))
+            points_searched = n_records  # counted before the filter (collection.go:589)
+
+        percent = float(points_searched) / float(n_records) * 100 if n_records else 0.0
+        return SearchResults(Results=results, PercentSearched=percent)

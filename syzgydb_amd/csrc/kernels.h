@@ -1,0 +1,96 @@
+// kernels.h -- launch-side declarations shared by the HIP kernel files and the
+// C-ABI implementation (scan_api.cpp).  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace szg {
+
+constexpr int kEuclidean = 0;  // collection.go:186-189
+constexpr int kCosine = 1;
+
+// A candidate is one packed 64-bit word: (ordered key << 32) | local row.
+// Unsigned comparison of the word orders by key, ties by lower row.
+constexpr uint64_t kInvalidCand = 0xFFFFFFFFFFFFFFFFull;
+
+// float -> uint32 so that unsigned order == float order (NaN sorts last).
+__host__ __device__ inline uint32_t ordered_key(float f)
+{
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float key_from_ordered(uint32_t u)
+{
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+
+// How the 64 lanes of a wave are laid over rows of r16 16-byte pieces:
+// groups of L lanes take one row each, every lane P pieces of it.
+struct RowMap {
+    int r16;  // 16-byte pieces per (pitched) row
+    int L;    // lanes per row
+    int P;    // pieces per lane per row (L*P >= r16)
+    int gpw;  // rows (lane groups) per wave iteration
+};
+
+struct ScanArgs {
+    const uint8_t *rows;        // resident mirror: n_rows x pitch bytes, little-endian elements
+    uint32_t n_rows;
+    uint32_t pitch;             // bytes, multiple of 16
+    int dim;
+    RowMap map;
+    const uint64_t *live_bits;  // nullable: bit r == 0 -> tombstoned
+    const uint64_t *allow_bits; // nullable: bit r == 0 -> filtered out (collection.go:592)
+    const void *query;          // device, piece-swizzled (see prep_query in scan_api.cpp)
+    int kp;                     // candidates kept per list (top-k mode)
+    uint64_t *block_lists;      // [grid][kp] sorted ascending (top-k mode)
+    // collect mode (radius search / escalation): every row with key <= thr is appended
+    int collect;
+    uint32_t thr_ukey;
+    uint64_t *collect_buf;
+    uint32_t collect_cap;
+    uint32_t *collect_count;
+};
+
+// Fused dequantize + distance + select.  QBITS in {4,8,16,32,64}.
+hipError_t launch_scan(int qbits, int metric, const ScanArgs &a, int grid, int block,
+                       hipStream_t stream);
+// LDS bytes launch_scan needs for (qbits, map, kp, block)
+size_t scan_lds_bytes(int qbits, const RowMap &m, int kp, int block);
+
+// Merge n_lists sorted lists of kp candidates into ceil(n_lists/fan) lists.
+hipError_t launch_merge(const uint64_t *in, int n_lists, int kp, int fan, uint64_t *out,
+                        hipStream_t stream);
+
+struct RerankOut {
+    double dist;    // the reference's float64 distance (collection.go:812-832)
+    uint32_t row;   // local row
+    uint32_t ukey;  // the scan's ordered key for that row
+};
+
+// Exact float64 distances, reference operation order, for n candidates.
+hipError_t launch_rerank(int qbits, int metric, const uint8_t *rows, uint32_t pitch, int dim,
+                         const double *query_f64, const uint64_t *cands, const uint32_t *n_cands_dev,
+                         uint32_t n_cands_max, RerankOut *out, hipStream_t stream);
+
+// Page-in transform: reference row encoding (big-endian 16/32/64-bit) -> resident layout.
+hipError_t launch_repack(int qbits, const uint8_t *src, uint32_t row_bytes, uint8_t *dst,
+                         uint32_t pitch, uint64_t n_rows, int to_reference, hipStream_t stream);
+
+// Synthetic corpus directly in the resident layout (see szg_index_synth).
+hipError_t launch_synth(int qbits, uint8_t *dst, uint32_t pitch, int dim, uint64_t n_rows,
+                        uint64_t seed, uint64_t first_row, hipStream_t stream);
+
+// device float64 primitive probe (tests)
+hipError_t launch_f64_probe(int op, const double *a, const double *b, double *out, uint64_t n,
+                            hipStream_t stream);
+
+// live-bit maintenance
+hipError_t launch_fill_bits(uint64_t *bits, uint64_t n_rows, uint64_t n_words, hipStream_t stream);
+
+}  // namespace szg

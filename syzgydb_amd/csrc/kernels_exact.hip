@@ -1,0 +1,397 @@
+// kernels_exact.hip -- float64, reference-operation-order kernels for gfx950.
+// Compiled with -ffp-contract=off: Go on amd64 never fuses a*b+c, and the
+// reference's distances are sequential float64 sums (collection.go:812-832).
+//
+//  * rerank_kernel: for the handful of candidates the fused scan kept, decode
+//    the row exactly as decodeVector/dequantize do (collection.go:768-794,
+//    quantization.go:25-36) and evaluate the reference distance bit for bit.
+//  * synth_kernel: counter-based synthetic corpus, quantized and packed exactly
+//    as encodeDocument/quantize (collection.go:713-743, quantization.go:5-23).
+//  * repack_kernel: page-in transform between the reference's big-endian
+//    element encoding and the resident little-endian, 16-byte-pitched layout.
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace szg {
+
+namespace {
+
+// ---- Go math.Acos (asin.go / atan.go, Cephes), restated ---------------------
+
+__device__ double go_xatan(double x)
+{
+    const double P0 = -8.750608600031904122785e-01;
+    const double P1 = -1.615753718733365076637e+01;
+    const double P2 = -7.500855792314704667340e+01;
+    const double P3 = -1.228866684490136173410e+02;
+    const double P4 = -6.485021904942025371773e+01;
+    const double Q0 = +2.485846490142306297962e+01;
+    const double Q1 = +1.650270098316988542046e+02;
+    const double Q2 = +4.328810604912902668951e+02;
+    const double Q3 = +4.853903996359136964868e+02;
+    const double Q4 = +1.945506571482613964425e+02;
+    double z = __dmul_rn(x, x);
+    double num = __dadd_rn(__dmul_rn(P0, z), P1);
+    num = __dadd_rn(__dmul_rn(num, z), P2);
+    num = __dadd_rn(__dmul_rn(num, z), P3);
+    num = __dadd_rn(__dmul_rn(num, z), P4);
+    double den = __dadd_rn(z, Q0);
+    den = __dadd_rn(__dmul_rn(den, z), Q1);
+    den = __dadd_rn(__dmul_rn(den, z), Q2);
+    den = __dadd_rn(__dmul_rn(den, z), Q3);
+    den = __dadd_rn(__dmul_rn(den, z), Q4);
+    z = __ddiv_rn(__dmul_rn(z, num), den);
+    z = __dadd_rn(__dmul_rn(x, z), x);
+    return z;
+}
+
+__device__ double go_satan(double x)
+{
+    const double Morebits = 6.123233995736765886130e-17;
+    const double Tan3pio8 = 2.41421356237309504880;
+    const double PiO2 = 1.57079632679489661923132169163975144;
+    const double PiO4 = 0.785398163397448309615660845819875721;
+    if (x <= 0.66) return go_xatan(x);
+    if (x > Tan3pio8) return __dadd_rn(__dsub_rn(PiO2, go_xatan(__ddiv_rn(1.0, x))), Morebits);
+    return __dadd_rn(__dadd_rn(PiO4, go_xatan(__ddiv_rn(__dsub_rn(x, 1.0), __dadd_rn(x, 1.0)))),
+                     0.5 * Morebits);
+}
+
+__device__ double go_asin(double x)
+{
+    const double PiO2 = 1.57079632679489661923132169163975144;
+    if (x == 0) return x;
+    bool sign = false;
+    if (x < 0) {
+        x = -x;
+        sign = true;
+    }
+    if (x > 1) return __longlong_as_double(0x7FF8000000000001ll);  // math.NaN()
+    double temp = __dsqrt_rn(__dsub_rn(1.0, __dmul_rn(x, x)));
+    if (x > 0.7)
+        temp = __dsub_rn(PiO2, go_satan(__ddiv_rn(temp, x)));
+    else
+        temp = go_satan(__ddiv_rn(x, temp));
+    if (sign) temp = -temp;
+    return temp;
+}
+
+__device__ double go_acos(double x)
+{
+    const double PiO2 = 1.57079632679489661923132169163975144;
+    return __dsub_rn(PiO2, go_asin(x));
+}
+
+// ---- exact element decode (resident layout -> reference float64 value) ------
+
+template <int QBITS>
+__device__ __forceinline__ double decode_elem(const uint8_t *rp, int i)
+{
+    if (QBITS == 64) {
+        return reinterpret_cast<const double *>(rp)[i];
+    } else if (QBITS == 32) {
+        return (double)reinterpret_cast<const float *>(rp)[i];  // float64(Float32frombits)
+    } else {
+        uint32_t v;
+        if (QBITS == 16) {
+            v = reinterpret_cast<const uint16_t *>(rp)[i];
+        } else if (QBITS == 8) {
+            v = rp[i];
+        } else {
+            const uint8_t b = rp[i >> 1];
+            v = (i & 1) ? (b & 0x0Fu) : (b >> 4);  // collection.go:774-779
+        }
+        const double maxInt = (double)((1u << QBITS) - 1u);
+        // (float64(value)/float64(maxInt))*2 - 1, quantization.go:35
+        return __dsub_rn(__dmul_rn(__ddiv_rn((double)v, maxInt), 2.0), 1.0);
+    }
+}
+
+template <int QBITS, int METRIC>
+__global__ __launch_bounds__(64) void rerank_kernel(const uint8_t *rows, uint32_t pitch, int dim,
+                                                    const double *query, const uint64_t *cands,
+                                                    const uint32_t *n_dev, uint32_t n_max,
+                                                    RerankOut *out)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    double *drow = reinterpret_cast<double *>(smem);
+    double *qv = drow + dim;
+    const int lane = threadIdx.x;
+    uint32_t n = n_max;
+    if (n_dev) n = min(*n_dev, n_max);
+    for (int i = lane; i < dim; i += 64) qv[i] = query[i];
+    for (uint32_t ci = blockIdx.x; ci < n; ci += gridDim.x) {
+        // cands == nullptr: candidate ci is row ci (full exact replay of a shard)
+        const uint64_t c = cands ? cands[ci] : (uint64_t)ci;
+        if (c == kInvalidCand) {
+            if (lane == 0) {
+                RerankOut r;
+                r.dist = 0.0;
+                r.row = 0xFFFFFFFFu;
+                r.ukey = 0xFFFFFFFFu;
+                out[ci] = r;
+            }
+            continue;
+        }
+        const uint32_t row = (uint32_t)c;
+        const uint8_t *rp = rows + (uint64_t)row * pitch;
+        __syncthreads();
+        for (int i = lane; i < dim; i += 64) drow[i] = decode_elem<QBITS>(rp, i);
+        __syncthreads();
+        if (lane == 0) {
+            double dist;
+            if (METRIC == kEuclidean) {  // collection.go:812-819
+                double sum = 0.0;
+                for (int i = 0; i < dim; i++) {
+                    const double diff = __dsub_rn(qv[i], drow[i]);
+                    sum = __dadd_rn(sum, __dmul_rn(diff, diff));
+                }
+                dist = __dsqrt_rn(sum);
+            } else {  // collection.go:821-832
+                double dot = 0.0, m1 = 0.0, m2 = 0.0;
+                for (int i = 0; i < dim; i++) {
+                    const double x = qv[i], y = drow[i];
+                    dot = __dadd_rn(dot, __dmul_rn(x, y));
+                    m1 = __dadd_rn(m1, __dmul_rn(x, x));
+                    m2 = __dadd_rn(m2, __dmul_rn(y, y));
+                }
+                if (m1 == 0 || m2 == 0) {
+                    dist = 1.0;
+                } else {
+                    const double Pi = 3.14159265358979323846264338327950288;
+                    const double cosv = __ddiv_rn(dot, __dmul_rn(__dsqrt_rn(m1), __dsqrt_rn(m2)));
+                    dist = __ddiv_rn(go_acos(cosv), Pi);
+                }
+            }
+            RerankOut r;
+            r.dist = dist;
+            r.row = row;
+            r.ukey = cands ? (uint32_t)(c >> 32) : 0u;
+            out[ci] = r;
+        }
+    }
+}
+
+// ---- synthetic corpus ---------------------------------------------------------
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ double synth_value(uint64_t seed, uint64_t index)
+{
+    const uint64_t m = splitmix64(seed + index) >> 11;
+    return __dsub_rn(__dmul_rn((double)m, 1.0 / 4503599627370496.0), 1.0);
+}
+
+// quantization.go:5-23
+template <int QBITS>
+__device__ __forceinline__ uint64_t quantize(double value)
+{
+    if (QBITS == 32) return (uint64_t)__float_as_uint((float)value);
+    if (QBITS == 64) return (uint64_t)__double_as_longlong(value);
+    if (value < -1) value = -1; else if (value > 1) value = 1;
+    const double maxInt = (double)((1u << QBITS) - 1u);
+    const double q = __dmul_rn(__ddiv_rn(__dadd_rn(value, 1.0), 2.0), maxInt);
+    return (uint64_t)round(q);  // half away from zero, like math.Round
+}
+
+// one thread per 16-byte piece of the resident row
+template <int QBITS>
+__global__ void synth_kernel(uint8_t *dst, uint32_t pitch, int dim, uint64_t n_rows,
+                             uint64_t seed, uint64_t first_row)
+{
+    constexpr int E = 128 / QBITS;
+    const uint32_t r16 = pitch / 16;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t row = t / r16;
+    const uint32_t j = (uint32_t)(t - row * r16);
+    if (row >= n_rows) return;
+    uint32_t w[4] = {0, 0, 0, 0};
+    const uint64_t ebase = (first_row + row) * (uint64_t)dim;
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        const int e = (int)j * E + i;
+        if (e >= dim) break;
+        const uint64_t q = quantize<QBITS>(synth_value(seed, ebase + (uint64_t)e));
+        if (QBITS == 64) {
+            w[2 * i] = (uint32_t)q;
+            w[2 * i + 1] = (uint32_t)(q >> 32);
+        } else if (QBITS == 32) {
+            w[i] = (uint32_t)q;
+        } else if (QBITS == 16) {
+            w[i >> 1] |= (uint32_t)q << (16 * (i & 1));
+        } else if (QBITS == 8) {
+            w[i >> 2] |= (uint32_t)q << (8 * (i & 3));
+        } else {  // 4-bit: even element in the high nibble of byte i/2
+            const int b = i >> 1;
+            w[b >> 2] |= (uint32_t)(q & 0xF) << (8 * (b & 3) + ((i & 1) ? 0 : 4));
+        }
+    }
+    *reinterpret_cast<uint4 *>(dst + row * pitch + (uint64_t)j * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---- page-in transform --------------------------------------------------------
+// Byte b of an element of size es maps to byte es-1-b (big-endian <-> little-
+// endian); 4- and 8-bit rows are copied.  One thread per destination byte; the
+// aligned 32-bit fast path below covers every bench-sized case.
+
+__global__ void repack_bytes_kernel(const uint8_t *src, uint32_t src_pitch, uint8_t *dst,
+                                    uint32_t dst_pitch, uint32_t row_bytes, uint32_t es,
+                                    uint64_t n_rows)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t row = t / dst_pitch;
+    const uint32_t b = (uint32_t)(t - row * dst_pitch);
+    if (row >= n_rows) return;
+    uint8_t v = 0;
+    if (b < row_bytes) {
+        const uint32_t e = b / es, k = b - e * es;
+        v = src[row * src_pitch + (uint64_t)e * es + (es - 1 - k)];
+    }
+    dst[row * dst_pitch + b] = v;
+}
+
+// row_bytes % 16 == 0 and both pitches == row_bytes: pure streaming, 16 B per thread
+__global__ void repack_vec_kernel(const uint4 *src, uint4 *dst, uint64_t n_vec, uint32_t es)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_vec) return;
+    uint4 v = src[t];
+    if (es == 2) {
+        auto sw = [](uint32_t x) { return ((x & 0x00FF00FFu) << 8) | ((x >> 8) & 0x00FF00FFu); };
+        v = make_uint4(sw(v.x), sw(v.y), sw(v.z), sw(v.w));
+    } else if (es == 4) {
+        v = make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y), __builtin_bswap32(v.z),
+                       __builtin_bswap32(v.w));
+    } else if (es == 8) {
+        v = make_uint4(__builtin_bswap32(v.y), __builtin_bswap32(v.x), __builtin_bswap32(v.w),
+                       __builtin_bswap32(v.z));
+    }
+    dst[t] = v;
+}
+
+__global__ void fill_bits_kernel(uint64_t *bits, uint64_t n_rows, uint64_t n_words)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_words) return;
+    const uint64_t lo = t * 64;
+    uint64_t v = 0;
+    if (lo + 64 <= n_rows) v = ~0ull;
+    else if (lo < n_rows) v = (1ull << (n_rows - lo)) - 1ull;
+    bits[t] = v;
+}
+
+// device-side float64 primitive probe (tests: bit-exactness of div/sqrt/acos)
+__global__ void f64_probe_kernel(int op, const double *a, const double *b, double *out, uint64_t n)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double r;
+    switch (op) {
+    case 0: r = __ddiv_rn(a[t], b[t]); break;
+    case 1: r = __dsqrt_rn(a[t]); break;
+    case 2: r = go_acos(a[t]); break;
+    case 3: r = round(a[t]); break;
+    default: r = (double)(float)a[t]; break;
+    }
+    out[t] = r;
+}
+
+template <int QBITS>
+hipError_t launch_rerank_q(int metric, const uint8_t *rows, uint32_t pitch, int dim,
+                           const double *q, const uint64_t *cands, const uint32_t *n_dev,
+                           uint32_t n_max, RerankOut *out, hipStream_t stream)
+{
+    if (n_max == 0) return hipSuccess;
+    const int grid = (int)(n_max < 4096u ? n_max : 4096u);
+    const size_t lds = (size_t)dim * 2 * sizeof(double);
+    if (metric == kCosine)
+        hipLaunchKernelGGL((rerank_kernel<QBITS, kCosine>), dim3(grid), dim3(64), lds, stream, rows,
+                           pitch, dim, q, cands, n_dev, n_max, out);
+    else
+        hipLaunchKernelGGL((rerank_kernel<QBITS, kEuclidean>), dim3(grid), dim3(64), lds, stream,
+                           rows, pitch, dim, q, cands, n_dev, n_max, out);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_rerank(int qbits, int metric, const uint8_t *rows, uint32_t pitch, int dim,
+                         const double *q, const uint64_t *cands, const uint32_t *n_dev,
+                         uint32_t n_max, RerankOut *out, hipStream_t stream)
+{
+    switch (qbits) {
+    case 4: return launch_rerank_q<4>(metric, rows, pitch, dim, q, cands, n_dev, n_max, out, stream);
+    case 8: return launch_rerank_q<8>(metric, rows, pitch, dim, q, cands, n_dev, n_max, out, stream);
+    case 16: return launch_rerank_q<16>(metric, rows, pitch, dim, q, cands, n_dev, n_max, out, stream);
+    case 32: return launch_rerank_q<32>(metric, rows, pitch, dim, q, cands, n_dev, n_max, out, stream);
+    case 64: return launch_rerank_q<64>(metric, rows, pitch, dim, q, cands, n_dev, n_max, out, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_repack(int qbits, const uint8_t *src, uint32_t row_bytes, uint8_t *dst,
+                         uint32_t pitch, uint64_t n_rows, int to_reference, hipStream_t stream)
+{
+    if (n_rows == 0) return hipSuccess;
+    const uint32_t es = qbits <= 8 ? 1u : (uint32_t)qbits / 8u;
+    if (row_bytes == pitch && (row_bytes % 16) == 0) {
+        const uint64_t n_vec = n_rows * (row_bytes / 16);
+        const uint64_t grid = (n_vec + 255) / 256;
+        hipLaunchKernelGGL(repack_vec_kernel, dim3((unsigned)grid), dim3(256), 0, stream,
+                           reinterpret_cast<const uint4 *>(src), reinterpret_cast<uint4 *>(dst),
+                           n_vec, es);
+        return hipGetLastError();
+    }
+    const uint32_t src_pitch = to_reference ? pitch : row_bytes;
+    const uint32_t dst_pitch = to_reference ? row_bytes : pitch;
+    const uint64_t total = n_rows * dst_pitch;
+    const uint64_t grid = (total + 255) / 256;
+    hipLaunchKernelGGL(repack_bytes_kernel, dim3((unsigned)grid), dim3(256), 0, stream, src,
+                       src_pitch, dst, dst_pitch, row_bytes, es, n_rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(int qbits, uint8_t *dst, uint32_t pitch, int dim, uint64_t n_rows,
+                        uint64_t seed, uint64_t first_row, hipStream_t stream)
+{
+    if (n_rows == 0) return hipSuccess;
+    const uint64_t total = n_rows * (pitch / 16);
+    const uint64_t grid = (total + 255) / 256;
+    const dim3 g((unsigned)grid), b(256);
+    switch (qbits) {
+    case 4: hipLaunchKernelGGL(synth_kernel<4>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row); break;
+    case 8: hipLaunchKernelGGL(synth_kernel<8>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row); break;
+    case 16: hipLaunchKernelGGL(synth_kernel<16>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row); break;
+    case 32: hipLaunchKernelGGL(synth_kernel<32>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row); break;
+    case 64: hipLaunchKernelGGL(synth_kernel<64>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_bits(uint64_t *bits, uint64_t n_rows, uint64_t n_words, hipStream_t stream)
+{
+    if (n_words == 0) return hipSuccess;
+    const uint64_t grid = (n_words + 255) / 256;
+    hipLaunchKernelGGL(fill_bits_kernel, dim3((unsigned)grid), dim3(256), 0, stream, bits, n_rows,
+                       n_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_f64_probe(int op, const double *a, const double *b, double *out, uint64_t n,
+                            hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t grid = (n + 255) / 256;
+    hipLaunchKernelGGL(f64_probe_kernel, dim3((unsigned)grid), dim3(256), 0, stream, op, a, b, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace szg

@@ -1,0 +1,1293 @@
+// scan_api.cpp -- implementation of include/syzgy_scan.h (the C ABI).
+//
+// Host side of the drop-in: owns the HBM mirror of a Collection's packed
+// vectors, runs the per-query pipeline
+//     H2D query -> fused scan -> list merges -> float64 rerank -> D2H
+// on pooled HIP streams, then does the reference's result assembly on the few
+// survivors: certification of the candidate set, the container/heap replay of
+// consider() (collection.go:598-619) and the ascending pop loop (:694-697).
+//
+// There is no CPU scan in here: without a usable gfx950 device every entry
+// point fails with SZG_E_NODEVICE.
+#include "../../include/syzgy_scan.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    else
+        snprintf(buf, sizeof(buf), "%s", what);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                    \
+    do {                                                                \
+        hipError_t e__ = (expr);                                        \
+        if (e__ != hipSuccess) return fail(SZG_E_DEVICE, #expr, e__);   \
+    } while (0)
+
+int64_t row_bytes_of(int bits, int dim)
+{   // getVectorSize, collection.go:796-811
+    switch (bits) {
+    case 4: return ((int64_t)dim + 1) / 2;
+    case 8: return dim;
+    case 16: return (int64_t)dim * 2;
+    case 32: return (int64_t)dim * 4;
+    case 64: return (int64_t)dim * 8;
+    default: return -1;
+    }
+}
+
+// ---- container/heap replay (Go stdlib heap.Push / heap.Pop over the
+// resultPriorityQueue of collection.go:536-564: max-heap on distance) ---------
+struct HeapItem {
+    uint64_t row;
+    double priority;
+};
+struct GoHeap {
+    std::vector<HeapItem> a;
+    bool less(size_t i, size_t j) const { return a[i].priority > a[j].priority; }
+    void up(size_t j)
+    {
+        for (;;) {
+            const size_t i = j == 0 ? 0 : (j - 1) / 2;
+            if (i == j || !less(j, i)) break;
+            std::swap(a[i], a[j]);
+            j = i;
+        }
+    }
+    void down(size_t i0, size_t n)
+    {
+        size_t i = i0;
+        for (;;) {
+            const size_t j1 = 2 * i + 1;
+            if (j1 >= n) break;
+            size_t j = j1;
+            const size_t j2 = j1 + 1;
+            if (j2 < n && less(j2, j1)) j = j2;
+            if (!less(j, i)) break;
+            std::swap(a[i], a[j]);
+            i = j;
+        }
+    }
+    void push(const HeapItem &it)
+    {
+        a.push_back(it);
+        up(a.size() - 1);
+    }
+    HeapItem pop()
+    {
+        const size_t n = a.size() - 1;
+        std::swap(a[0], a[n]);
+        down(0, n);
+        HeapItem it = a[n];
+        a.pop_back();
+        return it;
+    }
+};
+
+struct Cand {
+    uint64_t row;  // global row
+    double dist;   // reference float64 distance
+    float key;     // the scan's ranking key for this row
+};
+
+// ---- one in-flight query on one shard ------------------------------------------
+struct Ctx {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr, ev_all0 = nullptr, ev_all1 = nullptr;
+    // pinned host staging
+    uint8_t *h_qsw = nullptr;      // swizzled query for the scan
+    double *h_q64 = nullptr;       // float64 query for the rerank
+    szg::RerankOut *h_out = nullptr;
+    size_t h_out_cap = 0;
+    uint32_t *h_count = nullptr;
+    // device scratch
+    uint8_t *d_qsw = nullptr;
+    double *d_q64 = nullptr;
+    uint64_t *d_lists_a = nullptr, *d_lists_b = nullptr;
+    size_t lists_cap = 0;          // entries per buffer
+    szg::RerankOut *d_out = nullptr;
+    size_t d_out_cap = 0;
+    uint64_t *d_allow = nullptr;
+    size_t allow_cap = 0;          // words
+    uint64_t *d_collect = nullptr;
+    size_t collect_cap = 0;        // entries
+    uint32_t *d_count = nullptr;
+    bool timed_scan = false;
+};
+
+struct Shard {
+    int device = 0;
+    uint64_t first = 0;        // index-level row of this shard's row 0
+    uint64_t n_rows = 0;
+    uint64_t cap_rows = 0;
+    uint64_t n_live = 0;
+    uint8_t *rows = nullptr;
+    uint64_t *live_bits = nullptr;
+    uint64_t bits_cap = 0;     // words
+    bool has_dead = false;
+    int cu_count = 256;
+    std::vector<Ctx *> free_ctx;
+    std::vector<Ctx *> all_ctx;
+    std::mutex mu;
+    std::condition_variable cv;
+};
+
+}  // namespace
+
+struct szg_index {
+    int dim = 0, bits = 0, metric = 0;
+    uint32_t row_bytes = 0, pitch = 0;
+    szg::RowMap map{};
+    size_t qsw_bytes = 0;
+    uint64_t row_base = 0;
+    std::vector<Shard *> shards;
+    // tunables
+    int slack_min = 16;
+    int n_ctx = 3;
+    int blocks_per_cu = 2;
+    int block_threads = 512;
+    int force_escalate = 0;   // test hook: treat every first pass as uncertified
+    int tie_mode = 0;         // 0: exact full replay on ties/NaN, 1: keep the fast answer
+    bool timing = false;
+    std::mutex stats_mu;
+    szg_stats stats{};
+};
+
+namespace {
+
+szg::RowMap choose_map(int r16)
+{   // groups of L lanes per row, P pieces per lane: maximise lane utilisation
+    szg::RowMap best{r16, 64, (r16 + 63) / 64, 1};
+    double best_util = -1;
+    const int pmax = std::max(1, (r16 + 63) / 64 + 8);
+    for (int P = 1; P <= pmax; P++) {
+        const int L = (r16 + P - 1) / P;
+        if (L > 64) continue;
+        const int gpw = 64 / L;
+        const double util = (double)gpw * r16 / (64.0 * P);
+        if (util > best_util + 1e-9) {
+            best_util = util;
+            best = szg::RowMap{r16, L, P, gpw};
+        }
+    }
+    return best;
+}
+
+// Query as the scan wants it: float (double for 64-bit rows), pre-normalised for
+// cosine, pre-scaled by maxInt for quantized euclid, laid out [chunk][piece][4].
+void prep_query(const szg_index *ix, const double *q, uint8_t *out_sw, double *scaled_norm,
+                double *m1_out)
+{
+    const int dim = ix->dim, bits = ix->bits;
+    const int E = 128 / bits;
+    const int r16 = ix->map.r16;
+    memset(out_sw, 0, ix->qsw_bytes);
+    double m1 = 0.0;
+    for (int i = 0; i < dim; i++) m1 += q[i] * q[i];
+    *m1_out = m1;
+    double scale = 1.0;
+    if (ix->metric == SZG_COSINE) {
+        scale = m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0;
+    } else if (bits <= 16) {
+        scale = (double)((1u << bits) - 1u);
+    }
+    double nrm = 0.0;
+    for (int e = 0; e < dim; e++) {
+        const double v = q[e] * scale;
+        nrm += v * v;
+        const int j = e / E, i = e % E;
+        if (bits == 64) {
+            reinterpret_cast<double *>(out_sw)[(size_t)j * 2 + i] = v;
+        } else {
+            const int c = i / 4, m = i % 4;
+            reinterpret_cast<float *>(out_sw)[((size_t)c * r16 + j) * 4 + m] = (float)v;
+        }
+    }
+    *scaled_norm = std::sqrt(nrm);
+}
+
+// Bound on |scan key - real-number key| (see DESIGN.md "certification").
+double key_eps(const szg_index *ix, double key, double qnorm)
+{
+    const double u = ix->bits == 64 ? 0x1p-53 : 0x1p-24;
+    const double n = (double)ix->dim + 16.0;
+    if (ix->metric == SZG_COSINE) {
+        return 2.0 * n * u + (ix->bits == 64 ? 0x1p-22 : 0.0);
+    }
+    const double k = std::fabs(key);
+    return 2.0 * n * u * k + 8.0 * u * qnorm * std::sqrt(k) + (ix->bits == 64 ? 0x1p-22 * k : 0.0) +
+           1e-37;
+}
+
+int ctx_alloc(szg_index *ix, Shard *sh, Ctx **out)
+{
+    Ctx *c = new Ctx();
+    HIPCHK(hipSetDevice(sh->device));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&c->ev_scan0));
+    HIPCHK(hipEventCreate(&c->ev_scan1));
+    HIPCHK(hipEventCreate(&c->ev_all0));
+    HIPCHK(hipEventCreate(&c->ev_all1));
+    HIPCHK(hipHostMalloc((void **)&c->h_qsw, ix->qsw_bytes, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&c->h_q64, sizeof(double) * ix->dim, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&c->h_count, sizeof(uint32_t) * 4, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&c->d_qsw, ix->qsw_bytes));
+    HIPCHK(hipMalloc((void **)&c->d_q64, sizeof(double) * ix->dim));
+    HIPCHK(hipMalloc((void **)&c->d_count, sizeof(uint32_t) * 4));
+    *out = c;
+    return SZG_OK;
+}
+
+void ctx_free(Ctx *c)
+{
+    if (!c) return;
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (hipEvent_t e : {c->ev_scan0, c->ev_scan1, c->ev_all0, c->ev_all1})
+        if (e) (void)hipEventDestroy(e);
+    (void)hipHostFree(c->h_qsw);
+    (void)hipHostFree(c->h_q64);
+    (void)hipHostFree(c->h_out);
+    (void)hipHostFree(c->h_count);
+    (void)hipFree(c->d_qsw);
+    (void)hipFree(c->d_q64);
+    (void)hipFree(c->d_lists_a);
+    (void)hipFree(c->d_lists_b);
+    (void)hipFree(c->d_out);
+    (void)hipFree(c->d_allow);
+    (void)hipFree(c->d_collect);
+    (void)hipFree(c->d_count);
+    delete c;
+}
+
+Ctx *ctx_acquire(Shard *sh)
+{
+    std::unique_lock<std::mutex> lk(sh->mu);
+    sh->cv.wait(lk, [&] { return !sh->free_ctx.empty(); });
+    Ctx *c = sh->free_ctx.back();
+    sh->free_ctx.pop_back();
+    return c;
+}
+Ctx *ctx_try_acquire(Shard *sh)
+{
+    std::lock_guard<std::mutex> lk(sh->mu);
+    if (sh->free_ctx.empty()) return nullptr;
+    Ctx *c = sh->free_ctx.back();
+    sh->free_ctx.pop_back();
+    return c;
+}
+void ctx_release(Shard *sh, Ctx *c)
+{
+    {
+        std::lock_guard<std::mutex> lk(sh->mu);
+        sh->free_ctx.push_back(c);
+    }
+    sh->cv.notify_one();
+}
+
+template <typename T>
+int ensure_dev(T **p, size_t *cap, size_t need)
+{
+    if (*cap >= need) return SZG_OK;
+    if (*p) HIPCHK(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    size_t n = std::max(need, (size_t)64);
+    HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
+    *cap = n;
+    return SZG_OK;
+}
+template <typename T>
+int ensure_host(T **p, size_t *cap, size_t need)
+{
+    if (*cap >= need) return SZG_OK;
+    if (*p) HIPCHK(hipHostFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    size_t n = std::max(need, (size_t)64);
+    HIPCHK(hipHostMalloc((void **)p, n * sizeof(T), hipHostMallocDefault));
+    *cap = n;
+    return SZG_OK;
+}
+
+struct LaunchGeom {
+    int grid, block;
+};
+
+LaunchGeom scan_geometry(const szg_index *ix, const Shard *sh, int kp)
+{
+    int block = ix->block_threads;
+    // keep the per-wave lists within ~96 KiB of LDS next to the query
+    while (block > 64 && szg::scan_lds_bytes(ix->bits, ix->map, kp, block) > 64u * 1024u) block >>= 1;
+    const int nwaves = block / 64;
+    const uint64_t rows_per_block = (uint64_t)nwaves * ix->map.gpw;
+    uint64_t need = (sh->n_rows + rows_per_block - 1) / rows_per_block;
+    uint64_t grid = (uint64_t)sh->cu_count * ix->blocks_per_cu;
+    if (need < grid) grid = need;
+    if (grid < 1) grid = 1;
+    return LaunchGeom{(int)grid, block};
+}
+
+// Enqueue H2D of the query (+ mask) on the ctx stream.
+int enqueue_query(szg_index *ix, Shard *sh, Ctx *c, const double *q, const uint64_t *allow_words)
+{
+    HIPCHK(hipSetDevice(sh->device));
+    memcpy(c->h_q64, q, sizeof(double) * ix->dim);
+    if (ix->timing) HIPCHK(hipEventRecord(c->ev_all0, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_qsw, c->h_qsw, ix->qsw_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_q64, c->h_q64, sizeof(double) * ix->dim, hipMemcpyHostToDevice,
+                          c->stream));
+    if (allow_words) {
+        const size_t words = (sh->n_rows + 63) / 64;
+        int rc = ensure_dev(&c->d_allow, &c->allow_cap, words);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->d_allow, allow_words + sh->first / 64, words * sizeof(uint64_t),
+                              hipMemcpyHostToDevice, c->stream));
+    }
+    return SZG_OK;
+}
+
+void fill_scan_args(const szg_index *ix, const Shard *sh, const Ctx *c, bool has_allow,
+                    szg::ScanArgs *a)
+{
+    memset(a, 0, sizeof(*a));
+    a->rows = sh->rows;
+    a->n_rows = (uint32_t)sh->n_rows;
+    a->pitch = ix->pitch;
+    a->dim = ix->dim;
+    a->map = ix->map;
+    a->live_bits = sh->has_dead ? sh->live_bits : nullptr;
+    a->allow_bits = has_allow ? c->d_allow : nullptr;
+    a->query = c->d_qsw;
+}
+
+int record_scan(szg_index *ix, Ctx *c, bool before)
+{
+    if (!ix->timing) return SZG_OK;
+    HIPCHK(hipEventRecord(before ? c->ev_scan0 : c->ev_scan1, c->stream));
+    if (!before) c->timed_scan = true;
+    return SZG_OK;
+}
+
+void account_scan(szg_index *ix, const Shard *sh)
+{
+    std::lock_guard<std::mutex> lk(ix->stats_mu);
+    ix->stats.scan_launches++;
+    ix->stats.scan_bytes += sh->n_rows * (uint64_t)ix->row_bytes;
+}
+
+// top-k pass on one shard: scan -> merges -> rerank -> D2H (all async)
+int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, bool has_allow)
+{
+    HIPCHK(hipSetDevice(sh->device));
+    const LaunchGeom g = scan_geometry(ix, sh, kp);
+    int rc = SZG_OK;
+    if (c->lists_cap < (size_t)g.grid * kp) {  // both ping-pong buffers grow together
+        if (c->d_lists_a) HIPCHK(hipFree(c->d_lists_a));
+        if (c->d_lists_b) HIPCHK(hipFree(c->d_lists_b));
+        c->d_lists_a = c->d_lists_b = nullptr;
+        c->lists_cap = 0;
+        const size_t n = (size_t)g.grid * kp;
+        HIPCHK(hipMalloc((void **)&c->d_lists_a, n * sizeof(uint64_t)));
+        HIPCHK(hipMalloc((void **)&c->d_lists_b, n * sizeof(uint64_t)));
+        c->lists_cap = n;
+    }
+    rc = ensure_dev(&c->d_out, &c->d_out_cap, (size_t)kp);
+    if (rc) return rc;
+    rc = ensure_host(&c->h_out, &c->h_out_cap, (size_t)kp);
+    if (rc) return rc;
+
+    szg::ScanArgs a;
+    fill_scan_args(ix, sh, c, has_allow, &a);
+    a.kp = kp;
+    a.block_lists = c->d_lists_a;
+    rc = record_scan(ix, c, true);
+    if (rc) return rc;
+    HIPCHK(szg::launch_scan(ix->bits, ix->metric, a, g.grid, g.block, c->stream));
+    rc = record_scan(ix, c, false);
+    if (rc) return rc;
+    account_scan(ix, sh);
+
+    int n_lists = g.grid;
+    uint64_t *src = c->d_lists_a, *dst = c->d_lists_b;
+    const int fan = std::max(2, std::min(32, 8192 / kp));
+    while (n_lists > 1) {
+        HIPCHK(szg::launch_merge(src, n_lists, kp, fan, dst, c->stream));
+        n_lists = (n_lists + fan - 1) / fan;
+        std::swap(src, dst);
+    }
+    HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64, src,
+                              nullptr, (uint32_t)kp, c->d_out, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp, hipMemcpyDeviceToHost,
+                          c->stream));
+    if (ix->timing) HIPCHK(hipEventRecord(c->ev_all1, c->stream));
+    return SZG_OK;
+}
+
+int finish_timing(szg_index *ix, Ctx *c)
+{
+    if (!ix->timing) return SZG_OK;
+    float ms_scan = 0, ms_all = 0;
+    if (c->timed_scan) HIPCHK(hipEventElapsedTime(&ms_scan, c->ev_scan0, c->ev_scan1));
+    HIPCHK(hipEventElapsedTime(&ms_all, c->ev_all0, c->ev_all1));
+    std::lock_guard<std::mutex> lk(ix->stats_mu);
+    if (c->timed_scan) {
+        ix->stats.scan_ms += ms_scan;
+        ix->stats.timed_launches++;
+    }
+    ix->stats.total_ms += ms_all;
+    c->timed_scan = false;
+    return SZG_OK;
+}
+
+// wait for a top-k pass, append its candidates; returns threshold key of the
+// shard (the worst kept key if the list is full, +inf if every row is in it)
+int collect_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, std::vector<Cand> *cands, double *thr)
+{
+    HIPCHK(hipSetDevice(sh->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = finish_timing(ix, c);
+    if (rc) return rc;
+    int valid = 0;
+    float worst = -INFINITY;
+    for (int i = 0; i < kp; i++) {
+        const szg::RerankOut &r = c->h_out[i];
+        if (r.row == 0xFFFFFFFFu) continue;
+        valid++;
+        const float key = szg::key_from_ordered(r.ukey);
+        worst = std::max(worst, key);
+        cands->push_back(Cand{sh->first + r.row, r.dist, key});
+    }
+    *thr = valid == kp ? (double)worst : INFINITY;
+    return SZG_OK;
+}
+
+// collect pass (radius search / escalation): every row with key <= thr_key,
+// reranked exactly.  Synchronous; grows the buffer and reruns on overflow.
+int run_collect(szg_index *ix, Shard *sh, Ctx *c, float thr_key, bool has_allow,
+                std::vector<Cand> *cands)
+{
+    HIPCHK(hipSetDevice(sh->device));
+    if (sh->n_rows == 0) return SZG_OK;
+    size_t want = std::max<size_t>(c->collect_cap, 1u << 16);
+    for (;;) {
+        int rc = ensure_dev(&c->d_collect, &c->collect_cap, want);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(uint32_t), c->stream));
+        szg::ScanArgs a;
+        fill_scan_args(ix, sh, c, has_allow, &a);
+        a.collect = 1;
+        a.thr_ukey = szg::ordered_key(thr_key);
+        a.collect_buf = c->d_collect;
+        a.collect_cap = (uint32_t)std::min<size_t>(c->collect_cap, 0xFFFFFFFFu);
+        a.collect_count = c->d_count;
+        const LaunchGeom g = scan_geometry(ix, sh, 0);
+        rc = record_scan(ix, c, true);
+        if (rc) return rc;
+        HIPCHK(szg::launch_scan(ix->bits, ix->metric, a, g.grid, g.block, c->stream));
+        rc = record_scan(ix, c, false);
+        if (rc) return rc;
+        account_scan(ix, sh);
+        HIPCHK(hipMemcpyAsync(c->h_count, c->d_count, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                              c->stream));
+        if (ix->timing) HIPCHK(hipEventRecord(c->ev_all1, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        rc = finish_timing(ix, c);
+        if (rc) return rc;
+        const uint32_t count = c->h_count[0];
+        if (count > c->collect_cap) {
+            want = (size_t)count + count / 8 + 1024;
+            if (ix->timing) HIPCHK(hipEventRecord(c->ev_all0, c->stream));
+            continue;
+        }
+        if (count == 0) return SZG_OK;
+        rc = ensure_dev(&c->d_out, &c->d_out_cap, (size_t)count);
+        if (rc) return rc;
+        rc = ensure_host(&c->h_out, &c->h_out_cap, (size_t)count);
+        if (rc) return rc;
+        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64,
+                                  c->d_collect, nullptr, count, c->d_out, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * count,
+                              hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        cands->reserve(cands->size() + count);
+        for (uint32_t i = 0; i < count; i++) {
+            const szg::RerankOut &r = c->h_out[i];
+            cands->push_back(Cand{sh->first + r.row, r.dist, szg::key_from_ordered(r.ukey)});
+        }
+        return SZG_OK;
+    }
+}
+
+// consider()'s top-k branch replayed over the candidates in visit order
+// (collection.go:606-619), then the ascending pop loop (:694-697).
+void replay_topk(std::vector<Cand> &cands, int k, std::vector<HeapItem> *result)
+{
+    std::sort(cands.begin(), cands.end(), [](const Cand &x, const Cand &y) { return x.row < y.row; });
+    GoHeap h;
+    for (const Cand &c : cands) {
+        if ((int)h.a.size() <= k) {
+            if ((int)h.a.size() < k || h.a[0].priority > c.dist) {
+                h.push(HeapItem{c.row, c.dist});
+                if ((int)h.a.size() > k) h.pop();
+            }
+        }
+    }
+    result->assign(h.a.size(), HeapItem{});
+    for (size_t i = result->size(); i-- > 0;) (*result)[i] = h.pop();
+}
+
+// True when the reference's answer may depend on its whole heap history: a NaN
+// distance, or two exactly equal distances among the best k+1 candidates.
+bool history_dependent(const std::vector<Cand> &cands, int k)
+{
+    std::vector<double> d;
+    d.reserve(cands.size());
+    for (const Cand &c : cands) {
+        if (std::isnan(c.dist)) return true;
+        d.push_back(c.dist);
+    }
+    const size_t m = std::min(d.size(), (size_t)k + 1);
+    std::partial_sort(d.begin(), d.begin() + m, d.end());
+    for (size_t i = 1; i < m; i++)
+        if (d[i] == d[i - 1]) return true;
+    return false;
+}
+
+// Exact replay of the reference loop over EVERY row (collection.go:672-684 with
+// consider(), :583-629): float64 distances for all rows on the device, then the
+// heap on the host in visit order.  Bit-faithful in every case, used only when
+// history_dependent() says the fast answer could differ.
+int run_full_replay(szg_index *ix, std::vector<Ctx *> &ctx, const uint64_t *allow, int k,
+                    std::vector<HeapItem> *res)
+{
+    GoHeap h;
+    for (size_t s = 0; s < ix->shards.size(); s++) {
+        Shard *sh = ix->shards[s];
+        if (sh->n_rows == 0) continue;
+        Ctx *c = ctx[s];
+        HIPCHK(hipSetDevice(sh->device));
+        const size_t n = sh->n_rows;
+        int rc = ensure_dev(&c->d_out, &c->d_out_cap, n);
+        if (rc) return rc;
+        rc = ensure_host(&c->h_out, &c->h_out_cap, n);
+        if (rc) return rc;
+        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64,
+                                  nullptr, nullptr, (uint32_t)n, c->d_out, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * n, hipMemcpyDeviceToHost,
+                              c->stream));
+        std::vector<uint64_t> live((n + 63) / 64, ~0ull);
+        if (sh->has_dead)
+            HIPCHK(hipMemcpyAsync(live.data(), sh->live_bits, live.size() * sizeof(uint64_t),
+                                  hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const uint64_t *aw = allow ? allow + sh->first / 64 : nullptr;
+        for (size_t r = 0; r < n; r++) {
+            if (!((live[r >> 6] >> (r & 63)) & 1)) continue;       // removed record
+            if (aw && !((aw[r >> 6] >> (r & 63)) & 1)) continue;   // collection.go:592-594
+            const double dist = c->h_out[r].dist;
+            if ((int)h.a.size() <= k) {                            // collection.go:606-619
+                if ((int)h.a.size() < k || h.a[0].priority > dist) {
+                    h.push(HeapItem{sh->first + r, dist});
+                    if ((int)h.a.size() > k) h.pop();
+                }
+            }
+        }
+    }
+    res->assign(h.a.size(), HeapItem{});
+    for (size_t i = res->size(); i-- > 0;) (*res)[i] = h.pop();
+    return SZG_OK;
+}
+
+struct Ticket {
+    int query = -1;
+    std::vector<Ctx *> ctx;  // one per shard
+    double qnorm = 0, m1 = 0;
+    int kp = 0;
+};
+
+int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
+                     const uint64_t *allow_bits, uint64_t *out_rows, double *out_dist,
+                     int32_t *out_count)
+{
+    const size_t n_sh = ix->shards.size();
+    uint64_t total_rows = 0;
+    for (Shard *s : ix->shards) total_rows += s->n_rows;
+    const size_t allow_stride = (total_rows + 63) / 64;
+    const int kp = k + std::max(ix->slack_min, k / 2);
+    for (Shard *s : ix->shards) {
+        if (s->n_rows == 0) continue;
+        const LaunchGeom g = scan_geometry(ix, s, kp);
+        if (szg::scan_lds_bytes(ix->bits, ix->map, kp, g.block) > 64u * 1024u || kp > 4096)
+            return fail(SZG_E_UNSUPPORTED, "k too large for the fused selection (LDS)");
+    }
+
+    auto finish = [&](Ticket &t) -> int {
+        const int qi = t.query;
+        const uint64_t *allow = allow_bits ? allow_bits + (size_t)qi * allow_stride : nullptr;
+        std::vector<Cand> cands;
+        double thr_min = INFINITY;
+        int rc = SZG_OK;
+        for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
+            Shard *sh = ix->shards[s];
+            if (sh->n_rows == 0) continue;
+            double thr;
+            rc = collect_topk(ix, sh, t.ctx[s], t.kp, &cands, &thr);
+            thr_min = std::min(thr_min, thr);
+        }
+        std::vector<HeapItem> res;
+        if (rc == SZG_OK) {
+            replay_topk(cands, k, &res);
+            // certification: every row outside the lists has scan key >= thr_min, so
+            // the result is final once its worst key clears thr_min by the error bound
+            bool certified = true;
+            float kmax = -INFINITY;
+            const bool zero_query = ix->metric == SZG_COSINE && t.m1 == 0;  // all distances 1.0
+            if (std::isfinite(thr_min) && !zero_query) {
+                std::vector<std::pair<uint64_t, float>> by_row;  // cands are sorted by row now
+                by_row.reserve(cands.size());
+                for (const Cand &c : cands) by_row.emplace_back(c.row, c.key);
+                for (const HeapItem &h : res) {
+                    auto it = std::lower_bound(by_row.begin(), by_row.end(),
+                                               std::make_pair(h.row, -INFINITY));
+                    kmax = std::max(kmax, it->second);
+                }
+                const double lhs =
+                    (double)kmax + key_eps(ix, kmax, t.qnorm) + key_eps(ix, thr_min, t.qnorm);
+                certified = (int)res.size() == k && lhs < thr_min;
+            }
+            if (ix->force_escalate && std::isfinite(thr_min)) certified = false;
+            if (!certified) {
+                {
+                    std::lock_guard<std::mutex> lk(ix->stats_mu);
+                    ix->stats.escalations++;
+                }
+                double thr = INFINITY;
+                if ((int)res.size() == k && std::isfinite(kmax) && !zero_query)
+                    thr = (double)kmax + 2.1 * key_eps(ix, (double)kmax + key_eps(ix, kmax, t.qnorm), t.qnorm);
+                float thr_f = thr >= 3.0e38 ? 3.0e38f : std::nextafter((float)thr, INFINITY);
+                cands.clear();
+                for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
+                    Shard *sh = ix->shards[s];
+                    if (sh->n_rows == 0) continue;
+                    if (ix->timing) (void)hipEventRecord(t.ctx[s]->ev_all0, t.ctx[s]->stream);
+                    rc = run_collect(ix, sh, t.ctx[s], thr_f, allow != nullptr, &cands);
+                }
+                if (rc == SZG_OK) replay_topk(cands, k, &res);
+            }
+            if (rc == SZG_OK && ix->tie_mode == 0 && history_dependent(cands, k)) {
+                {
+                    std::lock_guard<std::mutex> lk(ix->stats_mu);
+                    ix->stats.full_replays++;
+                }
+                rc = run_full_replay(ix, t.ctx, allow, k, &res);
+            }
+        }
+        for (size_t s = 0; s < n_sh; s++)
+            if (t.ctx[s]) ctx_release(ix->shards[s], t.ctx[s]);
+        t.ctx.assign(n_sh, nullptr);
+        if (rc) return rc;
+        for (int i = 0; i < k; i++) {
+            const bool have = i < (int)res.size();
+            out_rows[(size_t)qi * k + i] = have ? res[i].row + ix->row_base : UINT64_MAX;
+            out_dist[(size_t)qi * k + i] = have ? res[i].priority : 0.0;
+        }
+        if (out_count) out_count[qi] = (int32_t)res.size();
+        {
+            std::lock_guard<std::mutex> lk(ix->stats_mu);
+            ix->stats.queries++;
+        }
+        return SZG_OK;
+    };
+
+    std::deque<Ticket> inflight;
+    int rc = SZG_OK;
+    for (int qi = 0; qi < n_queries && rc == SZG_OK; qi++) {
+        Ticket t;
+        t.query = qi;
+        t.kp = kp;
+        t.ctx.assign(n_sh, nullptr);
+        // get one context per shard; never block while holding in-flight work
+        bool got = true;
+        for (size_t s = 0; s < n_sh; s++) {
+            if (ix->shards[s]->n_rows == 0) continue;
+            Ctx *c = inflight.empty() ? ctx_acquire(ix->shards[s]) : ctx_try_acquire(ix->shards[s]);
+            if (!c) {
+                got = false;
+                break;
+            }
+            t.ctx[s] = c;
+        }
+        if (!got) {
+            for (size_t s = 0; s < n_sh; s++)
+                if (t.ctx[s]) ctx_release(ix->shards[s], t.ctx[s]);
+            rc = finish(inflight.front());
+            inflight.pop_front();
+            qi--;
+            continue;
+        }
+        const double *q = queries + (size_t)qi * ix->dim;
+        const uint64_t *allow = allow_bits ? allow_bits + (size_t)qi * allow_stride : nullptr;
+        for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
+            Shard *sh = ix->shards[s];
+            if (sh->n_rows == 0) continue;
+            prep_query(ix, q, t.ctx[s]->h_qsw, &t.qnorm, &t.m1);
+            rc = enqueue_query(ix, sh, t.ctx[s], q, allow);
+            if (rc == SZG_OK) rc = enqueue_topk(ix, sh, t.ctx[s], kp, allow != nullptr);
+        }
+        inflight.push_back(std::move(t));
+    }
+    while (!inflight.empty()) {
+        int r2 = finish(inflight.front());
+        if (rc == SZG_OK) rc = r2;
+        inflight.pop_front();
+    }
+    return rc;
+}
+
+int upload_rows(szg_index *ix, Shard *sh, uint64_t dst_row, const uint8_t *rows, uint64_t n)
+{
+    if (n == 0) return SZG_OK;
+    HIPCHK(hipSetDevice(sh->device));
+    const uint64_t chunk_rows = std::max<uint64_t>(1, (64ull << 20) / ix->row_bytes);
+    uint8_t *stage = nullptr;
+    const uint64_t cr = std::min(chunk_rows, n);
+    HIPCHK(hipMalloc((void **)&stage, cr * ix->row_bytes));
+    int rc = SZG_OK;
+    for (uint64_t off = 0; off < n && rc == SZG_OK; off += cr) {
+        const uint64_t m = std::min(cr, n - off);
+        hipError_t e = hipMemcpy(stage, rows + off * ix->row_bytes, m * ix->row_bytes,
+                                 hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = szg::launch_repack(ix->bits, stage, ix->row_bytes,
+                                   sh->rows + (dst_row + off) * ix->pitch, ix->pitch, m, 0, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "upload_rows", e);
+    }
+    (void)hipFree(stage);
+    return rc;
+}
+
+int shard_reserve(szg_index *ix, Shard *sh, uint64_t rows_needed)
+{
+    HIPCHK(hipSetDevice(sh->device));
+    if (rows_needed > 0xFFFFFFF0ull) return fail(SZG_E_UNSUPPORTED, "more than 2^32 rows per shard");
+    if (rows_needed > sh->cap_rows) {
+        uint64_t cap = std::max<uint64_t>(rows_needed, sh->cap_rows + sh->cap_rows / 2);
+        cap = (cap + 63) & ~63ull;
+        uint8_t *nr = nullptr;
+        hipError_t e = hipMalloc((void **)&nr, cap * ix->pitch + 64);
+        if (e != hipSuccess) return fail(SZG_E_NOMEM, "hipMalloc(corpus)", e);
+        if (sh->rows && sh->n_rows)
+            HIPCHK(hipMemcpy(nr, sh->rows, sh->n_rows * ix->pitch, hipMemcpyDeviceToDevice));
+        if (sh->rows) HIPCHK(hipFree(sh->rows));
+        sh->rows = nr;
+        sh->cap_rows = cap;
+    }
+    const uint64_t words = (sh->cap_rows + 63) / 64;
+    if (words > sh->bits_cap) {
+        uint64_t *nb = nullptr;
+        hipError_t e = hipMalloc((void **)&nb, words * sizeof(uint64_t));
+        if (e != hipSuccess) return fail(SZG_E_NOMEM, "hipMalloc(live bits)", e);
+        HIPCHK(hipMemset(nb, 0, words * sizeof(uint64_t)));
+        if (sh->live_bits && sh->bits_cap)
+            HIPCHK(hipMemcpy(nb, sh->live_bits, sh->bits_cap * sizeof(uint64_t),
+                             hipMemcpyDeviceToDevice));
+        if (sh->live_bits) HIPCHK(hipFree(sh->live_bits));
+        sh->live_bits = nb;
+        sh->bits_cap = words;
+    }
+    return SZG_OK;
+}
+
+// set live bits for rows [lo, hi) of a shard (host read-modify-write of the edge words)
+int shard_set_live(Shard *sh, uint64_t lo, uint64_t hi)
+{
+    if (hi <= lo) return SZG_OK;
+    HIPCHK(hipSetDevice(sh->device));
+    const uint64_t w0 = lo / 64, w1 = (hi - 1) / 64;
+    std::vector<uint64_t> words(w1 - w0 + 1);
+    HIPCHK(hipMemcpy(words.data(), sh->live_bits + w0, words.size() * sizeof(uint64_t),
+                     hipMemcpyDeviceToHost));
+    for (uint64_t r = lo; r < hi;) {
+        const uint64_t w = r / 64;
+        const uint64_t end = std::min(hi, (w + 1) * 64);
+        const uint64_t nb = end - r;
+        const uint64_t mask = (nb == 64 ? ~0ull : ((1ull << nb) - 1ull)) << (r % 64);
+        words[w - w0] |= mask;
+        r = end;
+    }
+    HIPCHK(hipMemcpy(sh->live_bits + w0, words.data(), words.size() * sizeof(uint64_t),
+                     hipMemcpyHostToDevice));
+    return SZG_OK;
+}
+
+// rows of the index are split over shards in contiguous ranges whose boundaries
+// are multiples of 64 (so filter words slice cleanly)
+void split_rows(const szg_index *ix, uint64_t n_rows, std::vector<uint64_t> *counts)
+{
+    const size_t g = ix->shards.size();
+    counts->assign(g, 0);
+    uint64_t per = (n_rows + g - 1) / g;
+    per = (per + 63) & ~63ull;
+    uint64_t left = n_rows;
+    for (size_t s = 0; s < g; s++) {
+        const uint64_t m = std::min(per, left);
+        (*counts)[s] = m;
+        left -= m;
+    }
+}
+
+Shard *shard_of(szg_index *ix, uint64_t row, uint64_t *local)
+{
+    for (Shard *s : ix->shards) {
+        if (row >= s->first && row < s->first + s->n_rows) {
+            *local = row - s->first;
+            return s;
+        }
+    }
+    return nullptr;
+}
+
+}  // namespace
+
+// ============================================================== C ABI ==========
+
+extern "C" {
+
+int szg_abi_version(void) { return SZG_ABI_VERSION; }
+
+const char *szg_last_error(void) { return g_last_error.c_str(); }
+
+const char *szg_strerror(int code)
+{
+    switch (code) {
+    case SZG_OK: return "ok";
+    case SZG_E_INVALID: return "invalid argument";
+    case SZG_E_NOMEM: return "out of memory";
+    case SZG_E_DEVICE: return "HIP runtime error";
+    case SZG_E_TRUNCATED: return "result truncated: more hits than capacity";
+    case SZG_E_NODEVICE: return "no usable gfx950 device";
+    case SZG_E_RANGE: return "row index out of range";
+    case SZG_E_UNSUPPORTED: return "outside this build's limits";
+    default: return "unknown error";
+    }
+}
+
+int64_t szg_row_bytes(int quant_bits, int dim)
+{
+    if (dim <= 0) return -1;
+    return row_bytes_of(quant_bits, dim);
+}
+
+int szg_index_create(szg_index **out, int dim, int quant_bits, int metric, const int *devices,
+                     int n_devices)
+{
+    if (!out) return fail(SZG_E_INVALID, "out is null");
+    *out = nullptr;
+    if (dim <= 0 || dim > (1 << 20)) return fail(SZG_E_INVALID, "dim out of range");
+    const int64_t rb = row_bytes_of(quant_bits, dim);
+    if (rb < 0) return fail(SZG_E_INVALID, "unsupported quantization (reference panics, collection.go:809)");
+    if (metric != SZG_EUCLIDEAN && metric != SZG_COSINE)
+        return fail(SZG_E_INVALID, "unsupported distance method (collection.go:282)");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(SZG_E_NODEVICE, "hipGetDeviceCount", e);
+
+    szg_index *ix = new szg_index();
+    ix->dim = dim;
+    ix->bits = quant_bits;
+    ix->metric = metric;
+    ix->row_bytes = (uint32_t)rb;
+    ix->pitch = (uint32_t)((rb + 15) & ~15ll);
+    ix->map = choose_map((int)(ix->pitch / 16));
+    const size_t E = 128 / quant_bits, QB = quant_bits == 64 ? 8 : 4;
+    ix->qsw_bytes = (size_t)ix->map.r16 * E * QB;
+    if (ix->qsw_bytes > 48u * 1024u) {
+        delete ix;
+        return fail(SZG_E_UNSUPPORTED, "dimension too large for the LDS-resident query");
+    }
+    std::vector<int> devs;
+    if (devices && n_devices > 0) {
+        devs.assign(devices, devices + n_devices);
+    } else {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        devs.push_back(cur);
+    }
+    for (int d : devs) {
+        if (d < 0 || d >= count) {
+            szg_index_destroy(ix);
+            return fail(SZG_E_INVALID, "device ordinal out of range");
+        }
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, d);
+        if (e != hipSuccess) {
+            szg_index_destroy(ix);
+            return fail(SZG_E_NODEVICE, "hipGetDeviceProperties", e);
+        }
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            szg_index_destroy(ix);
+            return fail(SZG_E_NODEVICE, "device is not gfx950 (kernels are built for MI355X only)");
+        }
+        Shard *sh = new Shard();
+        sh->device = d;
+        sh->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        ix->shards.push_back(sh);
+    }
+    for (Shard *sh : ix->shards) {
+        for (int i = 0; i < ix->n_ctx; i++) {
+            Ctx *c = nullptr;
+            int rc = ctx_alloc(ix, sh, &c);
+            if (rc) {
+                ctx_free(c);
+                szg_index_destroy(ix);
+                return rc;
+            }
+            sh->all_ctx.push_back(c);
+            sh->free_ctx.push_back(c);
+        }
+    }
+    *out = ix;
+    return SZG_OK;
+}
+
+void szg_index_destroy(szg_index *ix)
+{
+    if (!ix) return;
+    for (Shard *sh : ix->shards) {
+        (void)hipSetDevice(sh->device);
+        (void)hipDeviceSynchronize();
+        for (Ctx *c : sh->all_ctx) ctx_free(c);
+        (void)hipFree(sh->rows);
+        (void)hipFree(sh->live_bits);
+        delete sh;
+    }
+    delete ix;
+}
+
+uint64_t szg_index_rows(const szg_index *ix)
+{
+    uint64_t n = 0;
+    if (ix) for (const Shard *s : ix->shards) n += s->n_rows;
+    return n;
+}
+
+uint64_t szg_index_live_rows(const szg_index *ix)
+{
+    uint64_t n = 0;
+    if (ix) for (const Shard *s : ix->shards) n += s->n_live;
+    return n;
+}
+
+static int reset_shards(szg_index *ix, const std::vector<uint64_t> &counts)
+{
+    uint64_t first = 0;
+    for (size_t s = 0; s < ix->shards.size(); s++) {
+        Shard *sh = ix->shards[s];
+        HIPCHK(hipSetDevice(sh->device));
+        HIPCHK(hipDeviceSynchronize());
+        sh->first = first;
+        sh->n_rows = 0;
+        sh->n_live = 0;
+        sh->has_dead = false;
+        int rc = shard_reserve(ix, sh, counts[s]);
+        if (rc) return rc;
+        HIPCHK(szg::launch_fill_bits(sh->live_bits, counts[s], sh->bits_cap, nullptr));
+        HIPCHK(hipDeviceSynchronize());
+        first += counts[s];
+    }
+    return SZG_OK;
+}
+
+int szg_index_load(szg_index *ix, const uint8_t *rows, uint64_t n_rows)
+{
+    if (!ix || (!rows && n_rows)) return fail(SZG_E_INVALID, "null argument");
+    std::vector<uint64_t> counts;
+    split_rows(ix, n_rows, &counts);
+    int rc = reset_shards(ix, counts);
+    if (rc) return rc;
+    for (size_t s = 0; s < ix->shards.size(); s++) {
+        Shard *sh = ix->shards[s];
+        rc = upload_rows(ix, sh, 0, rows + sh->first * ix->row_bytes, counts[s]);
+        if (rc) return rc;
+        sh->n_rows = counts[s];
+        sh->n_live = counts[s];
+    }
+    return SZG_OK;
+}
+
+int szg_index_synth(szg_index *ix, uint64_t n_rows, uint64_t seed, uint64_t first_row)
+{
+    if (!ix) return fail(SZG_E_INVALID, "null argument");
+    std::vector<uint64_t> counts;
+    split_rows(ix, n_rows, &counts);
+    int rc = reset_shards(ix, counts);
+    if (rc) return rc;
+    for (size_t s = 0; s < ix->shards.size(); s++) {
+        Shard *sh = ix->shards[s];
+        HIPCHK(hipSetDevice(sh->device));
+        HIPCHK(szg::launch_synth(ix->bits, sh->rows, ix->pitch, ix->dim, counts[s], seed,
+                                 first_row + sh->first, nullptr));
+        HIPCHK(hipDeviceSynchronize());
+        sh->n_rows = counts[s];
+        sh->n_live = counts[s];
+    }
+    return SZG_OK;
+}
+
+int szg_index_append(szg_index *ix, const uint8_t *rows, uint64_t n_rows)
+{
+    if (!ix || (!rows && n_rows)) return fail(SZG_E_INVALID, "null argument");
+    if (n_rows == 0) return SZG_OK;
+    Shard *sh = ix->shards.back();  // new rows extend the last shard's range
+    HIPCHK(hipSetDevice(sh->device));
+    HIPCHK(hipDeviceSynchronize());
+    int rc = shard_reserve(ix, sh, sh->n_rows + n_rows);
+    if (rc) return rc;
+    rc = upload_rows(ix, sh, sh->n_rows, rows, n_rows);
+    if (rc) return rc;
+    rc = shard_set_live(sh, sh->n_rows, sh->n_rows + n_rows);
+    if (rc) return rc;
+    sh->n_rows += n_rows;
+    sh->n_live += n_rows;
+    return SZG_OK;
+}
+
+int szg_index_overwrite(szg_index *ix, uint64_t row, const uint8_t *row_bytes)
+{
+    if (!ix || !row_bytes) return fail(SZG_E_INVALID, "null argument");
+    uint64_t local;
+    Shard *sh = shard_of(ix, row, &local);
+    if (!sh) return fail(SZG_E_RANGE, "row out of range");
+    HIPCHK(hipSetDevice(sh->device));
+    HIPCHK(hipDeviceSynchronize());
+    return upload_rows(ix, sh, local, row_bytes, 1);
+}
+
+int szg_index_tombstone(szg_index *ix, uint64_t row)
+{
+    if (!ix) return fail(SZG_E_INVALID, "null argument");
+    uint64_t local;
+    Shard *sh = shard_of(ix, row, &local);
+    if (!sh) return fail(SZG_E_RANGE, "row out of range");
+    HIPCHK(hipSetDevice(sh->device));
+    HIPCHK(hipDeviceSynchronize());
+    uint64_t w = 0;
+    HIPCHK(hipMemcpy(&w, sh->live_bits + local / 64, sizeof(w), hipMemcpyDeviceToHost));
+    const uint64_t bit = 1ull << (local % 64);
+    if (w & bit) {
+        w &= ~bit;
+        HIPCHK(hipMemcpy(sh->live_bits + local / 64, &w, sizeof(w), hipMemcpyHostToDevice));
+        sh->n_live--;
+        sh->has_dead = true;
+    }
+    return SZG_OK;
+}
+
+int szg_index_read_rows(szg_index *ix, uint64_t first_row, uint64_t n_rows, uint8_t *out)
+{
+    if (!ix || (!out && n_rows)) return fail(SZG_E_INVALID, "null argument");
+    if (first_row + n_rows > szg_index_rows(ix)) return fail(SZG_E_RANGE, "row range out of bounds");
+    for (Shard *sh : ix->shards) {
+        const uint64_t lo = std::max(first_row, sh->first);
+        const uint64_t hi = std::min(first_row + n_rows, sh->first + sh->n_rows);
+        if (hi <= lo) continue;
+        HIPCHK(hipSetDevice(sh->device));
+        const uint64_t m = hi - lo;
+        uint8_t *stage = nullptr;
+        HIPCHK(hipMalloc((void **)&stage, m * ix->row_bytes));
+        hipError_t e = szg::launch_repack(ix->bits, sh->rows + (lo - sh->first) * ix->pitch,
+                                          ix->row_bytes, stage, ix->pitch, m, 1, nullptr);
+        if (e == hipSuccess)
+            e = hipMemcpy(out + (lo - first_row) * ix->row_bytes, stage, m * ix->row_bytes,
+                          hipMemcpyDeviceToHost);
+        (void)hipFree(stage);
+        if (e != hipSuccess) return fail(SZG_E_DEVICE, "read_rows", e);
+    }
+    return SZG_OK;
+}
+
+int szg_index_set_row_base(szg_index *ix, uint64_t base)
+{
+    if (!ix) return fail(SZG_E_INVALID, "null argument");
+    ix->row_base = base;
+    return SZG_OK;
+}
+
+int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
+                    const uint64_t *allow_bits, uint64_t *out_rows, double *out_dist,
+                    int32_t *out_count)
+{
+    if (!ix || !queries || !out_rows || !out_dist) return fail(SZG_E_INVALID, "null argument");
+    if (n_queries < 0 || k <= 0) return fail(SZG_E_INVALID, "k must be > 0 (K==0 is listing mode, collection.go:633)");
+    if (n_queries == 0) return SZG_OK;
+    if (szg_index_rows(ix) == 0) {  // empty collection -> no results (collection_test.go:294-309)
+        for (size_t i = 0; i < (size_t)n_queries * k; i++) {
+            out_rows[i] = UINT64_MAX;
+            out_dist[i] = 0.0;
+        }
+        if (out_count) for (int i = 0; i < n_queries; i++) out_count[i] = 0;
+        return SZG_OK;
+    }
+    return search_topk_impl(ix, queries, n_queries, k, allow_bits, out_rows, out_dist, out_count);
+}
+
+int szg_search_radius(szg_index *ix, const double *query, double radius,
+                      const uint64_t *allow_bits, uint64_t *out_rows, double *out_dist,
+                      uint64_t capacity, uint64_t *out_total)
+{
+    if (!ix || !query || !out_total) return fail(SZG_E_INVALID, "null argument");
+    if (!(radius > 0)) return fail(SZG_E_INVALID, "radius must be > 0 (collection.go:598)");
+    if (capacity && (!out_rows || !out_dist)) return fail(SZG_E_INVALID, "null output buffer");
+    *out_total = 0;
+    if (szg_index_rows(ix) == 0) return SZG_OK;
+
+    // key threshold that surely contains every row with distance <= radius
+    double qnorm = 0, m1 = 0;
+    std::vector<uint8_t> tmp(ix->qsw_bytes);
+    prep_query(ix, query, tmp.data(), &qnorm, &m1);
+    float thr_f;
+    if (ix->metric == SZG_COSINE) {
+        if (radius >= 1.0 || m1 == 0) {
+            thr_f = 3.0e38f;  // acos(c)/pi <= 1 always; zero query -> all 1.0
+        } else {
+            const double t = -std::cos(M_PI * radius) + 2.0 * key_eps(ix, 1.0, qnorm) + 1e-12;
+            thr_f = std::nextafter((float)t, INFINITY);
+        }
+    } else {
+        const double scale = ix->bits <= 16 ? (double)((1u << ix->bits) - 1u) : 1.0;
+        const double kk = (radius * scale) * (radius * scale);
+        const double t = kk * (1.0 + 1e-12) + 2.0 * key_eps(ix, kk, qnorm);
+        thr_f = t >= 3.0e38 ? 3.0e38f : std::nextafter((float)t, INFINITY);
+    }
+
+    std::vector<Cand> cands;
+    int rc = SZG_OK;
+    for (size_t s = 0; s < ix->shards.size() && rc == SZG_OK; s++) {
+        Shard *sh = ix->shards[s];
+        if (sh->n_rows == 0) continue;
+        Ctx *c = ctx_acquire(sh);
+        memcpy(c->h_qsw, tmp.data(), ix->qsw_bytes);
+        rc = enqueue_query(ix, sh, c, query, allow_bits);
+        if (rc == SZG_OK) rc = run_collect(ix, sh, c, thr_f, allow_bits != nullptr, &cands);
+        ctx_release(sh, c);
+    }
+    if (rc) return rc;
+    // consider()'s radius branch (collection.go:598-605) in visit order, then the pop loop
+    std::sort(cands.begin(), cands.end(), [](const Cand &x, const Cand &y) { return x.row < y.row; });
+    GoHeap h;
+    for (const Cand &c : cands)
+        if (c.dist <= radius) h.push(HeapItem{c.row, c.dist});
+    const uint64_t total = h.a.size();
+    *out_total = total;
+    for (uint64_t i = total; i-- > 0;) {
+        const HeapItem it = h.pop();
+        if (i < capacity) {
+            out_rows[i] = it.row + ix->row_base;
+            out_dist[i] = it.priority;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(ix->stats_mu);
+        ix->stats.queries++;
+    }
+    if (total > capacity) return fail(SZG_E_TRUNCATED, "radius search: capacity too small");
+    return SZG_OK;
+}
+
+int szg_set_timing(szg_index *ix, int enabled)
+{
+    if (!ix) return fail(SZG_E_INVALID, "null argument");
+    for (Shard *sh : ix->shards) {
+        (void)hipSetDevice(sh->device);
+        (void)hipDeviceSynchronize();
+    }
+    ix->timing = enabled != 0;
+    return SZG_OK;
+}
+
+int szg_get_stats(szg_index *ix, szg_stats *out)
+{
+    if (!ix || !out) return fail(SZG_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(ix->stats_mu);
+    *out = ix->stats;
+    return SZG_OK;
+}
+
+int szg_reset_stats(szg_index *ix)
+{
+    if (!ix) return fail(SZG_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(ix->stats_mu);
+    ix->stats = szg_stats{};
+    return SZG_OK;
+}
+
+int szg_set_option(szg_index *ix, const char *name, int64_t value)
+{
+    if (!ix || !name) return fail(SZG_E_INVALID, "null argument");
+    const std::string n(name);
+    if (n == "slack") {
+        if (value < 0 || value > 4096) return fail(SZG_E_INVALID, "slack out of range");
+        ix->slack_min = (int)value;
+    } else if (n == "blocks_per_cu") {
+        if (value < 1 || value > 16) return fail(SZG_E_INVALID, "blocks_per_cu out of range");
+        ix->blocks_per_cu = (int)value;
+    } else if (n == "block_threads") {
+        if (value != 64 && value != 128 && value != 256 && value != 512)
+            return fail(SZG_E_INVALID, "block_threads must be 64/128/256/512");
+        ix->block_threads = (int)value;
+    } else if (n == "tie_mode") {
+        if (value != 0 && value != 1) return fail(SZG_E_INVALID, "tie_mode must be 0 or 1");
+        ix->tie_mode = (int)value;
+    } else if (n == "force_escalate") {
+        ix->force_escalate = value != 0;
+    } else {
+        return fail(SZG_E_INVALID, "unknown option");
+    }
+    return SZG_OK;
+}
+
+// test hook: device float64 primitives (0 div, 1 sqrt, 2 go acos, 3 round, 4 f32 narrowing)
+int szg_debug_f64_probe(int op, const double *a, const double *b, double *out, uint64_t n)
+{
+    if (!a || !out) return fail(SZG_E_INVALID, "null argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(SZG_E_NODEVICE, "hipGetDeviceCount");
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc((void **)&da, n * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&db, n * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&dout, n * sizeof(double)));
+    HIPCHK(hipMemcpy(da, a, n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db, b ? b : a, n * sizeof(double), hipMemcpyHostToDevice));
+    hipError_t e = szg::launch_f64_probe(op, da, db, dout, n, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(da);
+    (void)hipFree(db);
+    (void)hipFree(dout);
+    if (e != hipSuccess) return fail(SZG_E_DEVICE, "f64 probe", e);
+    return SZG_OK;
+}
+
+}  // extern "C"

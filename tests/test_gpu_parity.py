@@ -1,0 +1,163 @@
+"""GPU parity: the HIP scan (through the C ABI) against the CPU oracle.
+
+IDs must be bit-exact and in the same order; distances are the reference's
+own float64 values, so they are compared for exact equality (the contract's
+tolerance, 1e-5 relative for float32 corpora, is the fallback the asserts
+name when a platform's float64 sqrt/div differs in the last bit).
+"""
+import numpy as np
+import pytest
+
+import oracle as orc
+from syzgydb_amd import ScanIndex, SZG_COSINE, SZG_EUCLIDEAN, f64_probe
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5  # north_star: distances within 1e-5 relative (float32)
+
+SEED = 0x53595A4700000000
+
+
+def assert_same(rows, dist, o_rows, o_dist):
+    assert len(rows) == len(o_rows)
+    assert list(map(int, rows)) == list(map(int, o_rows)), "doc rows differ"
+    d = np.asarray(dist, dtype=np.float64)
+    od = np.asarray(o_dist, dtype=np.float64)
+    both_nan = np.isnan(d) & np.isnan(od)
+    ok = both_nan | (np.abs(d - od) <= REL_TOL * np.abs(od))
+    assert ok.all(), (d, od)
+    # stronger, expected: bit-identical float64
+    assert (both_nan | (d == od)).all(), ("not bit-exact", d, od)
+
+
+@pytest.mark.parametrize("bits", [4, 8, 16, 32, 64])
+@pytest.mark.parametrize("metric", [SZG_EUCLIDEAN, SZG_COSINE])
+@pytest.mark.parametrize("dim,n", [(3, 10), (3, 1000), (17, 777), (128, 5000), (384, 3000), (768, 2000)])
+def test_topk_matches_oracle(bits, metric, dim, n):
+    rows = orc.synth_rows(SEED + bits, 0, n, dim, bits)
+    queries = orc.synth_vectors(SEED + 1, 0, 4, dim)
+    with ScanIndex(dim, bits, metric) as ix:
+        ix.load(rows)
+        assert ix.rows == n
+        for k in (1, 10):
+            r, d, c = ix.search_topk(queries, k)
+            for qi in range(queries.shape[0]):
+                o_rows, o_dist, searched = orc.search_exact(rows, dim, bits, metric, queries[qi], k=k)
+                assert searched == n
+                assert c[qi] == len(o_rows)
+                assert_same(r[qi, : c[qi]], d[qi, : c[qi]], o_rows, o_dist)
+
+
+@pytest.mark.parametrize("bits", [4, 8, 32])
+@pytest.mark.parametrize("metric", [SZG_EUCLIDEAN, SZG_COSINE])
+def test_synth_matches_oracle_bytes(bits, metric):
+    dim, n = 37, 513
+    with ScanIndex(dim, bits, metric) as ix:
+        ix.synth(n, SEED + 7, first_row=100)
+        got = ix.read_rows(0, n)
+    want = orc.synth_rows(SEED + 7, 100, n, dim, bits)
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("bits", [4, 8, 16, 32, 64])
+def test_load_read_roundtrip(bits):
+    dim, n = 21, 300
+    rows = orc.synth_rows(SEED, 0, n, dim, bits)
+    with ScanIndex(dim, bits, SZG_EUCLIDEAN) as ix:
+        ix.load(rows)
+        assert (ix.read_rows(0, n) == rows).all()
+        assert (ix.read_rows(17, 5) == rows[17:22]).all()
+
+
+def test_f64_primitives_bit_exact():
+    rng = np.random.default_rng(1)
+    a = rng.uniform(1e-3, 1e3, 20000)
+    b = rng.uniform(1e-3, 1e3, 20000)
+    assert (f64_probe(0, a, b) == a / b).all()
+    assert (f64_probe(1, a) == np.sqrt(a)).all()
+    x = np.concatenate([rng.uniform(-1, 1, 20000), [1.0, -1.0, 0.0, 1.0000000000000002, 0.7, 0.66]])
+    got = f64_probe(2, x)
+    want = np.array([orc.go_acos(v) for v in x])
+    assert ((got == want) | (np.isnan(got) & np.isnan(want))).all()
+
+
+@pytest.mark.parametrize("metric", [SZG_EUCLIDEAN, SZG_COSINE])
+def test_radius_matches_oracle(metric):
+    dim, n, bits = 16, 4000, 32
+    rows = orc.synth_rows(SEED, 0, n, dim, bits)
+    q = orc.synth_vectors(SEED + 1, 0, 1, dim)[0]
+    alld = orc.all_distances(rows, dim, bits, metric, q)
+    for frac in (0.001, 0.05, 0.5):
+        radius = float(np.quantile(alld, frac))
+        o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, q, radius=radius)
+        with ScanIndex(dim, bits, metric) as ix:
+            ix.load(rows)
+            r, d = ix.search_radius(q, radius)
+        assert_same(r, d, o_rows, o_dist)
+        assert (d <= radius).all()
+
+
+def test_filter_mask_and_tombstones():
+    dim, n, bits = 8, 500, 8
+    rows = orc.synth_rows(SEED, 0, n, dim, bits)
+    q = orc.synth_vectors(SEED + 1, 0, 1, dim)[0]
+    allow = (np.arange(n) % 2 == 0)
+    with ScanIndex(dim, bits, SZG_COSINE) as ix:
+        ix.load(rows)
+        r, d, c = ix.search_topk(q, 5, allow=allow)
+        o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, SZG_COSINE, q, k=5,
+                                             allow=allow.astype(np.uint8))
+        assert_same(r[0, : c[0]], d[0, : c[0]], o_rows, o_dist)
+        assert all(int(x) % 2 == 0 for x in r[0, : c[0]])
+        # tombstone the best hit: it must disappear
+        best = int(r[0, 0])
+        ix.tombstone(best)
+        assert ix.live_rows == n - 1
+        allow2 = allow.copy()
+        allow2[best] = False
+        r2, d2, c2 = ix.search_topk(q, 5, allow=allow)
+        o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, SZG_COSINE, q, k=5,
+                                             allow=allow2.astype(np.uint8))
+        assert_same(r2[0, : c2[0]], d2[0, : c2[0]], o_rows, o_dist)
+
+
+def test_k_larger_than_n_and_empty():
+    dim, bits = 5, 64
+    rows = orc.synth_rows(SEED, 0, 7, dim, bits)
+    q = orc.synth_vectors(SEED + 1, 0, 1, dim)[0]
+    with ScanIndex(dim, bits, SZG_EUCLIDEAN) as ix:
+        r, d, c = ix.search_topk(q, 3)
+        assert c[0] == 0
+        ix.load(rows)
+        r, d, c = ix.search_topk(q, 20)
+        o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, SZG_EUCLIDEAN, q, k=20)
+        assert c[0] == 7
+        assert_same(r[0, :7], d[0, :7], o_rows, o_dist)
+
+
+def test_escalation_path_is_exact():
+    """Many duplicate rows force ties across the candidate boundary (rule: a rare
+    data-dependent branch needs its own test); force_escalate drives the same path
+    on ordinary data."""
+    dim, bits = 6, 32
+    base = orc.synth_vectors(SEED, 0, 4, dim)
+    vecs = np.repeat(base, 300, axis=0)  # 1200 rows, 4 distinct vectors
+    rows = orc.encode_rows(vecs, bits)
+    q = base[2] + 0.01
+    for metric in (SZG_EUCLIDEAN, SZG_COSINE):
+        with ScanIndex(dim, bits, metric) as ix:
+            ix.load(rows)
+            r, d, c = ix.search_topk(q, 10)
+            st = ix.stats()
+            assert st["escalations"] >= 1
+            o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, q, k=10)
+            assert_same(r[0, : c[0]], d[0, : c[0]], o_rows, o_dist)
+    rows = orc.synth_rows(SEED, 0, 3000, 24, 8)
+    q = orc.synth_vectors(SEED + 1, 0, 1, 24)[0]
+    with ScanIndex(24, 8, SZG_COSINE) as ix:
+        ix.load(rows)
+        ix.set_option("force_escalate", 1)
+        r, d, c = ix.search_topk(q, 10)
+        assert ix.stats()["escalations"] == 1
+        o_rows, o_dist, _ = orc.search_exact(rows, 24, 8, SZG_COSINE, q, k=10)
+        assert_same(r[0, : c[0]], d[0, : c[0]], o_rows, o_dist)
