@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of the exact (brute-force) scan behind Collection.Search.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one exact top-k query over the whole synthetic corpus (one sweep of
+the packed rows through the fused HIP scan, rerank and result assembly
+included).  Default workload = BASELINE.json's headline: 1M x 768 float32,
+cosine (angular) distance, k=10, one query per sweep.  With N>1 (launched by
+torch.distributed.run, one rank per GPU) the corpus is sharded by rows over the
+ranks, every query goes to every rank and the per-shard top-k lists are merged
+after one RCCL all-gather per micro-batch ("scaling": "strong").
+
+Rank 0 prints ONE JSON line: metric/value/unit/..., plus
+  "roofline":     HBM roofline of the fused scan kernel, from HIP events recorded
+                  on the library's scan stream inside the timed region;
+  "cpu_baseline": the CPU oracle (a C port of the reference's Go scan; there is
+                  no Go toolchain in this image) timed on this box's host cores on
+                  a bounded sample of the same workload (N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (rows, dim, bits, metric, k, radius)   metric 0 = Euclidean, 1 = Cosine
+    "headline": (1_000_000, 768, 32, 1, 10, 0.0),      # BASELINE.json metric / north_star target
+    "cfg2": (1_000_000, 384, 32, 1, 10, 0.0),
+    "cfg3": (1_000_000, 768, 8, 1, 10, 0.0),
+    "cfg4": (10_000_000, 768, 32, 0, 100, 0.0),
+    "cfg5": (100_000_000, 384, 4, 1, 0, 0.42),
+    "plumbing": (10_000, 128, 32, 1, 10, 0.0),
+}
+SEED = 0x53595A4700000000
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Cores this process may actually use (affinity and cgroup quota), capped at the
+    16-core share a one-GPU box gets."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=0, help="override the workload's row count")
+    ap.add_argument("--exchange-every", type=int, default=64,
+                    help="N>1: queries per all-gather micro-batch")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip cpu_baseline and the recall check")
+    ap.add_argument("--verify", type=int, default=4, help="queries re-checked against the oracle")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            log("bench.py: --gpus %d needs torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+            sys.exit(2)
+        args.gpus = world
+
+    from syzgydb_amd import ScanIndex
+    from syzgydb_amd.synth import synth_vectors
+    from syzgydb_amd.sharded import ShardedSearcher, shard_range
+
+    n_rows, dim, bits, metric, k, radius = WORKLOADS[args.workload]
+    if args.rows:
+        n_rows = args.rows
+    if radius > 0:
+        log("bench.py: radius workloads are exercised by tests; timing the top-k form with k=10")
+        k = 10
+    seed = SEED + sorted(WORKLOADS).index(args.workload)
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        try:
+            import torch  # only for torch.cuda.synchronize() around the timed region
+        except Exception:  # pragma: no cover
+            torch = None
+
+    lo, hi = shard_range(n_rows, rank, world)
+    ix = ScanIndex(dim, bits, metric, devices=[local_rank])
+    t0 = time.time()
+    ix.synth(hi - lo, seed, first_row=lo)  # corpus generated in HBM, reference encoding rules
+    ix.set_row_base(lo)
+    log("[rank %d] corpus rows [%d, %d) x %d B resident in %.2f s" % (rank, lo, hi, ix.row_bytes,
+                                                                     time.time() - t0))
+    queries = synth_vectors(seed + 1, 0, args.warmup + args.steps, dim)
+    qw, qt = queries[: args.warmup], queries[args.warmup:]
+
+    if world > 1:
+        searcher = ShardedSearcher(lambda q, kk: ix.search_topk(q, kk),
+                                   device=torch.device("cuda", local_rank))
+
+        def run(q):
+            outs = []
+            for i in range(0, q.shape[0], args.exchange_every):
+                outs.append(searcher.search(q[i:i + args.exchange_every], k))
+            return (np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs]))
+    else:
+        def run(q):
+            r, d, _ = ix.search_topk(q, k)
+            return r, d
+
+    def sync():
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    if args.warmup:
+        run(qw)
+    ix.set_timing(True)
+    ix.reset_stats()
+    sync()
+    t0 = time.perf_counter()
+    res_rows, res_dist = run(qt)  # returns when every result is on the host
+    sync()
+    elapsed = time.perf_counter() - t0
+    stats = ix.stats()
+    ix.set_timing(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        qps = args.steps / elapsed
+        scan_ms = stats["scan_ms"] / max(stats["timed_launches"], 1)
+        bytes_per_launch = stats["scan_bytes"] / max(stats["scan_launches"], 1)
+        achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        out = {
+            "metric": "queries/sec, exact scan 1M x 768 cosine k=10" if args.workload == "headline"
+            else "queries/sec, exact scan (%s)" % args.workload,
+            "value": round(qps, 2),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": {4: "u4", 8: "u8", 16: "u16", 32: "f32", 64: "f64"}[bits],
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %d x %d, %d-bit, %s, k=%d, 1 query per sweep" % (
+                    args.workload, n_rows, dim, bits, "cosine" if metric else "euclidean", k),
+                "rows": n_rows, "dim": dim, "quantization": bits,
+                "distance": "cosine" if metric else "euclidean", "k": k,
+                "queries_per_sweep": 1,
+                "parallelism": "rows sharded over %d GPU(s)%s" % (
+                    world, ", 1 all-gather per %d queries" % args.exchange_every if world > 1 else ""),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "kernel": "szg::scan_kernel<%d,%d,...>" % (bits, metric),
+                "bytes_per_launch": int(bytes_per_launch),
+                "avg_launch_ms": round(scan_ms, 5),
+                "launches": int(stats["timed_launches"]),
+            },
+            "escalations": int(stats["escalations"]),
+            "full_replays": int(stats["full_replays"]),
+        }
+
+    # ---- recall / parity spot check + CPU baseline (rank 0, N=1) -----------------
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import oracle as orc
+        orc.build()
+        cores = host_cores()
+        t0 = time.time()
+        sample_rows = min(n_rows, 100_000)
+        rows_host = ix.read_rows(0, sample_rows)  # the same bytes the GPU scans
+        # single-thread rate first, to size the all-core sample
+        secs1, _ = orc.bench_topk(rows_host, dim, bits, metric, qt[:1], k, 1)
+        per_query = max(secs1, 1e-6)
+        nq = int(max(cores, min(len(qt), cores * args.cpu_seconds / per_query)))
+        nq = min(nq, len(qt))
+        secs, cpu_rows = orc.bench_topk(rows_host, dim, bits, metric, qt[:nq], k, cores)
+        scale = sample_rows / float(n_rows)
+        out["cpu_baseline"] = {
+            "value": round(nq / secs * scale, 3),
+            "unit": "queries/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": "%d queries x first %d of %d rows on %d threads (%.1f s), scaled linearly to "
+                      "%d rows; C port of the reference's Go scan (no Go toolchain here)" % (
+                          nq, sample_rows, n_rows, cores, secs, n_rows),
+            "single_thread": round(1.0 / per_query * scale, 4),
+        }
+        log("cpu_baseline leg: %.1f s" % (time.time() - t0))
+        # parity on the FULL corpus for a few queries: ids identical, distances bit-equal
+        nv = min(args.verify, len(qt))
+        if nv > 0:
+            t0 = time.time()
+            rows_all = rows_host if sample_rows == n_rows else ix.read_rows(0, n_rows)
+            _, ref_rows = orc.bench_topk(rows_all, dim, bits, metric, qt[:nv], k, min(cores, nv))
+            same = sum(int((ref_rows[i] == res_rows[i]).all()) for i in range(nv))
+            recall = float(np.mean([len(set(ref_rows[i]) & set(res_rows[i])) / float(k)
+                                    for i in range(nv)]))
+            out["parity"] = {"queries_checked": nv, "ids_identical": same, "recall_at_k": recall}
+            log("parity leg: %.1f s" % (time.time() - t0))
+            if same != nv:
+                log("bench.py: PARITY FAILURE: GPU ids differ from the oracle's")
+                print(json.dumps(out))
+                sys.exit(1)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ix.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

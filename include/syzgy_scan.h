@@ -117,6 +117,24 @@ int szg_search_radius(szg_index *ix, const double *query, double radius,
                       const uint64_t *allow_bits, uint64_t *out_rows, double *out_dist,
                       uint64_t capacity, uint64_t *out_total);
 
+/*
+ * Cross-shard result assembly for one-process-per-GPU sharding (host code, no
+ * device work).  Every rank answers the batch on its own row range with
+ * szg_search_topk asking for list_len = k+1 results (rows made global with
+ * szg_index_set_row_base); the per-rank lists are exchanged with one RCCL
+ * all-gather and merged here by replaying consider()'s top-k branch
+ * (collection.go:606-619) over their union in visit order.
+ *   rows/dist  [n_lists][n_queries][list_len], counts [n_lists][n_queries]
+ *   out_*      [n_queries][k] (+ out_count[n_queries])
+ *   out_history_dependent  nullable, [n_queries]: 1 when two of the best k+1
+ *              distances are equal or NaN, i.e. the reference's answer depends
+ *              on its whole heap history and a single-handle search over the
+ *              unsharded corpus would take the exact-replay path.
+ */
+int szg_merge_topk(int k, int n_lists, int list_len, int n_queries, const uint64_t *rows,
+                   const double *dist, const int32_t *counts, uint64_t *out_rows,
+                   double *out_dist, int32_t *out_count, uint8_t *out_history_dependent);
+
 /* ---- diagnostics -------------------------------------------------------- */
 
 const char *szg_strerror(int code);
@@ -143,7 +161,9 @@ int szg_reset_stats(szg_index *ix);
 
 /*
  * Tunables: "slack" (extra candidates kept beyond k), "blocks_per_cu",
- * "block_threads", "tie_mode" (0 = default: when two of the best k+1 distances
+ * "block_threads", "query_batch" (queries one scan launch walks back to back,
+ * default 16), "contexts" (batches in flight per shard), "serialize_scans",
+ * "tie_mode" (0 = default: when two of the best k+1 distances
  * are exactly equal, or one is NaN, the reference's output depends on its whole
  * heap history, so the query is re-answered by an exact replay over every row;
  * 1 = keep the fast answer, which is a valid top-k whose order among equal

@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsyzgy_scan.so")
+# SZG_LIB_PATH selects an alternative build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("SZG_LIB_PATH") or os.path.join(_HERE, "libsyzgy_scan.so")
 
 SZG_EUCLIDEAN = 0
 SZG_COSINE = 1
@@ -29,6 +30,7 @@ EXPORTS = [
     "szg_index_live_rows", "szg_index_read_rows", "szg_search_topk", "szg_search_radius",
     "szg_strerror", "szg_last_error", "szg_abi_version", "szg_set_timing", "szg_get_stats",
     "szg_reset_stats", "szg_set_option", "szg_index_synth", "szg_index_set_row_base",
+    "szg_merge_topk",
 ]
 
 
@@ -118,6 +120,9 @@ def load():
     L.szg_index_synth.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
     L.szg_index_set_row_base.restype = ctypes.c_int
     L.szg_index_set_row_base.argtypes = [vp, ctypes.c_uint64]
+    L.szg_merge_topk.restype = ctypes.c_int
+    L.szg_merge_topk.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, u64p, f64p,
+                                 i32p, u64p, f64p, i32p, u8p]
     L.szg_debug_f64_probe.restype = ctypes.c_int
     L.szg_debug_f64_probe.argtypes = [ctypes.c_int, f64p, f64p, f64p, ctypes.c_uint64]
     _lib = L

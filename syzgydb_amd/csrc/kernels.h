@@ -47,8 +47,11 @@ struct ScanArgs {
     const uint64_t *live_bits;  // nullable: bit r == 0 -> tombstoned
     const uint64_t *allow_bits; // nullable: bit r == 0 -> filtered out (collection.go:592)
     const void *query;          // device, piece-swizzled (see prep_query in scan_api.cpp)
+    int n_queries;              // queries walked back to back by one launch
+    uint32_t query_stride;      // bytes between consecutive swizzled queries
+    uint32_t allow_stride;      // words between consecutive queries' allow masks
     int kp;                     // candidates kept per list (top-k mode)
-    uint64_t *block_lists;      // [grid][kp] sorted ascending (top-k mode)
+    uint64_t *block_lists;      // [n_queries][grid][kp] sorted ascending (top-k mode)
     // collect mode (radius search / escalation): every row with key <= thr is appended
     int collect;
     uint32_t thr_ukey;
@@ -63,8 +66,10 @@ hipError_t launch_scan(int qbits, int metric, const ScanArgs &a, int grid, int b
 // LDS bytes launch_scan needs for (qbits, map, kp, block)
 size_t scan_lds_bytes(int qbits, const RowMap &m, int kp, int block);
 
-// Merge n_lists sorted lists of kp candidates into ceil(n_lists/fan) lists.
-hipError_t launch_merge(const uint64_t *in, int n_lists, int kp, int fan, uint64_t *out,
+// Merge n_lists sorted lists of kp candidates into ceil(n_lists/merge_fan(kp)) lists.
+int merge_fan(int kp);
+// Lists are [n_queries][n_lists][kp]; the output is [n_queries][n_out][kp].
+hipError_t launch_merge(const uint64_t *in, int n_lists, int kp, int n_queries, uint64_t *out,
                         hipStream_t stream);
 
 struct RerankOut {
@@ -73,10 +78,11 @@ struct RerankOut {
     uint32_t ukey;  // the scan's ordered key for that row
 };
 
-// Exact float64 distances, reference operation order, for n candidates.
+// Exact float64 distances, reference operation order, for n candidates of each of
+// n_queries queries: query_f64 [n_queries][dim], cands/out [n_queries][n_cands_max].
 hipError_t launch_rerank(int qbits, int metric, const uint8_t *rows, uint32_t pitch, int dim,
                          const double *query_f64, const uint64_t *cands, const uint32_t *n_cands_dev,
-                         uint32_t n_cands_max, RerankOut *out, hipStream_t stream);
+                         uint32_t n_cands_max, int n_queries, RerankOut *out, hipStream_t stream);
 
 // Page-in transform: reference row encoding (big-endian 16/32/64-bit) -> resident layout.
 hipError_t launch_repack(int qbits, const uint8_t *src, uint32_t row_bytes, uint8_t *dst,

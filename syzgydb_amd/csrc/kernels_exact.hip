@@ -108,6 +108,31 @@ __device__ __forceinline__ double decode_elem(const uint8_t *rp, int i)
     }
 }
 
+// ordered float64 sum  s = (((0 + p[0]) + p[1]) + ...)  by ONE lane: the order is
+// the reference's, so it cannot be parallelised, but the loads can run ahead.
+__device__ __forceinline__ double ordered_sum(double s, const double *p, int n)
+{
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const double v0 = p[i], v1 = p[i + 1], v2 = p[i + 2], v3 = p[i + 3];
+        const double v4 = p[i + 4], v5 = p[i + 5], v6 = p[i + 6], v7 = p[i + 7];
+        s = __dadd_rn(s, v0);
+        s = __dadd_rn(s, v1);
+        s = __dadd_rn(s, v2);
+        s = __dadd_rn(s, v3);
+        s = __dadd_rn(s, v4);
+        s = __dadd_rn(s, v5);
+        s = __dadd_rn(s, v6);
+        s = __dadd_rn(s, v7);
+    }
+    for (; i < n; i++) s = __dadd_rn(s, p[i]);
+    return s;
+}
+
+// One wave per candidate.  All lanes decode the row and form the per-element
+// products (each product is rounded once, exactly as `a*b` in Go); lanes 0..2
+// then add them up in index order, one accumulator each, as the loops of
+// collection.go:812-832 do.
 template <int QBITS, int METRIC>
 __global__ __launch_bounds__(64) void rerank_kernel(const uint8_t *rows, uint32_t pitch, int dim,
                                                     const double *query, const uint64_t *cands,
@@ -115,12 +140,16 @@ __global__ __launch_bounds__(64) void rerank_kernel(const uint8_t *rows, uint32_
                                                     RerankOut *out)
 {
     extern __shared__ __align__(16) uint8_t smem[];
-    double *drow = reinterpret_cast<double *>(smem);
-    double *qv = drow + dim;
+    constexpr int CH = 1024;                        // elements per LDS chunk
+    double *p0 = reinterpret_cast<double *>(smem);  // x*y   (euclid: diff*diff)
+    double *p1 = p0 + CH;                           // x*x
+    double *p2 = p1 + CH;                           // y*y
     const int lane = threadIdx.x;
     uint32_t n = n_max;
     if (n_dev) n = min(*n_dev, n_max);
-    for (int i = lane; i < dim; i += 64) qv[i] = query[i];
+    query += (size_t)blockIdx.y * dim;           // blockIdx.y = query of the batch
+    if (cands) cands += (size_t)blockIdx.y * n_max;
+    out += (size_t)blockIdx.y * n_max;
     for (uint32_t ci = blockIdx.x; ci < n; ci += gridDim.x) {
         // cands == nullptr: candidate ci is row ci (full exact replay of a shard)
         const uint64_t c = cands ? cands[ci] : (uint64_t)ci;
@@ -136,31 +165,41 @@ __global__ __launch_bounds__(64) void rerank_kernel(const uint8_t *rows, uint32_
         }
         const uint32_t row = (uint32_t)c;
         const uint8_t *rp = rows + (uint64_t)row * pitch;
-        __syncthreads();
-        for (int i = lane; i < dim; i += 64) drow[i] = decode_elem<QBITS>(rp, i);
-        __syncthreads();
+        double s = 0.0;
+        for (int base = 0; base < dim; base += CH) {
+            const int m = min(CH, dim - base);
+            __syncthreads();
+            for (int i = lane; i < m; i += 64) {
+                const double x = query[base + i];
+                const double y = decode_elem<QBITS>(rp, base + i);
+                if (METRIC == kEuclidean) {
+                    const double diff = __dsub_rn(x, y);
+                    p0[i] = __dmul_rn(diff, diff);
+                } else {
+                    p0[i] = __dmul_rn(x, y);
+                    p1[i] = __dmul_rn(x, x);
+                    p2[i] = __dmul_rn(y, y);
+                }
+            }
+            __syncthreads();
+            if (METRIC == kEuclidean) {
+                if (lane == 0) s = ordered_sum(s, p0, m);
+            } else {
+                if (lane < 3) s = ordered_sum(s, p0 + (size_t)lane * CH, m);
+            }
+        }
+        const double m1 = __shfl(s, 1);
+        const double m2 = __shfl(s, 2);
         if (lane == 0) {
             double dist;
             if (METRIC == kEuclidean) {  // collection.go:812-819
-                double sum = 0.0;
-                for (int i = 0; i < dim; i++) {
-                    const double diff = __dsub_rn(qv[i], drow[i]);
-                    sum = __dadd_rn(sum, __dmul_rn(diff, diff));
-                }
-                dist = __dsqrt_rn(sum);
+                dist = __dsqrt_rn(s);
             } else {  // collection.go:821-832
-                double dot = 0.0, m1 = 0.0, m2 = 0.0;
-                for (int i = 0; i < dim; i++) {
-                    const double x = qv[i], y = drow[i];
-                    dot = __dadd_rn(dot, __dmul_rn(x, y));
-                    m1 = __dadd_rn(m1, __dmul_rn(x, x));
-                    m2 = __dadd_rn(m2, __dmul_rn(y, y));
-                }
                 if (m1 == 0 || m2 == 0) {
                     dist = 1.0;
                 } else {
                     const double Pi = 3.14159265358979323846264338327950288;
-                    const double cosv = __ddiv_rn(dot, __dmul_rn(__dsqrt_rn(m1), __dsqrt_rn(m2)));
+                    const double cosv = __ddiv_rn(s, __dmul_rn(__dsqrt_rn(m1), __dsqrt_rn(m2)));
                     dist = __ddiv_rn(go_acos(cosv), Pi);
                 }
             }
@@ -306,16 +345,16 @@ __global__ void f64_probe_kernel(int op, const double *a, const double *b, doubl
 template <int QBITS>
 hipError_t launch_rerank_q(int metric, const uint8_t *rows, uint32_t pitch, int dim,
                            const double *q, const uint64_t *cands, const uint32_t *n_dev,
-                           uint32_t n_max, RerankOut *out, hipStream_t stream)
+                           uint32_t n_max, int n_queries, RerankOut *out, hipStream_t stream)
 {
-    if (n_max == 0) return hipSuccess;
-    const int grid = (int)(n_max < 4096u ? n_max : 4096u);
-    const size_t lds = (size_t)dim * 2 * sizeof(double);
+    if (n_max == 0 || n_queries == 0) return hipSuccess;
+    const dim3 grid(n_max < 4096u ? n_max : 4096u, n_queries);
+    const size_t lds = (size_t)1024 * 3 * sizeof(double);
     if (metric == kCosine)
-        hipLaunchKernelGGL((rerank_kernel<QBITS, kCosine>), dim3(grid), dim3(64), lds, stream, rows,
+        hipLaunchKernelGGL((rerank_kernel<QBITS, kCosine>), grid, dim3(64), lds, stream, rows,
                            pitch, dim, q, cands, n_dev, n_max, out);
     else
-        hipLaunchKernelGGL((rerank_kernel<QBITS, kEuclidean>), dim3(grid), dim3(64), lds, stream,
+        hipLaunchKernelGGL((rerank_kernel<QBITS, kEuclidean>), grid, dim3(64), lds, stream,
                            rows, pitch, dim, q, cands, n_dev, n_max, out);
     return hipGetLastError();
 }
@@ -324,14 +363,14 @@ hipError_t launch_rerank_q(int metric, const uint8_t *rows, uint32_t pitch, int 
 
 hipError_t launch_rerank(int qbits, int metric, const uint8_t *rows, uint32_t pitch, int dim,
                          const double *q, const uint64_t *cands, const uint32_t *n_dev,
-                         uint32_t n_max, RerankOut *out, hipStream_t stream)
+                         uint32_t n_max, int n_queries, RerankOut *out, hipStream_t stream)
 {
     switch (qbits) {
-    case 4: return launch_rerank_q<4>(metric, rows, pitch, dim, q, cands, n_dev, n_max, out, stream);
-    case 8: return launch_rerank_q<8>(metric, rows, pitch, dim, q, cands, n_dev, n_max, out, stream);
-    case 16: return launch_rerank_q<16>(metric, rows, pitch, dim, q, cands, n_dev, n_max, out, stream);
-    case 32: return launch_rerank_q<32>(metric, rows, pitch, dim, q, cands, n_dev, n_max, out, stream);
-    case 64: return launch_rerank_q<64>(metric, rows, pitch, dim, q, cands, n_dev, n_max, out, stream);
+    case 4: return launch_rerank_q<4>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream);
+    case 8: return launch_rerank_q<8>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream);
+    case 16: return launch_rerank_q<16>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream);
+    case 32: return launch_rerank_q<32>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream);
+    case 64: return launch_rerank_q<64>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream);
     default: return hipErrorInvalidValue;
     }
 }

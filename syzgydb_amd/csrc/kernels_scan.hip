@@ -20,6 +20,10 @@ namespace szg {
 namespace {
 
 constexpr int kWave = 64;
+#ifndef SZG_RING
+#define SZG_RING 8
+#endif
+constexpr int kRing = SZG_RING;  // 16-byte loads each lane keeps in flight
 
 template <int QBITS>
 struct Traits {
@@ -33,6 +37,20 @@ struct Traits<64> {
     using acc_t = double;
     static constexpr int QB = 8;
 };
+
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+// streaming 16-byte load of one piece of a packed row (read once per scan)
+__device__ __forceinline__ u32x4 load_piece(const uint8_t *p)
+{
+#ifdef SZG_PLAIN_LOADS
+    return *reinterpret_cast<const u32x4 *>(p);
+#else
+    // non-temporal: the corpus is far larger than L2 + Infinity Cache and each byte
+    // is used once per scan; measured 6.18 vs 5.66 TB/s on the 1M x 768 fp32 scan
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+#endif
+}
 
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src)
 {
@@ -191,12 +209,14 @@ struct Piece<4, METRIC> {
 };
 
 // ---- per-wave sorted candidate list in LDS ----------------------------------
-// Only the owning wave touches its list, DS operations of one wave complete in
-// issue order, so no barrier is needed; volatile keeps the compiler from
-// caching entries across the shuffle/ballot steps.
+// Only the owning wave touches its list and DS operations of one wave complete
+// in issue order, so no s_barrier is needed; the wave barriers stop the
+// compiler from moving one lane's store across another lane's load (it only
+// reasons per thread).  Plain (non-volatile) pointers keep the accesses ds_*
+// instructions: a volatile generic pointer would turn them into flat_* ops,
+// which drain the whole global-load queue on every use.
 
-__device__ __forceinline__ uint64_t list_insert(volatile uint64_t *list, int kp, uint64_t c,
-                                                int lane)
+__device__ __forceinline__ uint64_t list_insert(uint64_t *list, int kp, uint64_t c, int lane)
 {
     int pos = 0;
     for (int base = 0; base < kp; base += kWave) {
@@ -211,9 +231,12 @@ __device__ __forceinline__ uint64_t list_insert(volatile uint64_t *list, int kp,
         const bool mv = e > pos && e < kp;
         uint64_t v = 0;
         if (mv) v = list[e - 1];
+        __builtin_amdgcn_wave_barrier();
         if (mv) list[e] = v;
+        __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) list[pos] = c;
+    __builtin_amdgcn_wave_barrier();
     return list[kp - 1];
 }
 
@@ -230,7 +253,7 @@ __device__ __forceinline__ int lower_count(const uint64_t *list, int n, uint64_t
 
 // ---- the scan ---------------------------------------------------------------
 
-template <int QBITS, int METRIC>
+template <int QBITS, int METRIC, int D, bool COLLECT, bool MASKED>
 __global__ __launch_bounds__(512) void scan_kernel(const ScanArgs a)
 {
     using T = Traits<QBITS>;
@@ -244,51 +267,46 @@ __global__ __launch_bounds__(512) void scan_kernel(const ScanArgs a)
     const int r16 = a.map.r16;
     const int qbytes = r16 * T::E * T::QB;  // multiple of 16
 
-    {   // stage the query into LDS (it is L2-resident after the first block)
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.query);
-        uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (int i = tid; i < qbytes / 16; i += blockDim.x) dst[i] = src[i];
-    }
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem + qbytes);
-    volatile uint64_t *mylist = lists + (size_t)wave * a.kp;
-    if (!a.collect)
-        for (int i = lane; i < a.kp; i += kWave) mylist[i] = kInvalidCand;
-    __syncthreads();
-
+    uint64_t *mylist = lists + (size_t)wave * a.kp;
     const int L = a.map.L, P = a.map.P, gpw = a.map.gpw;
     const int grp = lane / L;
     const int lig = lane - grp * L;
     const bool active = grp < gpw;
     const uint64_t stride = (uint64_t)gridDim.x * nwaves * gpw;
+    const uint64_t row_first = ((uint64_t)blockIdx.x * nwaves + wave) * gpw;
+
+    // Query-major batch: one launch walks the corpus once per query, back to
+    // back.  Blocks move from query to query on their own (block-level barriers
+    // only), so there is no chip-wide tail or launch gap between queries.
+    for (int qi = 0; qi < a.n_queries; qi++) {
+    if (qi) __syncthreads();  // the previous query's lists have been merged
+    {   // stage the query into LDS (it is L2-resident after the first block)
+        const uint4 *src = reinterpret_cast<const uint4 *>(
+            reinterpret_cast<const uint8_t *>(a.query) + (size_t)qi * a.query_stride);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (int i = tid; i < qbytes / 16; i += blockDim.x) dst[i] = src[i];
+    }
+    if (!COLLECT)
+        for (int i = lane; i < a.kp; i += kWave) mylist[i] = kInvalidCand;
+    __syncthreads();
+    const uint64_t *allow_bits = a.allow_bits ? a.allow_bits + (size_t)qi * a.allow_stride : nullptr;
     uint64_t worst = kInvalidCand;
 
-    for (uint64_t row0 = ((uint64_t)blockIdx.x * nwaves + wave) * gpw; row0 < a.n_rows;
-         row0 += stride) {
-        const uint64_t row64 = row0 + grp;
-        const uint32_t row = (uint32_t)row64;
-        bool valid = active && row64 < a.n_rows;
-        if (valid && a.live_bits) valid = (a.live_bits[row >> 6] >> (row & 63)) & 1;
-        if (valid && a.allow_bits) valid = (a.allow_bits[row >> 6] >> (row & 63)) & 1;
-
-        acc_t a0 = 0, a1 = 0;
-        uint32_t nz = 0;
-        const uint8_t *rp = a.rows + (uint64_t)row * a.pitch;
-        for (int p0 = 0; p0 < P; p0 += 4) {
-            uint4 raw[4];
-            bool ok[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = (p0 + u) * L + lig;
-                ok[u] = valid && (p0 + u) < P && j < r16;
-                if (ok[u]) raw[u] = *reinterpret_cast<const uint4 *>(rp + (size_t)j * 16);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = (p0 + u) * L + lig;
-                if (ok[u]) Piece<QBITS, METRIC>::run(raw[u], smem, j, r16, a.dim, a0, a1, nz);
-            }
+    // is the row of this lane's group at wave-row `row0` to be scanned?
+    auto row_valid = [&](uint64_t row0) -> bool {
+        const uint64_t r = row0 + grp;
+        bool v = active && r < a.n_rows;
+        if (MASKED && v) {
+            const uint32_t rr = (uint32_t)r;
+            if (a.live_bits) v = (a.live_bits[rr >> 6] >> (rr & 63)) & 1;         // removed
+            if (v && allow_bits) v = (allow_bits[rr >> 6] >> (rr & 63)) & 1;      // filter
         }
-        // reduce the group's L lanes into its first lane
+        return v;
+    };
+
+    // One row is done: reduce the group's L lanes, form the key, select.
+    auto finish_row = [&](uint64_t row0, bool valid, acc_t a0, acc_t a1, uint32_t nz) {
         for (int w = L; w > 1;) {
             const int half = (w + 1) >> 1;
             const acc_t o0 = __shfl_down(a0, half);
@@ -301,7 +319,6 @@ __global__ __launch_bounds__(512) void scan_kernel(const ScanArgs a)
             }
             w = half;
         }
-
         float key;
         if (METRIC == kCosine) {
             // query is pre-normalised, so key = -cos; a zero row is distance 1.0
@@ -316,10 +333,11 @@ __global__ __launch_bounds__(512) void scan_kernel(const ScanArgs a)
         }
         if (!(key == key)) key = 3.0e38f;       // NaN: worst finite
         if (key > 3.0e38f) key = 3.0e38f;       // +inf (overflow): worst finite
+        const uint32_t row = (uint32_t)(row0 + grp);
         const uint64_t c = ((uint64_t)ordered_key(key) << 32) | row;
         const bool leader = valid && lig == 0;
 
-        if (a.collect) {
+        if (COLLECT) {
             const bool hit = leader && (uint32_t)(c >> 32) <= a.thr_ukey;
             const uint64_t m = __ballot(hit);
             if (m) {
@@ -341,13 +359,111 @@ __global__ __launch_bounds__(512) void scan_kernel(const ScanArgs a)
                 if (cc < worst) worst = list_insert(mylist, a.kp, cc, lane);
             }
         }
+    };
+
+    // The piece ring: every lane keeps D 16-byte loads in flight, walking its
+    // rows piece by piece (row-major), whatever the row size.  Slot u is consumed
+    // and immediately re-issued with the piece D steps ahead, so HBM requests
+    // keep flowing while a finished row is reduced and selected.  Loads are
+    // unconditional (idle lanes read a dummy address) and the steady-state loop
+    // is branch-free apart from the row-finish, so the compiler can emit
+    // counted s_waitcnt vmcnt(D-1) instead of draining the queue.
+    u32x4 ring[D];
+    uint32_t okmask = 0;
+    const uint64_t n_it = row_first < a.n_rows ? (a.n_rows - row_first + stride - 1) / stride : 0;
+    const uint64_t NP = n_it * (uint64_t)P;  // pieces this wave walks
+    // issue cursor
+    uint64_t irow0 = row_first;
+    int ip = 0;
+    bool ivalid = row_valid(irow0);
+    bool inext = MASKED ? row_valid(irow0 + stride) : false;
+    const uint8_t *irp = a.rows + (uint64_t)(uint32_t)(irow0 + grp) * a.pitch;
+    // consume cursor
+    uint64_t crow0 = row_first;
+    int cp = 0;
+    bool cvalid = false;
+    acc_t a0 = 0, a1 = 0;
+    uint32_t nz = 0;
+
+#define SZG_ISSUE(u)                                                                    \
+    {                                                                                   \
+        const int j_ = ip * L + lig;                                                    \
+        const bool ok_ = ivalid && j_ < r16;                                            \
+        ring[u] = load_piece(ok_ ? irp + (size_t)j_ * 16 : a.rows);                     \
+        okmask = (okmask & ~(1u << (u))) | ((uint32_t)ok_ << (u));                      \
+        if (++ip == P) {                                                                \
+            ip = 0;                                                                     \
+            irow0 += stride;                                                            \
+            irp = a.rows + (uint64_t)(uint32_t)(irow0 + grp) * a.pitch;                 \
+            if (MASKED) {                                                               \
+                ivalid = inext;                                                         \
+                inext = row_valid(irow0 + stride);                                      \
+            } else {                                                                    \
+                ivalid = active && irow0 + grp < a.n_rows;                              \
+            }                                                                           \
+        }                                                                               \
     }
 
-    if (a.collect) return;
+#define SZG_CONSUME(u)                                                                  \
+    {                                                                                   \
+        const int j_ = cp * L + lig;                                                    \
+        const bool ok_ = (okmask >> (u)) & 1u;                                          \
+        if (cp == 0) cvalid = ok_; /* piece 0 of the group's first lane is in range */  \
+        if (ok_) {                                                                      \
+            const u32x4 v_ = ring[u];                                                   \
+            Piece<QBITS, METRIC>::run(make_uint4(v_.x, v_.y, v_.z, v_.w), smem, j_, r16, \
+                                      a.dim, a0, a1, nz);                               \
+        }                                                                               \
+        if (++cp == P) {                                                                \
+            finish_row(crow0, cvalid, a0, a1, nz);                                      \
+            a0 = 0;                                                                     \
+            a1 = 0;                                                                     \
+            nz = 0;                                                                     \
+            cp = 0;                                                                     \
+            crow0 += stride;                                                            \
+        }                                                                               \
+    }
+
+    uint64_t issued = 0, consumed = 0;
+#pragma unroll
+    for (int u = 0; u < D; u++) {
+        if (issued < NP) {
+            SZG_ISSUE(u)
+            issued++;
+        }
+    }
+    // steady state: every slot consumed is re-issued
+    while (consumed + 2 * D <= NP) {
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            SZG_CONSUME(u)
+            SZG_ISSUE(u)
+        }
+        consumed += D;
+        issued += D;
+    }
+    // drain
+    while (consumed < NP) {
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            if (consumed < NP) {
+                SZG_CONSUME(u)
+                consumed++;
+                if (issued < NP) {
+                    SZG_ISSUE(u)
+                    issued++;
+                }
+            }
+        }
+    }
+#undef SZG_ISSUE
+#undef SZG_CONSUME
+
+    if (COLLECT) continue;
 
     // block-wide k-select: rank-merge the waves' sorted lists (entries are unique)
     __syncthreads();
-    uint64_t *out = a.block_lists + (size_t)blockIdx.x * a.kp;
+    uint64_t *out = a.block_lists + ((size_t)qi * gridDim.x + blockIdx.x) * a.kp;
     for (int i = tid; i < a.kp; i += blockDim.x) out[i] = kInvalidCand;
     __syncthreads();
     const int total = nwaves * a.kp;
@@ -364,10 +480,78 @@ __global__ __launch_bounds__(512) void scan_kernel(const ScanArgs a)
         }
         if (rank < a.kp) out[rank] = c;
     }
+    }  // for qi
 }
 
 // ---- merge of sorted candidate lists ----------------------------------------
 
+// minimum of a 64-bit value over the wave, returned in every lane: four DPP
+// steps reduce each row of 16 lanes, four readlanes finish across rows.
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
+{
+#define SZG_DPP_MIN(ctrl)                                                                  \
+    {                                                                                      \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(                        \
+            (int)(uint32_t)v, (int)(uint32_t)v, ctrl, 0xF, 0xF, false);                    \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(                        \
+            (int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), ctrl, 0xF, 0xF, false);    \
+        const uint64_t o_ = ((uint64_t)hi_ << 32) | lo_;                                   \
+        v = o_ < v ? o_ : v;                                                               \
+    }
+    SZG_DPP_MIN(0xB1)   // quad_perm [1,0,3,2]
+    SZG_DPP_MIN(0x4E)   // quad_perm [2,3,0,1]
+    SZG_DPP_MIN(0x141)  // row_half_mirror
+    SZG_DPP_MIN(0x140)  // row_mirror
+#undef SZG_DPP_MIN
+    uint64_t m = kInvalidCand;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, r * 16);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), r * 16);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
+        m = o < m ? o : m;
+    }
+    return m;
+}
+
+// Tournament merge: one wave per group of up to 64 sorted lists, one list per
+// lane; kp rounds of "take the smallest head".  Lists are staged in LDS with
+// coalesced loads first, so each round is a DPP reduction plus one LDS read.
+__global__ __launch_bounds__(256) void merge_heads_kernel(const uint64_t *in, int n_lists, int kp,
+                                                          uint64_t *out)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint64_t *lists = reinterpret_cast<uint64_t *>(smem);
+    const int lane = threadIdx.x & 63;
+    const int first = blockIdx.x * kWave;
+    const int mine = min(kWave, n_lists - first);
+    const int total = mine * kp;
+    in += (size_t)blockIdx.y * n_lists * kp;     // blockIdx.y = query of the batch
+    out += (size_t)blockIdx.y * gridDim.x * kp;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) lists[i] = in[(size_t)first * kp + i];
+    __syncthreads();
+    if (threadIdx.x >= kWave) return;  // the other waves only helped staging
+    int pos = 0;
+    uint64_t head = lane < mine ? lists[(size_t)lane * kp] : kInvalidCand;
+    uint64_t *o = out + (size_t)blockIdx.x * kp;
+    uint64_t keep = kInvalidCand;  // lane i keeps output i (+64 per round of 64)
+    for (int r = 0; r < kp; r++) {
+        const uint64_t m = wave_min_u64(head);
+        if (head == m && m != kInvalidCand) {  // entries are unique: exactly one lane advances
+            pos++;
+            head = pos < kp ? lists[(size_t)lane * kp + pos] : kInvalidCand;
+        }
+        if ((r & 63) == lane) keep = m;
+        if ((r & 63) == 63 || r == kp - 1) {
+            const int idx = (r & ~63) + lane;
+            if (idx <= r) o[idx] = keep;
+            keep = kInvalidCand;
+        }
+    }
+}
+
+// Rank merge (any kp): every entry finds its rank by binary searches in the
+// other lists.  More work, fully parallel; used when kp is large.
 __global__ __launch_bounds__(1024) void merge_kernel(const uint64_t *in, int n_lists, int kp,
                                                      int fan, uint64_t *out)
 {
@@ -376,6 +560,8 @@ __global__ __launch_bounds__(1024) void merge_kernel(const uint64_t *in, int n_l
     const int first = blockIdx.x * fan;
     const int mine = min(fan, n_lists - first);
     const int total = mine * kp;
+    in += (size_t)blockIdx.y * n_lists * kp;     // blockIdx.y = query of the batch
+    out += (size_t)blockIdx.y * gridDim.x * kp;
     for (int i = threadIdx.x; i < total; i += blockDim.x) lists[i] = in[(size_t)first * kp + i];
     uint64_t *o = out + (size_t)blockIdx.x * kp;
     for (int i = threadIdx.x; i < kp; i += blockDim.x) o[i] = kInvalidCand;
@@ -395,15 +581,31 @@ __global__ __launch_bounds__(1024) void merge_kernel(const uint64_t *in, int n_l
     }
 }
 
+template <int QBITS, int METRIC>
+hipError_t launch_scan_qm(const ScanArgs &a, int grid, int block, size_t lds, hipStream_t stream)
+{
+    const bool masked = a.live_bits != nullptr || a.allow_bits != nullptr;
+    const dim3 g(grid), b(block);
+    if (a.collect) {
+        if (masked)
+            hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, true, true>), g, b, lds, stream, a);
+        else
+            hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, true, false>), g, b, lds, stream, a);
+    } else {
+        if (masked)
+            hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, false, true>), g, b, lds, stream, a);
+        else
+            hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, false, false>), g, b, lds, stream, a);
+    }
+    return hipGetLastError();
+}
+
 template <int QBITS>
 hipError_t launch_scan_q(int metric, const ScanArgs &a, int grid, int block, size_t lds,
                          hipStream_t stream)
 {
-    if (metric == kCosine)
-        hipLaunchKernelGGL((scan_kernel<QBITS, kCosine>), dim3(grid), dim3(block), lds, stream, a);
-    else
-        hipLaunchKernelGGL((scan_kernel<QBITS, kEuclidean>), dim3(grid), dim3(block), lds, stream, a);
-    return hipGetLastError();
+    if (metric == kCosine) return launch_scan_qm<QBITS, kCosine>(a, grid, block, lds, stream);
+    return launch_scan_qm<QBITS, kEuclidean>(a, grid, block, lds, stream);
 }
 
 }  // namespace
@@ -429,16 +631,26 @@ hipError_t launch_scan(int qbits, int metric, const ScanArgs &a, int grid, int b
     }
 }
 
-hipError_t launch_merge(const uint64_t *in, int n_lists, int kp, int fan, uint64_t *out,
+int merge_fan(int kp)
+{
+    if (kp <= 128) return kWave;                       // tournament: one list per lane
+    return kp >= 4096 ? 2 : (8192 / kp < 32 ? 8192 / kp : 32);  // rank merge, <= 64 KiB of LDS
+}
+
+hipError_t launch_merge(const uint64_t *in, int n_lists, int kp, int n_queries, uint64_t *out,
                         hipStream_t stream)
 {
-    const int grid = (n_lists + fan - 1) / fan;
+    const int fan = merge_fan(kp);
+    const dim3 grid((n_lists + fan - 1) / fan, n_queries);
     const size_t lds = (size_t)fan * kp * sizeof(uint64_t);
+    if (kp <= 128) {
+        hipLaunchKernelGGL(merge_heads_kernel, grid, dim3(256), lds, stream, in, n_lists, kp, out);
+        return hipGetLastError();
+    }
     int block = fan * kp;
     if (block > 1024) block = 1024;
-    if (block < 64) block = 64;
     block = (block + 63) & ~63;
-    hipLaunchKernelGGL(merge_kernel, dim3(grid), dim3(block), lds, stream, in, n_lists, kp, fan, out);
+    hipLaunchKernelGGL(merge_kernel, grid, dim3(block), lds, stream, in, n_lists, kp, fan, out);
     return hipGetLastError();
 }
 

@@ -1,14 +1,15 @@
 // scan_api.cpp -- implementation of include/syzgy_scan.h (the C ABI).
 //
 // Host side of the drop-in: owns the HBM mirror of a Collection's packed
-// vectors, runs the per-query pipeline
-//     H2D query -> fused scan -> list merges -> float64 rerank -> D2H
+// vectors and runs, per batch of queries, the pipeline
+//     H2D queries -> fused scan (query-major, one launch per batch)
+//                 -> list merges -> float64 rerank -> D2H
 // on pooled HIP streams, then does the reference's result assembly on the few
 // survivors: certification of the candidate set, the container/heap replay of
 // consider() (collection.go:598-619) and the ascending pop loop (:694-697).
 //
 // There is no CPU scan in here: without a usable gfx950 device every entry
-// point fails with SZG_E_NODEVICE.
+// point that computes fails with SZG_E_NODEVICE.
 #include "../../include/syzgy_scan.h"
 #include "kernels.h"
 
@@ -25,6 +26,8 @@
 #include <vector>
 
 namespace {
+
+constexpr int kMaxBatch = 64;  // queries one scan launch may walk
 
 thread_local std::string g_last_error;
 
@@ -103,23 +106,43 @@ struct GoHeap {
         a.pop_back();
         return it;
     }
+    // consider()'s top-k branch for one visited record (collection.go:606-619)
+    void consider_topk(uint64_t row, double dist, int k)
+    {
+        if ((int)a.size() <= k) {
+            if ((int)a.size() < k || a[0].priority > dist) {
+                push(HeapItem{row, dist});
+                if ((int)a.size() > k) pop();
+            }
+        }
+    }
+    // the pop loop of collection.go:694-697: results in ascending order
+    void drain(std::vector<HeapItem> *out)
+    {
+        out->assign(a.size(), HeapItem{});
+        for (size_t i = out->size(); i-- > 0;) (*out)[i] = pop();
+    }
 };
 
 struct Cand {
-    uint64_t row;  // global row
+    uint64_t row;  // index-level row
     double dist;   // reference float64 distance
     float key;     // the scan's ranking key for this row
 };
 
-// ---- one in-flight query on one shard ------------------------------------------
+// ---- one in-flight batch of queries on one shard --------------------------------
 struct Ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr, ev_all0 = nullptr, ev_all1 = nullptr;
-    // pinned host staging
-    uint8_t *h_qsw = nullptr;      // swizzled query for the scan
-    double *h_q64 = nullptr;       // float64 query for the rerank
+    hipEvent_t ev_scan_done = nullptr;   // this batch's scans have finished (scan stream)
+    hipEvent_t ev_up = nullptr;          // this batch's uploads have finished (ctx stream)
+    // pinned host staging, kMaxBatch queries
+    uint8_t *h_qsw = nullptr;      // swizzled queries for the scan
+    double *h_q64 = nullptr;       // float64 queries for the rerank
     szg::RerankOut *h_out = nullptr;
     size_t h_out_cap = 0;
+    uint64_t *h_allow = nullptr;
+    size_t h_allow_cap = 0;        // words
     uint32_t *h_count = nullptr;
     // device scratch
     uint8_t *d_qsw = nullptr;
@@ -134,6 +157,7 @@ struct Ctx {
     size_t collect_cap = 0;        // entries
     uint32_t *d_count = nullptr;
     bool timed_scan = false;
+    int timed_n = 0;               // scan launches between ev_scan0 and ev_scan1
 };
 
 struct Shard {
@@ -148,9 +172,16 @@ struct Shard {
     bool has_dead = false;
     int cu_count = 256;
     std::vector<Ctx *> free_ctx;
+    std::vector<Ctx *> parked_ctx;   // contexts taken out of rotation ("contexts" option)
     std::vector<Ctx *> all_ctx;
     std::mutex mu;
     std::condition_variable cv;
+    // All scan launches of a shard go back to back onto ONE stream: each sweep
+    // gets the whole HBM bandwidth and the blocks of a launch stay in lockstep
+    // (that is what keeps DRAM pages hot); uploads and the small merge/rerank/
+    // copy work of other batches overlap them on the contexts' own streams.
+    std::mutex chain_mu;
+    hipStream_t scan_stream = nullptr;
 };
 
 }  // namespace
@@ -165,10 +196,12 @@ struct szg_index {
     // tunables
     int slack_min = 16;
     int n_ctx = 3;
-    int blocks_per_cu = 2;
-    int block_threads = 512;
+    int blocks_per_cu = 4;
+    int block_threads = 256;
+    int query_batch = 16;     // queries per scan launch
     int force_escalate = 0;   // test hook: treat every first pass as uncertified
     int tie_mode = 0;         // 0: exact full replay on ties/NaN, 1: keep the fast answer
+    int serialize_scans = 1;  // scan launches of a shard never overlap each other
     bool timing = false;
     std::mutex stats_mu;
     szg_stats stats{};
@@ -243,19 +276,22 @@ double key_eps(const szg_index *ix, double key, double qnorm)
 int ctx_alloc(szg_index *ix, Shard *sh, Ctx **out)
 {
     Ctx *c = new Ctx();
+    *out = c;
     HIPCHK(hipSetDevice(sh->device));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&c->ev_scan0));
     HIPCHK(hipEventCreate(&c->ev_scan1));
     HIPCHK(hipEventCreate(&c->ev_all0));
     HIPCHK(hipEventCreate(&c->ev_all1));
-    HIPCHK(hipHostMalloc((void **)&c->h_qsw, ix->qsw_bytes, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&c->h_q64, sizeof(double) * ix->dim, hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_scan_done, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
+    const size_t B = kMaxBatch;
+    HIPCHK(hipHostMalloc((void **)&c->h_qsw, B * ix->qsw_bytes, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&c->h_q64, B * sizeof(double) * ix->dim, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_count, sizeof(uint32_t) * 4, hipHostMallocDefault));
-    HIPCHK(hipMalloc((void **)&c->d_qsw, ix->qsw_bytes));
-    HIPCHK(hipMalloc((void **)&c->d_q64, sizeof(double) * ix->dim));
+    HIPCHK(hipMalloc((void **)&c->d_qsw, B * ix->qsw_bytes));
+    HIPCHK(hipMalloc((void **)&c->d_q64, B * sizeof(double) * ix->dim));
     HIPCHK(hipMalloc((void **)&c->d_count, sizeof(uint32_t) * 4));
-    *out = c;
     return SZG_OK;
 }
 
@@ -263,11 +299,12 @@ void ctx_free(Ctx *c)
 {
     if (!c) return;
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    for (hipEvent_t e : {c->ev_scan0, c->ev_scan1, c->ev_all0, c->ev_all1})
+    for (hipEvent_t e : {c->ev_scan0, c->ev_scan1, c->ev_all0, c->ev_all1, c->ev_scan_done, c->ev_up})
         if (e) (void)hipEventDestroy(e);
     (void)hipHostFree(c->h_qsw);
     (void)hipHostFree(c->h_q64);
     (void)hipHostFree(c->h_out);
+    (void)hipHostFree(c->h_allow);
     (void)hipHostFree(c->h_count);
     (void)hipFree(c->d_qsw);
     (void)hipFree(c->d_q64);
@@ -337,7 +374,7 @@ struct LaunchGeom {
 LaunchGeom scan_geometry(const szg_index *ix, const Shard *sh, int kp)
 {
     int block = ix->block_threads;
-    // keep the per-wave lists within ~96 KiB of LDS next to the query
+    // keep query + per-wave lists within 64 KiB of LDS
     while (block > 64 && szg::scan_lds_bytes(ix->bits, ix->map, kp, block) > 64u * 1024u) block >>= 1;
     const int nwaves = block / 64;
     const uint64_t rows_per_block = (uint64_t)nwaves * ix->map.gpw;
@@ -348,27 +385,37 @@ LaunchGeom scan_geometry(const szg_index *ix, const Shard *sh, int kp)
     return LaunchGeom{(int)grid, block};
 }
 
-// Enqueue H2D of the query (+ mask) on the ctx stream.
-int enqueue_query(szg_index *ix, Shard *sh, Ctx *c, const double *q, const uint64_t *allow_words)
+size_t shard_words(const Shard *sh) { return (size_t)((sh->n_rows + 63) / 64); }
+
+// Enqueue H2D of nq prepared queries (+ their masks) on the ctx stream.
+// allow: nq masks of allow_stride words each (index-level), or nullptr.
+int enqueue_queries(szg_index *ix, Shard *sh, Ctx *c, const double *q, int nq,
+                    const uint64_t *allow, size_t allow_stride)
 {
     HIPCHK(hipSetDevice(sh->device));
-    memcpy(c->h_q64, q, sizeof(double) * ix->dim);
+    memcpy(c->h_q64, q, sizeof(double) * ix->dim * nq);
     if (ix->timing) HIPCHK(hipEventRecord(c->ev_all0, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_qsw, c->h_qsw, ix->qsw_bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_q64, c->h_q64, sizeof(double) * ix->dim, hipMemcpyHostToDevice,
+    HIPCHK(hipMemcpyAsync(c->d_qsw, c->h_qsw, ix->qsw_bytes * nq, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_q64, c->h_q64, sizeof(double) * ix->dim * nq, hipMemcpyHostToDevice,
                           c->stream));
-    if (allow_words) {
-        const size_t words = (sh->n_rows + 63) / 64;
-        int rc = ensure_dev(&c->d_allow, &c->allow_cap, words);
+    if (allow) {
+        const size_t words = shard_words(sh);
+        int rc = ensure_dev(&c->d_allow, &c->allow_cap, words * nq);
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(c->d_allow, allow_words + sh->first / 64, words * sizeof(uint64_t),
+        rc = ensure_host(&c->h_allow, &c->h_allow_cap, words * nq);
+        if (rc) return rc;
+        for (int i = 0; i < nq; i++)
+            memcpy(c->h_allow + (size_t)i * words, allow + (size_t)i * allow_stride + sh->first / 64,
+                   words * sizeof(uint64_t));
+        HIPCHK(hipMemcpyAsync(c->d_allow, c->h_allow, words * nq * sizeof(uint64_t),
                               hipMemcpyHostToDevice, c->stream));
     }
     return SZG_OK;
 }
 
-void fill_scan_args(const szg_index *ix, const Shard *sh, const Ctx *c, bool has_allow,
-                    szg::ScanArgs *a)
+// scan arguments for queries [slot, slot+nq) of the ctx's staged batch
+void fill_scan_args(const szg_index *ix, const Shard *sh, const Ctx *c, bool has_allow, int slot,
+                    int nq, szg::ScanArgs *a)
 {
     memset(a, 0, sizeof(*a));
     a->rows = sh->rows;
@@ -377,69 +424,86 @@ void fill_scan_args(const szg_index *ix, const Shard *sh, const Ctx *c, bool has
     a->dim = ix->dim;
     a->map = ix->map;
     a->live_bits = sh->has_dead ? sh->live_bits : nullptr;
-    a->allow_bits = has_allow ? c->d_allow : nullptr;
-    a->query = c->d_qsw;
+    a->allow_stride = (uint32_t)shard_words(sh);
+    a->allow_bits = has_allow ? c->d_allow + (size_t)slot * a->allow_stride : nullptr;
+    a->query_stride = (uint32_t)ix->qsw_bytes;
+    a->query = c->d_qsw + (size_t)slot * ix->qsw_bytes;
+    a->n_queries = nq;
 }
 
-int record_scan(szg_index *ix, Ctx *c, bool before)
+// Launch the fused scan for each of the batch's queries (n = a->size()) as the
+// next links of the shard's scan chain; the ctx stream resumes after the last.
+int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg::ScanArgs> &a,
+                         const LaunchGeom &g)
 {
-    if (!ix->timing) return SZG_OK;
-    HIPCHK(hipEventRecord(before ? c->ev_scan0 : c->ev_scan1, c->stream));
-    if (!before) c->timed_scan = true;
+    const int n = (int)a.size();
+    {
+        std::lock_guard<std::mutex> lk(sh->chain_mu);
+        hipStream_t st = ix->serialize_scans ? sh->scan_stream : c->stream;
+        if (st != c->stream) {
+            HIPCHK(hipEventRecord(c->ev_up, c->stream));
+            HIPCHK(hipStreamWaitEvent(st, c->ev_up, 0));
+        }
+        if (ix->timing) HIPCHK(hipEventRecord(c->ev_scan0, st));
+        for (int j = 0; j < n; j++)
+            HIPCHK(szg::launch_scan(ix->bits, ix->metric, a[j], g.grid, g.block, st));
+        if (ix->timing) {
+            HIPCHK(hipEventRecord(c->ev_scan1, st));
+            c->timed_scan = true;
+            c->timed_n = n;
+        }
+        if (st != c->stream) {
+            HIPCHK(hipEventRecord(c->ev_scan_done, st));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_scan_done, 0));
+        }
+    }
+    std::lock_guard<std::mutex> lk(ix->stats_mu);
+    ix->stats.scan_launches += n;
+    ix->stats.scan_bytes += (uint64_t)n * sh->n_rows * (uint64_t)ix->row_bytes;
     return SZG_OK;
 }
 
-void account_scan(szg_index *ix, const Shard *sh)
-{
-    std::lock_guard<std::mutex> lk(ix->stats_mu);
-    ix->stats.scan_launches++;
-    ix->stats.scan_bytes += sh->n_rows * (uint64_t)ix->row_bytes;
-}
-
-// top-k pass on one shard: scan -> merges -> rerank -> D2H (all async)
-int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, bool has_allow)
+// top-k pass for the nq staged queries of one shard: scan -> merges -> rerank -> D2H (async)
+int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allow)
 {
     HIPCHK(hipSetDevice(sh->device));
     const LaunchGeom g = scan_geometry(ix, sh, kp);
-    int rc = SZG_OK;
-    if (c->lists_cap < (size_t)g.grid * kp) {  // both ping-pong buffers grow together
+    const size_t need = (size_t)nq * g.grid * kp;
+    if (c->lists_cap < need) {  // both ping-pong buffers grow together
         if (c->d_lists_a) HIPCHK(hipFree(c->d_lists_a));
         if (c->d_lists_b) HIPCHK(hipFree(c->d_lists_b));
         c->d_lists_a = c->d_lists_b = nullptr;
         c->lists_cap = 0;
-        const size_t n = (size_t)g.grid * kp;
-        HIPCHK(hipMalloc((void **)&c->d_lists_a, n * sizeof(uint64_t)));
-        HIPCHK(hipMalloc((void **)&c->d_lists_b, n * sizeof(uint64_t)));
-        c->lists_cap = n;
+        HIPCHK(hipMalloc((void **)&c->d_lists_a, need * sizeof(uint64_t)));
+        HIPCHK(hipMalloc((void **)&c->d_lists_b, need * sizeof(uint64_t)));
+        c->lists_cap = need;
     }
-    rc = ensure_dev(&c->d_out, &c->d_out_cap, (size_t)kp);
+    int rc = ensure_dev(&c->d_out, &c->d_out_cap, (size_t)nq * kp);
     if (rc) return rc;
-    rc = ensure_host(&c->h_out, &c->h_out_cap, (size_t)kp);
+    rc = ensure_host(&c->h_out, &c->h_out_cap, (size_t)nq * kp);
     if (rc) return rc;
 
-    szg::ScanArgs a;
-    fill_scan_args(ix, sh, c, has_allow, &a);
-    a.kp = kp;
-    a.block_lists = c->d_lists_a;
-    rc = record_scan(ix, c, true);
+    std::vector<szg::ScanArgs> args(nq);
+    for (int j = 0; j < nq; j++) {  // one sweep per query, results side by side
+        fill_scan_args(ix, sh, c, has_allow, j, 1, &args[j]);
+        args[j].kp = kp;
+        args[j].block_lists = c->d_lists_a + (size_t)j * g.grid * kp;
+    }
+    rc = launch_scans_chained(ix, sh, c, args, g);
     if (rc) return rc;
-    HIPCHK(szg::launch_scan(ix->bits, ix->metric, a, g.grid, g.block, c->stream));
-    rc = record_scan(ix, c, false);
-    if (rc) return rc;
-    account_scan(ix, sh);
 
     int n_lists = g.grid;
     uint64_t *src = c->d_lists_a, *dst = c->d_lists_b;
-    const int fan = std::max(2, std::min(32, 8192 / kp));
+    const int fan = szg::merge_fan(kp);
     while (n_lists > 1) {
-        HIPCHK(szg::launch_merge(src, n_lists, kp, fan, dst, c->stream));
+        HIPCHK(szg::launch_merge(src, n_lists, kp, nq, dst, c->stream));
         n_lists = (n_lists + fan - 1) / fan;
         std::swap(src, dst);
     }
     HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64, src,
-                              nullptr, (uint32_t)kp, c->d_out, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp, hipMemcpyDeviceToHost,
-                          c->stream));
+                              nullptr, (uint32_t)kp, nq, c->d_out, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp * nq,
+                          hipMemcpyDeviceToHost, c->stream));
     if (ix->timing) HIPCHK(hipEventRecord(c->ev_all1, c->stream));
     return SZG_OK;
 }
@@ -453,25 +517,22 @@ int finish_timing(szg_index *ix, Ctx *c)
     std::lock_guard<std::mutex> lk(ix->stats_mu);
     if (c->timed_scan) {
         ix->stats.scan_ms += ms_scan;
-        ix->stats.timed_launches++;
+        ix->stats.timed_launches += c->timed_n;
     }
     ix->stats.total_ms += ms_all;
     c->timed_scan = false;
     return SZG_OK;
 }
 
-// wait for a top-k pass, append its candidates; returns threshold key of the
-// shard (the worst kept key if the list is full, +inf if every row is in it)
-int collect_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, std::vector<Cand> *cands, double *thr)
+// candidates of staged query `slot` from a finished top-k pass; *thr = the worst
+// kept key if the shard's list is full, +inf if every eligible row is in it
+void gather_topk(const Shard *sh, const Ctx *c, int kp, int slot, std::vector<Cand> *cands,
+                 double *thr)
 {
-    HIPCHK(hipSetDevice(sh->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    int rc = finish_timing(ix, c);
-    if (rc) return rc;
     int valid = 0;
     float worst = -INFINITY;
     for (int i = 0; i < kp; i++) {
-        const szg::RerankOut &r = c->h_out[i];
+        const szg::RerankOut &r = c->h_out[(size_t)slot * kp + i];
         if (r.row == 0xFFFFFFFFu) continue;
         valid++;
         const float key = szg::key_from_ordered(r.ukey);
@@ -479,12 +540,12 @@ int collect_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, std::vector<Cand> *ca
         cands->push_back(Cand{sh->first + r.row, r.dist, key});
     }
     *thr = valid == kp ? (double)worst : INFINITY;
-    return SZG_OK;
 }
 
-// collect pass (radius search / escalation): every row with key <= thr_key,
-// reranked exactly.  Synchronous; grows the buffer and reruns on overflow.
-int run_collect(szg_index *ix, Shard *sh, Ctx *c, float thr_key, bool has_allow,
+// collect pass (radius search / escalation) for staged query `slot`: every row
+// with key <= thr_key, reranked exactly.  Synchronous; grows the buffer and
+// reruns on overflow.
+int run_collect(szg_index *ix, Shard *sh, Ctx *c, int slot, float thr_key, bool has_allow,
                 std::vector<Cand> *cands)
 {
     HIPCHK(hipSetDevice(sh->device));
@@ -493,21 +554,18 @@ int run_collect(szg_index *ix, Shard *sh, Ctx *c, float thr_key, bool has_allow,
     for (;;) {
         int rc = ensure_dev(&c->d_collect, &c->collect_cap, want);
         if (rc) return rc;
+        if (ix->timing) HIPCHK(hipEventRecord(c->ev_all0, c->stream));
         HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(uint32_t), c->stream));
-        szg::ScanArgs a;
-        fill_scan_args(ix, sh, c, has_allow, &a);
-        a.collect = 1;
-        a.thr_ukey = szg::ordered_key(thr_key);
-        a.collect_buf = c->d_collect;
-        a.collect_cap = (uint32_t)std::min<size_t>(c->collect_cap, 0xFFFFFFFFu);
-        a.collect_count = c->d_count;
+        std::vector<szg::ScanArgs> a(1);
+        fill_scan_args(ix, sh, c, has_allow, slot, 1, &a[0]);
+        a[0].collect = 1;
+        a[0].thr_ukey = szg::ordered_key(thr_key);
+        a[0].collect_buf = c->d_collect;
+        a[0].collect_cap = (uint32_t)std::min<size_t>(c->collect_cap, 0xFFFFFFFFu);
+        a[0].collect_count = c->d_count;
         const LaunchGeom g = scan_geometry(ix, sh, 0);
-        rc = record_scan(ix, c, true);
+        rc = launch_scans_chained(ix, sh, c, a, g);
         if (rc) return rc;
-        HIPCHK(szg::launch_scan(ix->bits, ix->metric, a, g.grid, g.block, c->stream));
-        rc = record_scan(ix, c, false);
-        if (rc) return rc;
-        account_scan(ix, sh);
         HIPCHK(hipMemcpyAsync(c->h_count, c->d_count, sizeof(uint32_t), hipMemcpyDeviceToHost,
                               c->stream));
         if (ix->timing) HIPCHK(hipEventRecord(c->ev_all1, c->stream));
@@ -517,7 +575,6 @@ int run_collect(szg_index *ix, Shard *sh, Ctx *c, float thr_key, bool has_allow,
         const uint32_t count = c->h_count[0];
         if (count > c->collect_cap) {
             want = (size_t)count + count / 8 + 1024;
-            if (ix->timing) HIPCHK(hipEventRecord(c->ev_all0, c->stream));
             continue;
         }
         if (count == 0) return SZG_OK;
@@ -525,8 +582,9 @@ int run_collect(szg_index *ix, Shard *sh, Ctx *c, float thr_key, bool has_allow,
         if (rc) return rc;
         rc = ensure_host(&c->h_out, &c->h_out_cap, (size_t)count);
         if (rc) return rc;
-        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64,
-                                  c->d_collect, nullptr, count, c->d_out, c->stream));
+        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim,
+                                  c->d_q64 + (size_t)slot * ix->dim, c->d_collect, nullptr, count, 1,
+                                  c->d_out, c->stream));
         HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * count,
                               hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -545,27 +603,19 @@ void replay_topk(std::vector<Cand> &cands, int k, std::vector<HeapItem> *result)
 {
     std::sort(cands.begin(), cands.end(), [](const Cand &x, const Cand &y) { return x.row < y.row; });
     GoHeap h;
-    for (const Cand &c : cands) {
-        if ((int)h.a.size() <= k) {
-            if ((int)h.a.size() < k || h.a[0].priority > c.dist) {
-                h.push(HeapItem{c.row, c.dist});
-                if ((int)h.a.size() > k) h.pop();
-            }
-        }
-    }
-    result->assign(h.a.size(), HeapItem{});
-    for (size_t i = result->size(); i-- > 0;) (*result)[i] = h.pop();
+    for (const Cand &c : cands) h.consider_topk(c.row, c.dist, k);
+    h.drain(result);
 }
 
 // True when the reference's answer may depend on its whole heap history: a NaN
 // distance, or two exactly equal distances among the best k+1 candidates.
-bool history_dependent(const std::vector<Cand> &cands, int k)
+bool history_dependent(const double *dist, size_t n, int k)
 {
     std::vector<double> d;
-    d.reserve(cands.size());
-    for (const Cand &c : cands) {
-        if (std::isnan(c.dist)) return true;
-        d.push_back(c.dist);
+    d.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        if (std::isnan(dist[i])) return true;
+        d.push_back(dist[i]);
     }
     const size_t m = std::min(d.size(), (size_t)k + 1);
     std::partial_sort(d.begin(), d.begin() + m, d.end());
@@ -578,7 +628,7 @@ bool history_dependent(const std::vector<Cand> &cands, int k)
 // consider(), :583-629): float64 distances for all rows on the device, then the
 // heap on the host in visit order.  Bit-faithful in every case, used only when
 // history_dependent() says the fast answer could differ.
-int run_full_replay(szg_index *ix, std::vector<Ctx *> &ctx, const uint64_t *allow, int k,
+int run_full_replay(szg_index *ix, std::vector<Ctx *> &ctx, int slot, const uint64_t *allow, int k,
                     std::vector<HeapItem> *res)
 {
     GoHeap h;
@@ -592,8 +642,9 @@ int run_full_replay(szg_index *ix, std::vector<Ctx *> &ctx, const uint64_t *allo
         if (rc) return rc;
         rc = ensure_host(&c->h_out, &c->h_out_cap, n);
         if (rc) return rc;
-        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64,
-                                  nullptr, nullptr, (uint32_t)n, c->d_out, c->stream));
+        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim,
+                                  c->d_q64 + (size_t)slot * ix->dim, nullptr, nullptr, (uint32_t)n, 1,
+                                  c->d_out, c->stream));
         HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * n, hipMemcpyDeviceToHost,
                               c->stream));
         std::vector<uint64_t> live((n + 63) / 64, ~0ull);
@@ -605,24 +656,17 @@ int run_full_replay(szg_index *ix, std::vector<Ctx *> &ctx, const uint64_t *allo
         for (size_t r = 0; r < n; r++) {
             if (!((live[r >> 6] >> (r & 63)) & 1)) continue;       // removed record
             if (aw && !((aw[r >> 6] >> (r & 63)) & 1)) continue;   // collection.go:592-594
-            const double dist = c->h_out[r].dist;
-            if ((int)h.a.size() <= k) {                            // collection.go:606-619
-                if ((int)h.a.size() < k || h.a[0].priority > dist) {
-                    h.push(HeapItem{sh->first + r, dist});
-                    if ((int)h.a.size() > k) h.pop();
-                }
-            }
+            h.consider_topk(sh->first + r, c->h_out[r].dist, k);
         }
     }
-    res->assign(h.a.size(), HeapItem{});
-    for (size_t i = res->size(); i-- > 0;) (*res)[i] = h.pop();
+    h.drain(res);
     return SZG_OK;
 }
 
 struct Ticket {
-    int query = -1;
-    std::vector<Ctx *> ctx;  // one per shard
-    double qnorm = 0, m1 = 0;
+    int first = 0, nq = 0;       // queries [first, first+nq) of the call
+    std::vector<Ctx *> ctx;      // one per shard
+    std::vector<double> qnorm, m1;
     int kp = 0;
 };
 
@@ -642,28 +686,44 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
             return fail(SZG_E_UNSUPPORTED, "k too large for the fused selection (LDS)");
     }
 
+    // result assembly for one finished batch
     auto finish = [&](Ticket &t) -> int {
-        const int qi = t.query;
-        const uint64_t *allow = allow_bits ? allow_bits + (size_t)qi * allow_stride : nullptr;
-        std::vector<Cand> cands;
-        double thr_min = INFINITY;
         int rc = SZG_OK;
         for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
             Shard *sh = ix->shards[s];
             if (sh->n_rows == 0) continue;
-            double thr;
-            rc = collect_topk(ix, sh, t.ctx[s], t.kp, &cands, &thr);
-            thr_min = std::min(thr_min, thr);
+            hipError_t e = hipSetDevice(sh->device);
+            if (e == hipSuccess) e = hipStreamSynchronize(t.ctx[s]->stream);
+            if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "hipStreamSynchronize", e);
+            if (rc == SZG_OK) rc = finish_timing(ix, t.ctx[s]);
         }
-        std::vector<HeapItem> res;
+        // gather every query's candidates first: the escalation and replay paths
+        // below reuse the contexts' output buffers
+        std::vector<std::vector<Cand>> all(t.nq);
+        std::vector<double> thr_min(t.nq, INFINITY);
         if (rc == SZG_OK) {
+            for (int j = 0; j < t.nq; j++) {
+                for (size_t s = 0; s < n_sh; s++) {
+                    Shard *sh = ix->shards[s];
+                    if (sh->n_rows == 0) continue;
+                    double thr;
+                    gather_topk(sh, t.ctx[s], t.kp, j, &all[j], &thr);
+                    thr_min[j] = std::min(thr_min[j], thr);
+                }
+            }
+        }
+        for (int j = 0; j < t.nq && rc == SZG_OK; j++) {
+            const int qi = t.first + j;
+            const uint64_t *allow = allow_bits ? allow_bits + (size_t)qi * allow_stride : nullptr;
+            std::vector<Cand> &cands = all[j];
+            std::vector<HeapItem> res;
             replay_topk(cands, k, &res);
             // certification: every row outside the lists has scan key >= thr_min, so
             // the result is final once its worst key clears thr_min by the error bound
             bool certified = true;
             float kmax = -INFINITY;
-            const bool zero_query = ix->metric == SZG_COSINE && t.m1 == 0;  // all distances 1.0
-            if (std::isfinite(thr_min) && !zero_query) {
+            const bool zero_query = ix->metric == SZG_COSINE && t.m1[j] == 0;  // all distances 1.0
+            if (std::isfinite(thr_min[j]) && !zero_query) {
                 std::vector<std::pair<uint64_t, float>> by_row;  // cands are sorted by row now
                 by_row.reserve(cands.size());
                 for (const Cand &c : cands) by_row.emplace_back(c.row, c.key);
@@ -672,11 +732,11 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                                                std::make_pair(h.row, -INFINITY));
                     kmax = std::max(kmax, it->second);
                 }
-                const double lhs =
-                    (double)kmax + key_eps(ix, kmax, t.qnorm) + key_eps(ix, thr_min, t.qnorm);
-                certified = (int)res.size() == k && lhs < thr_min;
+                const double lhs = (double)kmax + key_eps(ix, kmax, t.qnorm[j]) +
+                                   key_eps(ix, thr_min[j], t.qnorm[j]);
+                certified = (int)res.size() == k && lhs < thr_min[j];
             }
-            if (ix->force_escalate && std::isfinite(thr_min)) certified = false;
+            if (ix->force_escalate && std::isfinite(thr_min[j])) certified = false;
             if (!certified) {
                 {
                     std::lock_guard<std::mutex> lk(ix->stats_mu);
@@ -684,50 +744,58 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 }
                 double thr = INFINITY;
                 if ((int)res.size() == k && std::isfinite(kmax) && !zero_query)
-                    thr = (double)kmax + 2.1 * key_eps(ix, (double)kmax + key_eps(ix, kmax, t.qnorm), t.qnorm);
-                float thr_f = thr >= 3.0e38 ? 3.0e38f : std::nextafter((float)thr, INFINITY);
+                    thr = (double)kmax +
+                          2.1 * key_eps(ix, (double)kmax + key_eps(ix, kmax, t.qnorm[j]), t.qnorm[j]);
+                const float thr_f = thr >= 3.0e38 ? 3.0e38f : std::nextafter((float)thr, INFINITY);
                 cands.clear();
                 for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
                     Shard *sh = ix->shards[s];
                     if (sh->n_rows == 0) continue;
-                    if (ix->timing) (void)hipEventRecord(t.ctx[s]->ev_all0, t.ctx[s]->stream);
-                    rc = run_collect(ix, sh, t.ctx[s], thr_f, allow != nullptr, &cands);
+                    rc = run_collect(ix, sh, t.ctx[s], j, thr_f, allow != nullptr, &cands);
                 }
                 if (rc == SZG_OK) replay_topk(cands, k, &res);
             }
-            if (rc == SZG_OK && ix->tie_mode == 0 && history_dependent(cands, k)) {
-                {
-                    std::lock_guard<std::mutex> lk(ix->stats_mu);
-                    ix->stats.full_replays++;
+            if (rc == SZG_OK && ix->tie_mode == 0) {
+                std::vector<double> d(cands.size());
+                for (size_t i = 0; i < cands.size(); i++) d[i] = cands[i].dist;
+                if (history_dependent(d.data(), d.size(), k)) {
+                    {
+                        std::lock_guard<std::mutex> lk(ix->stats_mu);
+                        ix->stats.full_replays++;
+                    }
+                    rc = run_full_replay(ix, t.ctx, j, allow, k, &res);
                 }
-                rc = run_full_replay(ix, t.ctx, allow, k, &res);
             }
+            if (rc) break;
+            for (int i = 0; i < k; i++) {
+                const bool have = i < (int)res.size();
+                out_rows[(size_t)qi * k + i] = have ? res[i].row + ix->row_base : UINT64_MAX;
+                out_dist[(size_t)qi * k + i] = have ? res[i].priority : 0.0;
+            }
+            if (out_count) out_count[qi] = (int32_t)res.size();
         }
         for (size_t s = 0; s < n_sh; s++)
             if (t.ctx[s]) ctx_release(ix->shards[s], t.ctx[s]);
         t.ctx.assign(n_sh, nullptr);
-        if (rc) return rc;
-        for (int i = 0; i < k; i++) {
-            const bool have = i < (int)res.size();
-            out_rows[(size_t)qi * k + i] = have ? res[i].row + ix->row_base : UINT64_MAX;
-            out_dist[(size_t)qi * k + i] = have ? res[i].priority : 0.0;
-        }
-        if (out_count) out_count[qi] = (int32_t)res.size();
-        {
+        if (rc == SZG_OK) {
             std::lock_guard<std::mutex> lk(ix->stats_mu);
-            ix->stats.queries++;
+            ix->stats.queries += t.nq;
         }
-        return SZG_OK;
+        return rc;
     };
 
     std::deque<Ticket> inflight;
     int rc = SZG_OK;
-    for (int qi = 0; qi < n_queries && rc == SZG_OK; qi++) {
+    const int B = std::max(1, std::min(ix->query_batch, kMaxBatch));
+    for (int q0 = 0; q0 < n_queries && rc == SZG_OK;) {
         Ticket t;
-        t.query = qi;
+        t.first = q0;
+        t.nq = std::min(B, n_queries - q0);
         t.kp = kp;
         t.ctx.assign(n_sh, nullptr);
-        // get one context per shard; never block while holding in-flight work
+        t.qnorm.assign(t.nq, 0.0);
+        t.m1.assign(t.nq, 0.0);
+        // one context per shard; never block while holding in-flight work
         bool got = true;
         for (size_t s = 0; s < n_sh; s++) {
             if (ix->shards[s]->n_rows == 0) continue;
@@ -743,19 +811,21 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 if (t.ctx[s]) ctx_release(ix->shards[s], t.ctx[s]);
             rc = finish(inflight.front());
             inflight.pop_front();
-            qi--;
             continue;
         }
-        const double *q = queries + (size_t)qi * ix->dim;
-        const uint64_t *allow = allow_bits ? allow_bits + (size_t)qi * allow_stride : nullptr;
+        const double *q = queries + (size_t)q0 * ix->dim;
+        const uint64_t *allow = allow_bits ? allow_bits + (size_t)q0 * allow_stride : nullptr;
         for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
             Shard *sh = ix->shards[s];
             if (sh->n_rows == 0) continue;
-            prep_query(ix, q, t.ctx[s]->h_qsw, &t.qnorm, &t.m1);
-            rc = enqueue_query(ix, sh, t.ctx[s], q, allow);
-            if (rc == SZG_OK) rc = enqueue_topk(ix, sh, t.ctx[s], kp, allow != nullptr);
+            for (int j = 0; j < t.nq; j++)
+                prep_query(ix, q + (size_t)j * ix->dim, t.ctx[s]->h_qsw + (size_t)j * ix->qsw_bytes,
+                           &t.qnorm[j], &t.m1[j]);
+            rc = enqueue_queries(ix, sh, t.ctx[s], q, t.nq, allow, allow_stride);
+            if (rc == SZG_OK) rc = enqueue_topk(ix, sh, t.ctx[s], kp, t.nq, allow != nullptr);
         }
         inflight.push_back(std::move(t));
+        q0 += inflight.back().nq;
     }
     while (!inflight.empty()) {
         int r2 = finish(inflight.front());
@@ -869,6 +939,26 @@ Shard *shard_of(szg_index *ix, uint64_t row, uint64_t *local)
     return nullptr;
 }
 
+int reset_shards(szg_index *ix, const std::vector<uint64_t> &counts)
+{
+    uint64_t first = 0;
+    for (size_t s = 0; s < ix->shards.size(); s++) {
+        Shard *sh = ix->shards[s];
+        HIPCHK(hipSetDevice(sh->device));
+        HIPCHK(hipDeviceSynchronize());
+        sh->first = first;
+        sh->n_rows = 0;
+        sh->n_live = 0;
+        sh->has_dead = false;
+        int rc = shard_reserve(ix, sh, counts[s]);
+        if (rc) return rc;
+        HIPCHK(szg::launch_fill_bits(sh->live_bits, counts[s], sh->bits_cap, nullptr));
+        HIPCHK(hipDeviceSynchronize());
+        first += counts[s];
+    }
+    return SZG_OK;
+}
+
 }  // namespace
 
 // ============================================================== C ABI ==========
@@ -956,6 +1046,11 @@ int szg_index_create(szg_index **out, int dim, int quant_bits, int metric, const
         ix->shards.push_back(sh);
     }
     for (Shard *sh : ix->shards) {
+        if (hipSetDevice(sh->device) != hipSuccess ||
+            hipStreamCreateWithFlags(&sh->scan_stream, hipStreamNonBlocking) != hipSuccess) {
+            szg_index_destroy(ix);
+            return fail(SZG_E_DEVICE, "hipStreamCreate(scan stream)");
+        }
         for (int i = 0; i < ix->n_ctx; i++) {
             Ctx *c = nullptr;
             int rc = ctx_alloc(ix, sh, &c);
@@ -979,6 +1074,7 @@ void szg_index_destroy(szg_index *ix)
         (void)hipSetDevice(sh->device);
         (void)hipDeviceSynchronize();
         for (Ctx *c : sh->all_ctx) ctx_free(c);
+        if (sh->scan_stream) (void)hipStreamDestroy(sh->scan_stream);
         (void)hipFree(sh->rows);
         (void)hipFree(sh->live_bits);
         delete sh;
@@ -998,26 +1094,6 @@ uint64_t szg_index_live_rows(const szg_index *ix)
     uint64_t n = 0;
     if (ix) for (const Shard *s : ix->shards) n += s->n_live;
     return n;
-}
-
-static int reset_shards(szg_index *ix, const std::vector<uint64_t> &counts)
-{
-    uint64_t first = 0;
-    for (size_t s = 0; s < ix->shards.size(); s++) {
-        Shard *sh = ix->shards[s];
-        HIPCHK(hipSetDevice(sh->device));
-        HIPCHK(hipDeviceSynchronize());
-        sh->first = first;
-        sh->n_rows = 0;
-        sh->n_live = 0;
-        sh->has_dead = false;
-        int rc = shard_reserve(ix, sh, counts[s]);
-        if (rc) return rc;
-        HIPCHK(szg::launch_fill_bits(sh->live_bits, counts[s], sh->bits_cap, nullptr));
-        HIPCHK(hipDeviceSynchronize());
-        first += counts[s];
-    }
-    return SZG_OK;
 }
 
 int szg_index_load(szg_index *ix, const uint8_t *rows, uint64_t n_rows)
@@ -1063,6 +1139,12 @@ int szg_index_append(szg_index *ix, const uint8_t *rows, uint64_t n_rows)
     Shard *sh = ix->shards.back();  // new rows extend the last shard's range
     HIPCHK(hipSetDevice(sh->device));
     HIPCHK(hipDeviceSynchronize());
+    if (sh->n_rows == 0) {  // keep ranges contiguous when earlier shards hold rows
+        uint64_t first = 0;
+        for (Shard *o : ix->shards)
+            if (o != sh) first += o->n_rows;
+        sh->first = first;
+    }
     int rc = shard_reserve(ix, sh, sh->n_rows + n_rows);
     if (rc) return rc;
     rc = upload_rows(ix, sh, sh->n_rows, rows, n_rows);
@@ -1161,7 +1243,8 @@ int szg_search_radius(szg_index *ix, const double *query, double radius,
     if (!(radius > 0)) return fail(SZG_E_INVALID, "radius must be > 0 (collection.go:598)");
     if (capacity && (!out_rows || !out_dist)) return fail(SZG_E_INVALID, "null output buffer");
     *out_total = 0;
-    if (szg_index_rows(ix) == 0) return SZG_OK;
+    const uint64_t total_rows = szg_index_rows(ix);
+    if (total_rows == 0) return SZG_OK;
 
     // key threshold that surely contains every row with distance <= radius
     double qnorm = 0, m1 = 0;
@@ -1189,8 +1272,8 @@ int szg_search_radius(szg_index *ix, const double *query, double radius,
         if (sh->n_rows == 0) continue;
         Ctx *c = ctx_acquire(sh);
         memcpy(c->h_qsw, tmp.data(), ix->qsw_bytes);
-        rc = enqueue_query(ix, sh, c, query, allow_bits);
-        if (rc == SZG_OK) rc = run_collect(ix, sh, c, thr_f, allow_bits != nullptr, &cands);
+        rc = enqueue_queries(ix, sh, c, query, 1, allow_bits, (total_rows + 63) / 64);
+        if (rc == SZG_OK) rc = run_collect(ix, sh, c, 0, thr_f, allow_bits != nullptr, &cands);
         ctx_release(sh, c);
     }
     if (rc) return rc;
@@ -1213,6 +1296,45 @@ int szg_search_radius(szg_index *ix, const double *query, double radius,
         ix->stats.queries++;
     }
     if (total > capacity) return fail(SZG_E_TRUNCATED, "radius search: capacity too small");
+    return SZG_OK;
+}
+
+/*
+ * Cross-shard result assembly for one-process-per-GPU sharding: every rank
+ * answers the query on its row range with szg_search_topk (list_len = k+1
+ * results, rows already global via szg_index_set_row_base), the per-rank
+ * lists are exchanged (RCCL all-gather) and this replays consider()'s top-k
+ * branch over their union in visit order.  Pure host code.
+ */
+int szg_merge_topk(int k, int n_lists, int list_len, int n_queries, const uint64_t *rows,
+                   const double *dist, const int32_t *counts, uint64_t *out_rows, double *out_dist,
+                   int32_t *out_count, uint8_t *out_history_dependent)
+{
+    if (k <= 0 || n_lists <= 0 || list_len <= 0 || n_queries < 0 || !rows || !dist || !counts ||
+        !out_rows || !out_dist)
+        return fail(SZG_E_INVALID, "bad argument");
+    std::vector<Cand> cands;
+    std::vector<HeapItem> res;
+    for (int q = 0; q < n_queries; q++) {
+        cands.clear();
+        for (int l = 0; l < n_lists; l++) {
+            const size_t base = ((size_t)l * n_queries + q) * list_len;
+            const int n = std::min<int>(counts[(size_t)l * n_queries + q], list_len);
+            for (int i = 0; i < n; i++) cands.push_back(Cand{rows[base + i], dist[base + i], 0.0f});
+        }
+        replay_topk(cands, k, &res);
+        if (out_history_dependent) {
+            std::vector<double> d(cands.size());
+            for (size_t i = 0; i < cands.size(); i++) d[i] = cands[i].dist;
+            out_history_dependent[q] = history_dependent(d.data(), d.size(), k) ? 1 : 0;
+        }
+        for (int i = 0; i < k; i++) {
+            const bool have = i < (int)res.size();
+            out_rows[(size_t)q * k + i] = have ? res[i].row : UINT64_MAX;
+            out_dist[(size_t)q * k + i] = have ? res[i].priority : 0.0;
+        }
+        if (out_count) out_count[q] = (int32_t)res.size();
+    }
     return SZG_OK;
 }
 
@@ -1257,6 +1379,24 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
         if (value != 64 && value != 128 && value != 256 && value != 512)
             return fail(SZG_E_INVALID, "block_threads must be 64/128/256/512");
         ix->block_threads = (int)value;
+    } else if (n == "query_batch") {
+        if (value < 1 || value > kMaxBatch) return fail(SZG_E_INVALID, "query_batch out of range");
+        ix->query_batch = (int)value;
+    } else if (n == "contexts") {
+        if (value < 1 || value > ix->n_ctx) return fail(SZG_E_INVALID, "contexts out of range");
+        for (Shard *sh : ix->shards) {   // call while no search is in flight
+            std::lock_guard<std::mutex> lk(sh->mu);
+            while (!sh->parked_ctx.empty()) {
+                sh->free_ctx.push_back(sh->parked_ctx.back());
+                sh->parked_ctx.pop_back();
+            }
+            while ((int64_t)sh->free_ctx.size() > value) {
+                sh->parked_ctx.push_back(sh->free_ctx.back());
+                sh->free_ctx.pop_back();
+            }
+        }
+    } else if (n == "serialize_scans") {
+        ix->serialize_scans = value != 0;
     } else if (n == "tie_mode") {
         if (value != 0 && value != 1) return fail(SZG_E_INVALID, "tie_mode must be 0 or 1");
         ix->tie_mode = (int)value;
