@@ -83,10 +83,11 @@ class ShardedSearcher:
         mine = torch.from_numpy(rec)
         if self.device is not None:
             mine = mine.to(self.device)
-        gathered = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype,
+        # concatenated along dim 0 (the form both RCCL and gloo accept), viewed [world, nq, .]
+        gathered = torch.empty((self.world * nq, mine.shape[1]), dtype=mine.dtype,
                                device=mine.device)
         self._dist.all_gather_into_tensor(gathered, mine, group=self.group)
-        g = gathered.cpu().numpy()
+        g = gathered.cpu().numpy().reshape(self.world, nq, -1)
         g_rows = np.ascontiguousarray(g[:, :, :kk]).view(np.uint64)
         g_dist = np.ascontiguousarray(g[:, :, kk:2 * kk]).view(np.float64)
         g_count = np.ascontiguousarray(g[:, :, 2 * kk]).astype(np.int32)

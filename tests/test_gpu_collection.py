@@ -1,0 +1,175 @@
+"""The reference's own search tests (collection_test.go), re-stated against the
+host mirror of its API: same calls, same assertions; the scan runs in HIP."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from syzgydb_amd import (Collection, CollectionOptions, Cosine, Euclidean, ScanIndex, SearchArgs)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_exhaustive_search():
+    """collection_test.go:549-612 TestExhaustiveSearch."""
+    c = Collection(CollectionOptions(Name="test_exhaustive_search", DistanceMethod=Euclidean,
+                                     DimensionCount=3))
+    docs = [(1, [1.0, 2.0, 3.0], b"doc1"), (2, [4.0, 5.0, 6.0], b"doc2"), (3, [7.0, 8.0, 9.0], b"doc3")]
+    for id, v, m in docs:
+        c.AddDocument(id, v, m)
+    res = c.Search(SearchArgs(Vector=[1.0, 2.0, 3.0], Precision="exact", K=3))
+    assert len(res.Results) == len(docs)
+    assert {r.ID for r in res.Results} == {1, 2, 3}
+    assert res.PercentSearched == 100.0
+    assert [r.Distance for r in res.Results] == [0.0, 5.196152422706632, 10.392304845413264]
+    assert res.Results[0].Metadata == b"doc1"
+    c.Close()
+
+
+def test_collection_search_modes():
+    """collection_test.go:283-382 TestCollectionSearch."""
+    opts = CollectionOptions(Name="test_collection", DistanceMethod=Euclidean, DimensionCount=2)
+    empty = Collection(opts)
+    assert len(empty.Search(SearchArgs(Vector=[50, 50], K=5)).Results) == 0
+    assert empty.Search(SearchArgs(Vector=[50, 50], K=5)).PercentSearched == 0
+    empty.Close()
+
+    c = Collection(CollectionOptions(Name="test_collection", DistanceMethod=Euclidean, DimensionCount=2))
+    rng = np.random.default_rng(1)
+    for i in range(10):
+        c.AddDocument(i, rng.uniform(0, 100, 2), b"metadata")
+    assert len(c.Search(SearchArgs(Vector=[50, 50], K=5)).Results) > 0           # Basic Search
+    assert len(c.Search(SearchArgs(Vector=[50, 50], K=3)).Results) <= 3          # Max Count
+    for r in c.Search(SearchArgs(Vector=[50, 50], Radius=10)).Results:           # Radius Search
+        assert r.Distance <= 10
+    res = c.Search(SearchArgs(Vector=[50, 50], K=5, Filter=lambda id, md: id % 2 == 0))
+    assert len(res.Results) == 5 and all(r.ID % 2 == 0 for r in res.Results)     # Filter Function
+    assert res.PercentSearched == 100.0   # counted before the filter (collection.go:589)
+    c.Close()
+
+
+def test_vector_search_with_4bit_quantization():
+    """collection_test.go:614-667."""
+    c = Collection(CollectionOptions(Name="4bit", DistanceMethod=Euclidean, DimensionCount=3,
+                                     Quantization=4))
+    rng = np.random.default_rng(2)
+    vecs = rng.uniform(0, 1, (10, 3))
+    for i in range(10):
+        c.AddDocument(i, vecs[i], b"metadata")
+    q = rng.uniform(0, 1, 3)
+    res = c.Search(SearchArgs(Vector=q, K=5))
+    assert len(res.Results) == 5
+    rows = orc.encode_rows(vecs, 4)
+    o_rows, o_dist, _ = orc.search_exact(rows, 3, 4, 0, q, k=5)
+    assert [r.ID for r in res.Results] == [int(x) for x in o_rows]
+    assert [r.Distance for r in res.Results] == list(o_dist)
+    c.Close()
+
+
+def test_cosine_exact_20000x3():
+    """collection_test.go:23-103 (the exact half): 20 000 x 3, Cosine, K=10, query = doc 0."""
+    rng = np.random.default_rng(0)
+    vecs = rng.uniform(0, 1, (20000, 3))
+    c = Collection(CollectionOptions(Name="cos", DistanceMethod=Cosine, DimensionCount=3))
+    c.AddDocuments(range(20000), vecs, [b"metadata_%d" % i for i in range(20000)])
+    res = c.Search(SearchArgs(Vector=vecs[0], K=10, Precision="exact"))
+    o_rows, o_dist, _ = orc.search_exact(orc.encode_rows(vecs, 64), 3, 64, 1, vecs[0], k=10)
+    assert [r.ID for r in res.Results] == [int(x) for x in o_rows]
+    got = np.array([r.Distance for r in res.Results])
+    assert ((got == o_dist) | (np.isnan(got) & np.isnan(o_dist))).all()
+    assert res.PercentSearched == 100.0
+    c.Close()
+
+
+def test_add_update_remove_and_listing():
+    """collection_test.go:459-534 / :196-281 in spirit: CRUD keeps the mirror in step."""
+    c = Collection(CollectionOptions(Name="crud", DistanceMethod=Euclidean, DimensionCount=4,
+                                     Quantization=32))
+    for i in range(20):
+        c.AddDocument(i, [i, 0, 0, 0], b"m%d" % i)
+    assert c.GetDocumentCount() == 20
+    assert list(c.GetDocument(7).Vector) == [7.0, 0, 0, 0]
+    res = c.Search(SearchArgs(Vector=[7.2, 0, 0, 0], K=2, Precision="exact"))
+    assert [r.ID for r in res.Results] == [7, 8]
+    c.removeDocument(7)
+    with pytest.raises(KeyError):
+        c.GetDocument(7)
+    res = c.Search(SearchArgs(Vector=[7.2, 0, 0, 0], K=2, Precision="exact"))
+    assert [r.ID for r in res.Results] == [8, 6]
+    assert res.PercentSearched == 100.0
+    c.AddDocument(3, [7.1, 0, 0, 0], b"moved")          # rewriting an id replaces its vector
+    res = c.Search(SearchArgs(Vector=[7.2, 0, 0, 0], K=1))
+    assert res.Results[0].ID == 3 and res.Results[0].Metadata == b"moved"
+    c.UpdateDocument(3, b"again")
+    assert c.Search(SearchArgs(Vector=[7.2, 0, 0, 0], K=1)).Results[0].Metadata == b"again"
+    # listing mode (K == 0 and Radius == 0): sorted *string* id order, Offset/Limit
+    ids = [r.ID for r in c.Search(SearchArgs(Offset=0, Limit=5)).Results]
+    assert ids == [0, 1, 10, 11, 12]
+    ids = [r.ID for r in c.Search(SearchArgs(Offset=2, Limit=3)).Results]
+    assert ids == [10, 11, 12]
+    with pytest.raises(ValueError):
+        c.AddDocument(99, [1, 2, 3], b"")                 # dimension mismatch panics (collection.go:432)
+    with pytest.raises(ValueError):
+        c.Search(SearchArgs(Vector=[1, 2, 3], K=1))       # query length is validated here
+    c.Close()
+
+
+def test_unsupported_options():
+    with pytest.raises(ValueError):
+        Collection(CollectionOptions(DistanceMethod=2, DimensionCount=3))
+    with pytest.raises(ValueError):
+        Collection(CollectionOptions(DistanceMethod=0, DimensionCount=3, Quantization=7))
+
+
+@pytest.mark.parametrize("bits,metric", [(32, 1), (8, 0), (4, 1)])
+def test_two_shards_on_one_device_equal_one_shard(bits, metric):
+    """devices=[0, 0] exercises the in-process sharding + cross-shard assembly on one GPU."""
+    dim, n = 40, 5000
+    rows = orc.synth_rows(9, 0, n, dim, bits)
+    Q = orc.synth_vectors(10, 0, 5, dim)
+    allow = np.arange(n) % 5 != 0
+    with ScanIndex(dim, bits, metric, devices=[0, 0]) as two, ScanIndex(dim, bits, metric) as one:
+        two.load(rows)
+        one.load(rows)
+        assert two.rows == n
+        for kw in ({}, {"allow": np.tile(allow, (5, 1))}):
+            r2, d2, c2 = two.search_topk(Q, 10, **kw)
+            r1, d1, c1 = one.search_topk(Q, 10, **kw)
+            assert (r2 == r1).all() and (d2 == d1).all() and (c2 == c1).all()
+        for qi in range(2):
+            o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, Q[qi], k=10,
+                                                 allow=allow.astype(np.uint8))
+            assert [int(x) for x in r2[qi]] == [int(x) for x in o_rows]
+            assert (d2[qi] == o_dist).all()
+        alld = orc.all_distances(rows, dim, bits, metric, Q[0])
+        radius = float(np.sort(alld)[40])
+        ra, da = two.search_radius(Q[0], radius)
+        rb, db = one.search_radius(Q[0], radius)
+        assert (ra == rb).all() and (da == db).all() and len(ra) == 41
+        assert (two.read_rows(0, n) == rows).all()
+        two.tombstone(int(r2[0, 0]))
+        r3, _, _ = two.search_topk(Q[0], 10)
+        assert int(r2[0, 0]) not in [int(x) for x in r3[0]]
+
+
+def test_concurrent_searches_from_threads():
+    """The reference serves Searches concurrently under RLock (collection.go:570)."""
+    import threading
+    dim, n, bits = 32, 20000, 32
+    rows = orc.synth_rows(21, 0, n, dim, bits)
+    Q = orc.synth_vectors(22, 0, 24, dim)
+    want = [orc.search_exact(rows, dim, bits, 1, Q[i], k=5)[0] for i in range(Q.shape[0])]
+    with ScanIndex(dim, bits, 1) as ix:
+        ix.load(rows)
+        errs = []
+
+        def worker(t):
+            try:
+                for i in range(t, Q.shape[0], 6):
+                    r, _, _ = ix.search_topk(Q[i], 5)
+                    assert [int(x) for x in r[0]] == [int(x) for x in want[i]]
+            except Exception as e:  # pragma: no cover
+                errs.append(e)
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs

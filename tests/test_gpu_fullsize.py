@@ -1,0 +1,96 @@
+"""BASELINE.json's configurations at (or near) full size, checked through
+size-independent properties plus oracle spot checks on the rows returned:
+
+  * the returned distances equal the oracle's distance for exactly those rows
+    (rows are read back from the device mirror, so this pins decode + distance);
+  * results ascend; top-10 is a prefix of top-100 (selection is consistent in k);
+  * a radius search at the k-th distance returns the same first k rows;
+  * a query equal to a stored row finds that row first;
+  * nothing outside the result beats the k-th distance, checked on a random sample
+    of rows (any miss of the scan would show up here with probability ~ sample/n).
+"""
+import numpy as np
+import pytest
+
+import oracle as orc
+from syzgydb_amd import ScanIndex
+from syzgydb_amd.synth import synth_vectors
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [
+    # name, rows, dim, bits, metric, k
+    ("cfg1-plumbing", 10_000, 128, 32, 1, 10),
+    ("cfg2", 1_000_000, 384, 32, 1, 10),
+    ("cfg3", 1_000_000, 768, 8, 1, 10),
+    ("headline", 1_000_000, 768, 32, 1, 10),
+    ("cfg4-one-gpu-shard", 1_250_000, 768, 32, 0, 100),     # 10M / 8 GPUs
+    ("cfg5-slice", 4_000_000, 384, 4, 1, 10),                # 100M x 384 4-bit, a 768 MB slice
+]
+
+
+def oracle_dist_for(ix, rows_idx, dim, bits, metric, q):
+    out = []
+    for r in rows_idx:
+        raw = ix.read_rows(int(r), 1)
+        out.append(orc.all_distances(raw, dim, bits, metric, q)[0])
+    return np.array(out)
+
+
+@pytest.mark.parametrize("name,n,dim,bits,metric,k", CONFIGS, ids=[c[0] for c in CONFIGS])
+def test_fullsize_properties(name, n, dim, bits, metric, k):
+    seed = 0x53595A4700000100 + len(name)
+    Q = synth_vectors(seed + 1, 0, 3, dim)
+    with ScanIndex(dim, bits, metric) as ix:
+        ix.synth(n, seed)
+        assert ix.rows == n
+        # device-side synthesis == oracle synthesis on a window in the middle
+        assert (ix.read_rows(n // 2, 4) == orc.synth_rows(seed, n // 2, 4, dim, bits)).all()
+        r, d, c = ix.search_topk(Q, k)
+        r100, d100, c100 = ix.search_topk(Q, max(100, k))
+        st = ix.stats()
+        for qi in range(Q.shape[0]):
+            assert c[qi] == k
+            assert (np.diff(d[qi]) >= 0).all()
+            assert (r100[qi, :k] == r[qi]).all() and (d100[qi, :k] == d[qi]).all()
+            want = oracle_dist_for(ix, r[qi], dim, bits, metric, Q[qi])
+            assert (want == d[qi]).all(), (want, d[qi])            # bit-exact float64
+            # sample of other rows: none may beat the k-th distance
+            rng = np.random.default_rng(qi)
+            sample = rng.integers(0, n, 300)
+            block = orc.synth_rows(seed, int(sample.min()), 1, dim, bits)  # warm the oracle
+            del block
+            sd = np.array([orc.all_distances(orc.synth_rows(seed, int(s), 1, dim, bits), dim, bits,
+                                             metric, Q[qi])[0] for s in sample[:60]])
+            inside = set(int(x) for x in r[qi])
+            for s, dist in zip(sample[:60], sd):
+                if int(s) not in inside:
+                    assert dist >= d[qi, k - 1]
+        # radius at the k-th distance returns the same leading rows
+        rr, dd = ix.search_radius(Q[0], float(d[0, k - 1]))
+        assert len(rr) >= k and (rr[:k] == r[0]).all() and (dd[:k] == d[0]).all()
+        # a stored row as the query comes back first (distance 0, or NaN/tiny for cosine)
+        target = n - 7
+        stored = orc.decode_vector(ix.read_rows(target, 1)[0], dim, bits)
+        r1, d1, _ = ix.search_topk(stored, 1)
+        o = orc.all_distances(ix.read_rows(target, 1), dim, bits, metric, stored)[0]
+        if not np.isnan(o):
+            assert int(r1[0, 0]) == target and d1[0, 0] == o
+        assert st["escalations"] == 0 or name.startswith("cfg5")
+
+
+def test_headline_full_oracle_scan_one_query():
+    """One full 1M x 768 oracle scan (a few seconds of CPU) against the HIP answer."""
+    n, dim, bits, metric, k = 1_000_000, 768, 32, 1, 10
+    seed = 0x53595A4700000200
+    q = synth_vectors(seed + 1, 0, 1, dim)
+    with ScanIndex(dim, bits, metric) as ix:
+        ix.synth(n, seed)
+        r, d, c = ix.search_topk(q, k)
+        rows = ix.read_rows(0, n)
+    o_rows, o_dist, searched = orc.search_exact(rows, dim, bits, metric, q[0], k=k)
+    assert searched == n
+    assert [int(x) for x in r[0]] == [int(x) for x in o_rows]
+    assert (d[0] == o_dist).all()
+    rel = np.abs(d[0] - o_dist) / o_dist
+    assert (rel <= 1e-5).all()   # the contract's tolerance; bit-equality above is stronger

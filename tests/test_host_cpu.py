@@ -1,0 +1,138 @@
+"""Host-side logic that needs no GPU: the numpy codec, the query synthesiser, the
+C-ABI library's exports, error paths and the cross-shard merge."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from golden_util import load_kats, same_f64
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_codec_matches_oracle(oracle):
+    from syzgydb_amd import codec
+    rng = np.random.default_rng(0)
+    V = rng.uniform(-1.3, 1.3, (64, 9))
+    V[0, :] = [0.0, 1.0, -1.0, 0.5, -0.5, 1e-9, -1e-9, 0.999999, -0.999999]
+    for bits in (4, 8, 16, 32, 64):
+        enc = codec.encode_rows(V, bits)
+        assert (enc == oracle.encode_rows(V, bits)).all(), bits
+        dec = codec.decode_rows(enc, 9, bits)
+        ref = np.stack([oracle.decode_vector(enc[i], 9, bits) for i in range(V.shape[0])])
+        assert same_f64(dec, ref), bits
+        assert codec.vector_size(bits, 9) == oracle.vector_size(bits, 9)
+    with pytest.raises(ValueError):
+        codec.vector_size(7, 3)
+
+
+def test_codec_kats():
+    from syzgydb_amd import codec
+    kat = load_kats()["encode_vector"]
+    for bits, hx in kat["bytes_hex"].items():
+        assert codec.encode_rows([kat["vector"]], int(bits)).tobytes().hex() == hx
+    # half away from zero, incl. the value just below a tie
+    assert int(codec.quantize(np.array([0.0]), 4)[0]) == 8
+    below = np.nextafter(0.5, 0) * 2 / 15 - 1  # (v+1)/2*15 just below 0.5
+    assert int(codec.quantize(np.array([below]), 4)[0]) == 0
+
+
+def test_synth_matches_oracle(oracle):
+    from syzgydb_amd.synth import splitmix64, synth_vectors
+    for seed, first, n, dim in ((1, 0, 3, 4), (0x53595A4700000003, 7, 5, 11), (2**63 + 5, 1000, 2, 768)):
+        assert (synth_vectors(seed, first, n, dim) == oracle.synth_vectors(seed, first, n, dim)).all()
+    assert int(splitmix64(np.array([12345], dtype=np.uint64))[0]) == oracle.splitmix64(12345)
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "syzgy_scan.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(szg_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from syzgydb_amd import _lib
+    L = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(L, name), "libsyzgy_scan.so does not export %s" % name
+    assert sorted(_lib.EXPORTS) == declared
+    assert L.szg_abi_version() == 1
+
+
+def test_error_paths_without_gpu_work():
+    from syzgydb_amd import _lib
+    L = _lib.load()
+    assert L.szg_strerror(0) == b"ok"
+    assert b"capacity" in L.szg_strerror(_lib.SZG_E_TRUNCATED)
+    assert L.szg_row_bytes(4, 3) == 2 and L.szg_row_bytes(32, 768) == 3072
+    assert L.szg_row_bytes(7, 3) == -1 and L.szg_row_bytes(8, 0) == -1
+    h = ctypes.c_void_p()
+    # bad arguments are rejected before any device work
+    assert L.szg_index_create(ctypes.byref(h), 0, 32, 1, None, 0) == _lib.SZG_E_INVALID
+    assert L.szg_index_create(ctypes.byref(h), 8, 5, 1, None, 0) == _lib.SZG_E_INVALID
+    assert L.szg_index_create(ctypes.byref(h), 8, 32, 2, None, 0) == _lib.SZG_E_INVALID
+    assert b"distance method" in L.szg_last_error()
+    assert L.szg_index_create(None, 8, 32, 1, None, 0) == _lib.SZG_E_INVALID
+
+
+def test_no_cpu_fallback_without_device():
+    """On a box without a GPU the product must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from syzgydb_amd import ScanIndex, SzgError, _lib
+    with pytest.raises(SzgError) as e:
+        ScanIndex(8, 32, 1)
+    assert e.value.code == _lib.SZG_E_NODEVICE
+
+
+def test_merge_topk_matches_oracle_over_shards(oracle):
+    from syzgydb_amd.sharded import merge_topk, shard_range
+    dim, bits, n, k, G = 12, 32, 1000, 10, 3
+    rows = oracle.synth_rows(5, 0, n, dim, bits)
+    Q = oracle.synth_vectors(6, 0, 4, dim)
+    for metric in (0, 1):
+        R = np.zeros((G, Q.shape[0], k + 1), np.uint64)
+        D = np.zeros((G, Q.shape[0], k + 1), np.float64)
+        C = np.zeros((G, Q.shape[0]), np.int32)
+        for g in range(G):
+            lo, hi = shard_range(n, g, G)
+            assert lo % 64 == 0
+            for qi in range(Q.shape[0]):
+                r, d, _ = oracle.search_exact(rows[lo:hi], dim, bits, metric, Q[qi], k=k + 1)
+                R[g, qi, : len(r)] = r + lo
+                D[g, qi, : len(r)] = d
+                C[g, qi] = len(r)
+        out_r, out_d, out_c, hist = merge_topk(k, R, D, C)
+        for qi in range(Q.shape[0]):
+            r, d, _ = oracle.search_exact(rows, dim, bits, metric, Q[qi], k=k)
+            assert [int(x) for x in out_r[qi, : out_c[qi]]] == [int(x) for x in r]
+            assert same_f64(out_d[qi, : out_c[qi]], d)
+            assert not hist[qi]
+
+
+def test_merge_topk_flags_ties_and_short_lists():
+    from syzgydb_amd.sharded import merge_topk
+    R = np.array([[[0, 1, 2]], [[64, 65, 66]]], np.uint64)
+    D = np.array([[[1.0, 2.0, 9.0]], [[2.0, 3.0, 9.0]]])
+    C = np.array([[2], [2]], np.int32)
+    r, d, c, hist = merge_topk(2, R, D, C)
+    assert list(r[0]) == [0, 1] and list(d[0]) == [1.0, 2.0] and hist[0]  # 2.0 == 2.0 at the boundary
+    r, d, c, hist = merge_topk(5, R, D, C)
+    assert c[0] == 4 and r[0, 4] == np.iinfo(np.uint64).max
+
+
+def test_shard_ranges_cover_everything():
+    from syzgydb_amd.sharded import shard_range
+    for n in (0, 1, 63, 64, 65, 1000, 1_000_000, 10_000_001):
+        for world in (1, 2, 3, 8):
+            prev = 0
+            for r in range(world):
+                lo, hi = shard_range(n, r, world)
+                assert lo == prev and hi >= lo
+                prev = hi
+            assert prev == n
