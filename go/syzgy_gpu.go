@@ -1,0 +1,217 @@
+//go:build syzgy_gpu
+
+// Package syzgydb: cgo binding of libsyzgy_scan.so (include/syzgy_scan.h), the
+// MI355X-native exact scan behind Collection.Search{Precision:"exact"}.
+//
+// This file is what a SyzgyDB maintainer adds to the reference tree
+// (github.com/smhanov/syzgydb, package syzgydb); INTEGRATION.md shows the few
+// lines of collection.go that call it.  It cannot be compiled in this
+// repository's image (no Go toolchain), so it is kept deliberately thin: all
+// logic lives behind the C ABI, where the C++/ctypes drivers exercise it.
+//
+// Build:  CGO_CFLAGS="-I$REPO/include" CGO_LDFLAGS="-L$REPO/syzgydb_amd -lsyzgy_scan" \
+//         go build -tags syzgy_gpu ./...
+package syzgydb
+
+/*
+#cgo LDFLAGS: -lsyzgy_scan
+#include <stdlib.h>
+#include "syzgy_scan.h"
+*/
+import "C"
+
+import (
+	"fmt"
+	"sort"
+	"strconv"
+	"unsafe"
+)
+
+// gpuMirror is the HBM mirror of one Collection's packed vectors plus the
+// row -> document id table (rows are in IterateSortedRecords order, i.e. the
+// reference's deterministic visit order, spanfile.go:540-560).
+type gpuMirror struct {
+	h     *C.szg_index
+	ids   []uint64          // row -> document id
+	rowOf map[uint64]uint64 // document id -> row
+	dirty bool              // set by mutators that could not be applied incrementally
+}
+
+// newGPUMirror pages every record's stream 1 (the packed vector, exactly the
+// bytes encodeDocument wrote, collection.go:713-743) into HBM.  Called from
+// NewCollection where the LSH tree is rebuilt (collection.go:297-311).
+func newGPUMirror(c *Collection, devices []int) (*gpuMirror, error) {
+	m := &gpuMirror{rowOf: map[uint64]uint64{}}
+	var devp *C.int
+	cdev := make([]C.int, len(devices))
+	for i, d := range devices {
+		cdev[i] = C.int(d)
+	}
+	if len(cdev) > 0 {
+		devp = &cdev[0]
+	}
+	rc := C.szg_index_create(&m.h, C.int(c.DimensionCount), C.int(c.Quantization),
+		C.int(c.DistanceMethod), devp, C.int(len(cdev)))
+	if rc != C.SZG_OK {
+		return nil, fmt.Errorf("szg_index_create: %s (%s)", C.GoString(C.szg_strerror(rc)),
+			C.GoString(C.szg_last_error()))
+	}
+	if err := m.reload(c); err != nil {
+		m.close()
+		return nil, err
+	}
+	return m, nil
+}
+
+// reload copies all vectors into one contiguous host buffer and loads it.
+func (m *gpuMirror) reload(c *Collection) error {
+	rowBytes := getVectorSize(c.Quantization, c.DimensionCount)
+	var recordIDs []string
+	for id := range c.spanfile.index {
+		if id != "" {
+			recordIDs = append(recordIDs, id)
+		}
+	}
+	sort.Strings(recordIDs) // IterateSortedRecords order
+	buf := make([]byte, 0, len(recordIDs)*rowBytes)
+	m.ids = m.ids[:0]
+	m.rowOf = map[uint64]uint64{}
+	for _, rid := range recordIDs {
+		id, err := strconv.ParseUint(rid, 10, 64)
+		if err != nil {
+			continue // collection.go:676-678 skips non-numeric record ids
+		}
+		span, err := c.spanfile.ReadRecord(rid)
+		if err != nil {
+			return err
+		}
+		m.rowOf[id] = uint64(len(m.ids))
+		m.ids = append(m.ids, id)
+		buf = append(buf, span.DataStreams[1].Data...)
+	}
+	var p *C.uint8_t
+	if len(buf) > 0 {
+		p = (*C.uint8_t)(unsafe.Pointer(&buf[0]))
+	}
+	if rc := C.szg_index_load(m.h, p, C.uint64_t(len(m.ids))); rc != C.SZG_OK {
+		return fmt.Errorf("szg_index_load: %s", C.GoString(C.szg_last_error()))
+	}
+	m.dirty = false
+	return nil
+}
+
+// add mirrors AddDocument (collection.go:427-457); called under c.mutex.Lock.
+func (m *gpuMirror) add(id uint64, encoded []byte) {
+	p := (*C.uint8_t)(unsafe.Pointer(&encoded[0]))
+	if row, ok := m.rowOf[id]; ok {
+		if C.szg_index_overwrite(m.h, C.uint64_t(row), p) != C.SZG_OK {
+			m.dirty = true
+		}
+		return
+	}
+	if C.szg_index_append(m.h, p, 1) != C.SZG_OK {
+		m.dirty = true
+		return
+	}
+	m.rowOf[id] = uint64(len(m.ids))
+	m.ids = append(m.ids, id)
+}
+
+// remove mirrors removeDocument (collection.go:511-521); called under c.mutex.Lock.
+func (m *gpuMirror) remove(id uint64) {
+	if row, ok := m.rowOf[id]; ok {
+		if C.szg_index_tombstone(m.h, C.uint64_t(row)) != C.SZG_OK {
+			m.dirty = true
+		}
+		delete(m.rowOf, id)
+	}
+}
+
+func (m *gpuMirror) close() {
+	if m.h != nil {
+		C.szg_index_destroy(m.h)
+		m.h = nil
+	}
+}
+
+// allowBits evaluates args.Filter over every live row (collection.go:592-594);
+// a Go closure cannot run on the GPU, its verdicts travel as one bit per row.
+func (m *gpuMirror) allowBits(c *Collection, filter FilterFn) []C.uint64_t {
+	words := (len(m.ids) + 63) / 64
+	bits := make([]C.uint64_t, words)
+	for id, row := range m.rowOf {
+		span, err := c.spanfile.ReadRecord(fmt.Sprintf("%d", id))
+		if err != nil {
+			continue
+		}
+		if filter(id, span.DataStreams[0].Data) {
+			bits[row/64] |= 1 << (row % 64)
+		}
+	}
+	return bits
+}
+
+// searchExact replaces the hot loop of Collection.Search (collection.go:672-684
+// plus the pop loop :694-697).  ok == false tells the caller to run the
+// reference's own CPU loop (keeps Search's no-error signature).
+func (m *gpuMirror) searchExact(c *Collection, args SearchArgs) (results []SearchResult, ok bool) {
+	if m.dirty {
+		if err := m.reload(c); err != nil {
+			return nil, false
+		}
+	}
+	if len(args.Vector) != c.DimensionCount || len(m.ids) == 0 {
+		return nil, len(m.ids) == 0 // empty collection: no results (collection_test.go:294-309)
+	}
+	var allow *C.uint64_t
+	var keep []C.uint64_t
+	if args.Filter != nil {
+		keep = m.allowBits(c, args.Filter)
+		allow = &keep[0]
+	}
+	q := (*C.double)(unsafe.Pointer(&args.Vector[0]))
+	var rows []C.uint64_t
+	var dist []C.double
+	n := 0
+	if args.Radius > 0 { // K is ignored (collection.go:598-605)
+		capacity := 1024
+		for {
+			rows = make([]C.uint64_t, capacity)
+			dist = make([]C.double, capacity)
+			var total C.uint64_t
+			rc := C.szg_search_radius(m.h, q, C.double(args.Radius), allow, &rows[0], &dist[0],
+				C.uint64_t(capacity), &total)
+			if rc == C.SZG_E_TRUNCATED {
+				capacity = int(total)
+				continue
+			}
+			if rc != C.SZG_OK {
+				return nil, false
+			}
+			n = int(total)
+			break
+		}
+	} else {
+		rows = make([]C.uint64_t, args.K)
+		dist = make([]C.double, args.K)
+		var count C.int32_t
+		rc := C.szg_search_topk(m.h, q, 1, C.int(args.K), allow, &rows[0], &dist[0], &count)
+		if rc != C.SZG_OK {
+			return nil, false
+		}
+		n = int(count)
+	}
+	results = make([]SearchResult, n)
+	for i := 0; i < n; i++ {
+		id := m.ids[rows[i]]
+		span, err := c.spanfile.ReadRecord(fmt.Sprintf("%d", id))
+		if err != nil {
+			return nil, false
+		}
+		// Metadata is the live mmap slice, as in getDocument (collection.go:476); the
+		// caller still holds c.mutex.RLock.
+		results[i] = SearchResult{ID: id, Metadata: span.DataStreams[0].Data, Distance: float64(dist[i])}
+	}
+	_ = keep
+	return results, true
+}
