@@ -1,0 +1,11 @@
+"""Run one scan config for a few queries (profiling target)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from syzgydb_amd import ScanIndex
+from syzgydb_amd.synth import synth_vectors
+n, dim, bits, metric, k, nq = [int(x) for x in sys.argv[1:7]]
+with ScanIndex(dim, bits, metric, devices=[0]) as ix:
+    ix.synth(n, 1234)
+    q = synth_vectors(99, 0, nq, dim)
+    r, d, c = ix.search_topk(q, k)
+    print("done", r[0][:3])

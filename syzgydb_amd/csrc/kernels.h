@@ -36,6 +36,7 @@ struct RowMap {
     int L;    // lanes per row
     int P;    // pieces per lane per row (L*P >= r16)
     int gpw;  // rows (lane groups) per wave iteration
+    int pow2; // L is a power of two (groups are aligned: DPP reductions apply)
 };
 
 struct ScanArgs {

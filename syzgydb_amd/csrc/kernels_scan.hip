@@ -52,6 +52,23 @@ __device__ __forceinline__ u32x4 load_piece(const uint8_t *p)
 #endif
 }
 
+// value of the lane a DPP control pairs this lane with (quad_perm xor 1 / xor 2,
+// row_half_mirror, row_mirror: after the four steps every lane of an aligned
+// 2/4/8/16-lane group holds the group's sum)
+template <int CTRL>
+__device__ __forceinline__ float dpp_xchg(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_xchg(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src)
 {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
@@ -307,26 +324,43 @@ __global__ __launch_bounds__(512) void scan_kernel(const ScanArgs a)
 
     // One row is done: reduce the group's L lanes, form the key, select.
     auto finish_row = [&](uint64_t row0, bool valid, acc_t a0, acc_t a1, uint32_t nz) {
-        for (int w = L; w > 1;) {
-            const int half = (w + 1) >> 1;
-            const acc_t o0 = __shfl_down(a0, half);
-            const acc_t o1 = __shfl_down(a1, half);
-            const uint32_t oz = __shfl_down(nz, half);
-            if (lig + half < w) {
-                a0 += o0;
-                a1 += o1;
-                nz |= oz;
+        if (a.map.pow2) {
+            // aligned power-of-two groups: DPP inside the 16-lane row, permutes across rows
+            if (L >= 2) { a0 += dpp_xchg<0xB1>(a0); if (METRIC == kCosine) a1 += dpp_xchg<0xB1>(a1); }
+            if (L >= 4) { a0 += dpp_xchg<0x4E>(a0); if (METRIC == kCosine) a1 += dpp_xchg<0x4E>(a1); }
+            if (L >= 8) { a0 += dpp_xchg<0x141>(a0); if (METRIC == kCosine) a1 += dpp_xchg<0x141>(a1); }
+            if (L >= 16) { a0 += dpp_xchg<0x140>(a0); if (METRIC == kCosine) a1 += dpp_xchg<0x140>(a1); }
+            if (L >= 32) { a0 += __shfl_xor(a0, 16); if (METRIC == kCosine) a1 += __shfl_xor(a1, 16); }
+            if (L >= 64) { a0 += __shfl_xor(a0, 32); if (METRIC == kCosine) a1 += __shfl_xor(a1, 32); }
+        } else {
+            for (int w = L; w > 1;) {
+                const int half = (w + 1) >> 1;
+                const acc_t o0 = __shfl_down(a0, half);
+                const acc_t o1 = __shfl_down(a1, half);
+                if (lig + half < w) {
+                    a0 += o0;
+                    a1 += o1;
+                }
+                w = half;
             }
-            w = half;
         }
         float key;
         if (METRIC == kCosine) {
-            // query is pre-normalised, so key = -cos; a zero row is distance 1.0
+            // query is pre-normalised, so key = -cos.  A zero row is distance 1.0
             // (collection.go:828-830) == cos -1; an underflowed norm is forced in.
-            if (a1 == (acc_t)0) {
-                key = nz ? -2.0f : 1.0f;
-            } else {
+            const bool zero = a1 == (acc_t)0;
+            if (sizeof(acc_t) == 4)
+                key = -(float)a0 * __frsqrt_rn((float)a1);
+            else
                 key = (float)(-a0 / sqrt(a1));
+            if (__ballot(zero && valid && lig == 0)) {  // rare: tell true zeros from underflow
+                for (int w = L; w > 1;) {
+                    const int half = (w + 1) >> 1;
+                    const uint32_t oz = __shfl_down(nz, half);
+                    if (lig + half < w) nz |= oz;
+                    w = half;
+                }
+                if (zero) key = nz ? -2.0f : 1.0f;
             }
         } else {
             key = (float)a0;

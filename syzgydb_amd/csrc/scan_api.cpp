@@ -211,7 +211,7 @@ namespace {
 
 szg::RowMap choose_map(int r16)
 {   // groups of L lanes per row, P pieces per lane: maximise lane utilisation
-    szg::RowMap best{r16, 64, (r16 + 63) / 64, 1};
+    szg::RowMap best{r16, 64, (r16 + 63) / 64, 1, 1};
     double best_util = -1;
     const int pmax = std::max(1, (r16 + 63) / 64 + 8);
     for (int P = 1; P <= pmax; P++) {
@@ -221,7 +221,7 @@ szg::RowMap choose_map(int r16)
         const double util = (double)gpw * r16 / (64.0 * P);
         if (util > best_util + 1e-9) {
             best_util = util;
-            best = szg::RowMap{r16, L, P, gpw};
+            best = szg::RowMap{r16, L, P, gpw, (L & (L - 1)) == 0 ? 1 : 0};
         }
     }
     return best;
