@@ -39,6 +39,20 @@ struct RowMap {
     int pow2; // L is a power of two (groups are aligned: DPP reductions apply)
 };
 
+// Bytes of one prepared query as the scan stages it in LDS: float32 (float64 for
+// 64-bit rows) per element, or integer digit planes of 16 bytes per piece for the
+// exact-integer paths (3 int8 planes for 8-bit rows, 5 int4 planes for 4-bit rows).
+__host__ __device__ inline size_t query_lds_bytes(int qbits, int r16)
+{
+    switch (qbits) {
+    case 4: return (size_t)r16 * 16 * 5;
+    case 8: return (size_t)r16 * 16 * 3;
+    case 16: return (size_t)r16 * 8 * 4;
+    case 32: return (size_t)r16 * 4 * 4;
+    default: return (size_t)r16 * 2 * 8;
+    }
+}
+
 struct ScanArgs {
     const uint8_t *rows;        // resident mirror: n_rows x pitch bytes, little-endian elements
     uint32_t n_rows;
@@ -51,6 +65,9 @@ struct ScanArgs {
     int n_queries;              // queries walked back to back by one launch
     uint32_t query_stride;      // bytes between consecutive swizzled queries
     uint32_t allow_stride;      // words between consecutive queries' allow masks
+    // integer paths (4/8-bit rows): query ~ qscale * Q, qconst = sum Q, norm_bias turns
+    // the row's integer sums into sum n^2 without the padding; qnorm2 = sum g^2 (euclid)
+    double qscale, qconst, qnorm2, norm_bias;
     int kp;                     // candidates kept per list (top-k mode)
     uint64_t *block_lists;      // [n_queries][grid][kp] sorted ascending (top-k mode)
     // collect mode (radius search / escalation): every row with key <= thr is appended

@@ -61,6 +61,11 @@ __device__ __forceinline__ float dpp_xchg(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 template <int CTRL>
+__device__ __forceinline__ int dpp_xchg(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
 __device__ __forceinline__ double dpp_xchg(double v)
 {
     const long long b = __double_as_longlong(v);
@@ -77,151 +82,228 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src)
     return ((uint64_t)hi << 32) | lo;
 }
 
-// ---- per-piece accumulation -------------------------------------------------
-// a0: dot (cosine) or sum of squared differences (euclid); a1: sum of squares of
-// the row (cosine only); nz: OR of the row's magnitude bits (cosine, float rows).
+// ---- row accumulators ---------------------------------------------------------
+// RowAcc<QBITS, METRIC> holds one lane's partial sums for the row its group is
+// walking: reset(), piece() for each 16-byte piece, finish() reduces over the
+// group's L lanes and returns the ranking key (valid in the group's first lane).
 
-template <int METRIC>
-__device__ __forceinline__ void acc4(const float4 q, float x0, float x1, float x2, float x3,
-                                     float &a0, float &a1)
+struct Grp {
+    int L, lig;
+    bool pow2;
+};
+
+// sum over the L lanes of a row group; every lane of an aligned power-of-two
+// group gets the total, otherwise the group's first lane does
+template <typename T>
+__device__ __forceinline__ T grp_sum(T v, const Grp &g)
 {
-    if (METRIC == kCosine) {
-        a0 = fmaf(q.x, x0, a0);
-        a0 = fmaf(q.y, x1, a0);
-        a0 = fmaf(q.z, x2, a0);
-        a0 = fmaf(q.w, x3, a0);
-        a1 = fmaf(x0, x0, a1);
-        a1 = fmaf(x1, x1, a1);
-        a1 = fmaf(x2, x2, a1);
-        a1 = fmaf(x3, x3, a1);
+    if (g.pow2) {
+        if (g.L >= 2) v += dpp_xchg<0xB1>(v);
+        if (g.L >= 4) v += dpp_xchg<0x4E>(v);
+        if (g.L >= 8) v += dpp_xchg<0x141>(v);
+        if (g.L >= 16) v += dpp_xchg<0x140>(v);
+        if (g.L >= 32) v += __shfl_xor(v, 16);
+        if (g.L >= 64) v += __shfl_xor(v, 32);
     } else {
-        float d0 = q.x - x0, d1 = q.y - x1, d2 = q.z - x2, d3 = q.w - x3;
-        a0 = fmaf(d0, d0, a0);
-        a0 = fmaf(d1, d1, a0);
-        a0 = fmaf(d2, d2, a0);
-        a0 = fmaf(d3, d3, a0);
+        for (int w = g.L; w > 1;) {
+            const int half = (w + 1) >> 1;
+            const T o = __shfl_down(v, half);
+            if (g.lig + half < w) v += o;
+            w = half;
+        }
     }
+    return v;
 }
 
+__device__ __forceinline__ uint32_t grp_or(uint32_t v, const Grp &g)
+{
+    for (int w = g.L; w > 1;) {
+        const int half = (w + 1) >> 1;
+        const uint32_t o = __shfl_down(v, half);
+        if (g.lig + half < w) v |= o;
+        w = half;
+    }
+    return v;
+}
+
+// Float rows (16/32-bit, float32 sums) and 64-bit rows (float64 sums).
+// a0: dot (cosine) or sum of squared differences (euclid); a1: sum of squares of
+// the row; nz: OR of the row's magnitude bits (tells a true zero row from an
+// underflowed norm).  The query is pre-normalised (cosine: key = -cos) or, for
+// 16-bit rows under euclid, pre-scaled by maxInt.
 template <int QBITS, int METRIC>
-struct Piece;
-
-// 32-bit: resident elements are little-endian IEEE floats.
-template <int METRIC>
-struct Piece<32, METRIC> {
-    __device__ static __forceinline__ void run(const uint4 raw, const uint8_t *q, int j, int r16,
-                                               int dim, float &a0, float &a1, uint32_t &nz)
+struct RowAcc {
+    using acc_t = typename Traits<QBITS>::acc_t;
+    acc_t a0, a1;
+    uint32_t nz;
+    __device__ __forceinline__ void reset()
     {
-        const float4 qv = reinterpret_cast<const float4 *>(q)[j];
-        acc4<METRIC>(qv, __uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z),
-                     __uint_as_float(raw.w), a0, a1);
-        if (METRIC == kCosine) nz |= (raw.x | raw.y | raw.z | raw.w) & 0x7FFFFFFFu;
+        a0 = 0;
+        a1 = 0;
+        nz = 0;
     }
-};
-
-// 64-bit: native float64 arithmetic (FP64 VALU is ample at HBM rate).
-template <int METRIC>
-struct Piece<64, METRIC> {
-    __device__ static __forceinline__ void run(const uint4 raw, const uint8_t *q, int j, int r16,
-                                               int dim, double &a0, double &a1, uint32_t &nz)
+    __device__ __forceinline__ void add4(const float4 q, float x0, float x1, float x2, float x3)
     {
-        const double2 qv = reinterpret_cast<const double2 *>(q)[j];
-        const double x0 = __longlong_as_double(((long long)raw.y << 32) | (long long)raw.x);
-        const double x1 = __longlong_as_double(((long long)raw.w << 32) | (long long)raw.z);
         if (METRIC == kCosine) {
-            a0 = fma(qv.x, x0, a0);
-            a0 = fma(qv.y, x1, a0);
-            a1 = fma(x0, x0, a1);
-            a1 = fma(x1, x1, a1);
-            nz |= (raw.x | raw.z) | ((raw.y | raw.w) & 0x7FFFFFFFu);
+            a0 = fmaf(q.x, x0, a0);
+            a0 = fmaf(q.y, x1, a0);
+            a0 = fmaf(q.z, x2, a0);
+            a0 = fmaf(q.w, x3, a0);
+            a1 = fmaf(x0, x0, a1);
+            a1 = fmaf(x1, x1, a1);
+            a1 = fmaf(x2, x2, a1);
+            a1 = fmaf(x3, x3, a1);
         } else {
-            const double d0 = qv.x - x0, d1 = qv.y - x1;
-            a0 = fma(d0, d0, a0);
-            a0 = fma(d1, d1, a0);
+            const float d0 = q.x - x0, d1 = q.y - x1, d2 = q.z - x2, d3 = q.w - x3;
+            a0 = fmaf(d0, d0, a0);
+            a0 = fmaf(d1, d1, a0);
+            a0 = fmaf(d2, d2, a0);
+            a0 = fmaf(d3, d3, a0);
         }
     }
-};
-
-// Quantized kinds decode to the odd integer n = 2v - maxInt (exact in float);
-// dequantize(v) = n / maxInt (quantization.go:34-35 up to rounding), and the
-// common 1/maxInt cancels in -cos and is folded into the query for euclid.
-template <int QBITS>
-__device__ __forceinline__ float qn(uint32_t v)
-{
-    constexpr float M = (float)((1u << QBITS) - 1u);
-    return fmaf((float)v, 2.0f, -M);
-}
-
-template <int QBITS, int METRIC, int E>
-__device__ __forceinline__ void acc_quant(float (&n)[E], const uint8_t *q, int j, int r16, int dim,
-                                          float &a0, float &a1)
-{
-    const int e0 = j * E;
-    if (e0 + E > dim) {  // tail piece of the row: padding decodes to -maxInt, mask it
-#pragma unroll
-        for (int i = 0; i < E; i++)
-            if (e0 + i >= dim) n[i] = 0.0f;
-    }
-    const float4 *q4 = reinterpret_cast<const float4 *>(q);
-#pragma unroll
-    for (int c = 0; c < E / 4; c++) {
-        const float4 qv = q4[c * r16 + j];
-        acc4<METRIC>(qv, n[4 * c], n[4 * c + 1], n[4 * c + 2], n[4 * c + 3], a0, a1);
-    }
-}
-
-template <int METRIC>
-struct Piece<16, METRIC> {
-    __device__ static __forceinline__ void run(const uint4 raw, const uint8_t *q, int j, int r16,
-                                               int dim, float &a0, float &a1, uint32_t &nz)
+    __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const ScanArgs &a)
     {
-        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-        float n[8];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            n[2 * d] = qn<16>(w[d] & 0xFFFFu);
-            n[2 * d + 1] = qn<16>(w[d] >> 16);
-        }
-        acc_quant<16, METRIC, 8>(n, q, j, r16, dim, a0, a1);
-    }
-};
-
-template <int METRIC>
-struct Piece<8, METRIC> {
-    __device__ static __forceinline__ void run(const uint4 raw, const uint8_t *q, int j, int r16,
-                                               int dim, float &a0, float &a1, uint32_t &nz)
-    {
-        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-        float n[16];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) n[4 * d + k] = qn<8>((w[d] >> (8 * k)) & 0xFFu);
-        }
-        acc_quant<8, METRIC, 16>(n, q, j, r16, dim, a0, a1);
-    }
-};
-
-// 4-bit: byte b holds element 2b in its high nibble, 2b+1 in its low nibble
-// (collection.go:774-779).
-template <int METRIC>
-struct Piece<4, METRIC> {
-    __device__ static __forceinline__ void run(const uint4 raw, const uint8_t *q, int j, int r16,
-                                               int dim, float &a0, float &a1, uint32_t &nz)
-    {
-        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-        float n[32];
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            const uint32_t hi = (w[d] >> 4) & 0x0F0F0F0Fu;
-            const uint32_t lo = w[d] & 0x0F0F0F0Fu;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                n[8 * d + 2 * k] = qn<4>((hi >> (8 * k)) & 0xFFu);
-                n[8 * d + 2 * k + 1] = qn<4>((lo >> (8 * k)) & 0xFFu);
+        if (QBITS == 32) {  // resident elements are little-endian IEEE floats
+            const float4 qv = reinterpret_cast<const float4 *>(q)[j];
+            add4(qv, __uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z),
+                 __uint_as_float(raw.w));
+            if (METRIC == kCosine) nz |= (raw.x | raw.y | raw.z | raw.w) & 0x7FFFFFFFu;
+        } else if (QBITS == 64) {  // native float64 arithmetic (FP64 VALU is ample at HBM rate)
+            const double2 qv = reinterpret_cast<const double2 *>(q)[j];
+            const double x0 = __longlong_as_double(((long long)raw.y << 32) | (long long)raw.x);
+            const double x1 = __longlong_as_double(((long long)raw.w << 32) | (long long)raw.z);
+            if (METRIC == kCosine) {
+                a0 = fma(qv.x, x0, a0);
+                a0 = fma(qv.y, x1, a0);
+                a1 = fma(x0, x0, a1);
+                a1 = fma(x1, x1, a1);
+                nz |= (raw.x | raw.z) | ((raw.y | raw.w) & 0x7FFFFFFFu);
+            } else {
+                const double d0 = qv.x - x0, d1 = qv.y - x1;
+                a0 = fma(d0, d0, a0);
+                a0 = fma(d1, d1, a0);
             }
+        } else {  // 16-bit: n = 2v - 65535 (odd, exact in float); dequantize(v) = n / 65535
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+            float n[8];
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                n[2 * d] = fmaf((float)(w[d] & 0xFFFFu), 2.0f, -65535.0f);
+                n[2 * d + 1] = fmaf((float)(w[d] >> 16), 2.0f, -65535.0f);
+            }
+            const int e0 = j * 8;
+            if (e0 + 8 > a.dim) {  // tail piece: padding decodes to -maxInt, mask it
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (e0 + i >= a.dim) n[i] = 0.0f;
+            }
+            const float4 *q4 = reinterpret_cast<const float4 *>(q);
+            add4(q4[j], n[0], n[1], n[2], n[3]);
+            add4(q4[a.map.r16 + j], n[4], n[5], n[6], n[7]);
         }
-        acc_quant<4, METRIC, 32>(n, q, j, r16, dim, a0, a1);
+    }
+    __device__ __forceinline__ float finish(const ScanArgs &a, const Grp &g, bool lead)
+    {
+        a0 = grp_sum(a0, g);
+        if (METRIC != kCosine) return (float)a0;
+        a1 = grp_sum(a1, g);
+        // a zero row is distance 1.0 (collection.go:828-830) == cos -1; an underflowed
+        // norm is forced in (key -2) and settled by the float64 rerank
+        const bool zero = a1 == (acc_t)0;
+        float key;
+        if (sizeof(acc_t) == 4)
+            key = -(float)a0 * __frsqrt_rn((float)a1);
+        else
+            key = (float)(-a0 / sqrt(a1));
+        if (__ballot(zero && lead)) {  // rare
+            nz = grp_or(nz, g);
+            if (zero) key = nz ? -2.0f : 1.0f;
+        }
+        return key;
+    }
+};
+
+// 8-bit rows, exact integer arithmetic.  With v' = v - 128 (one xor per dword)
+// the decoded element is n = 2v - 255 = 2v' + 1.  The query is quantized on the
+// host to Q_i = h*16384 + m*128 + l (balanced int8 digits, |Q| < 2^20), so
+//     sum Q_i n_i = 2*(16384*H + 128*M + L) + sum Q_i,   H = sum h_i v'_i ...
+// and sum n_i^2 = 4*sum v'^2 + 4*sum v' + count, all via v_dot4_i32_i8: five VALU
+// ops per four elements, no conversions, and the only error left in the key is
+// the query's quantization (bounded on the host, key_eps).
+template <int METRIC>
+struct RowAcc<8, METRIC> {
+    int H, M, L, SQ, SV;
+    __device__ __forceinline__ void reset() { H = M = L = SQ = SV = 0; }
+    __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const ScanArgs &a)
+    {
+        const uint4 *q4 = reinterpret_cast<const uint4 *>(q);
+        const int r16 = a.map.r16;
+        const uint4 qh = q4[j], qm = q4[r16 + j], ql = q4[2 * r16 + j];
+        const uint32_t w[4] = {raw.x ^ 0x80808080u, raw.y ^ 0x80808080u, raw.z ^ 0x80808080u,
+                               raw.w ^ 0x80808080u};
+        const uint32_t h[4] = {qh.x, qh.y, qh.z, qh.w};
+        const uint32_t m[4] = {qm.x, qm.y, qm.z, qm.w};
+        const uint32_t l[4] = {ql.x, ql.y, ql.z, ql.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            H = __builtin_amdgcn_sdot4((int)h[d], (int)w[d], H, false);
+            M = __builtin_amdgcn_sdot4((int)m[d], (int)w[d], M, false);
+            L = __builtin_amdgcn_sdot4((int)l[d], (int)w[d], L, false);
+            SQ = __builtin_amdgcn_sdot4((int)w[d], (int)w[d], SQ, false);
+            SV = __builtin_amdgcn_sdot4((int)w[d], 0x01010101, SV, false);
+        }
+    }
+    __device__ __forceinline__ float finish(const ScanArgs &a, const Grp &g, bool lead)
+    {
+        double dot = 2.0 * (16384.0 * (double)H + 128.0 * (double)M + (double)L);
+        int nrm = 4 * (SQ + SV);
+        dot = grp_sum(dot, g) + a.qconst;
+        nrm = grp_sum(nrm, g);
+        const double norm = (double)nrm + a.norm_bias;  // padding removed, exact
+        if (METRIC == kCosine) return -(float)(dot * a.qscale) * __frsqrt_rn((float)norm);
+        return (float)(a.qnorm2 - 2.0 * a.qscale * dot + norm);
+    }
+};
+
+// 4-bit rows: the same with v'' = v - 8 (xor 0x88888888), n = 2v - 15 = 2v'' + 1,
+// the query in five balanced int4 digit planes (|Q| < 2^19) and v_dot8_i32_i4:
+// seven VALU ops per eight elements, no nibble unpacking.
+template <int METRIC>
+struct RowAcc<4, METRIC> {
+    int D0, D1, D2, D3, D4, SQ, SV;
+    __device__ __forceinline__ void reset() { D0 = D1 = D2 = D3 = D4 = SQ = SV = 0; }
+    __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const ScanArgs &a)
+    {
+        const uint4 *q4 = reinterpret_cast<const uint4 *>(q);
+        const int r16 = a.map.r16;
+        const uint4 p0 = q4[j], p1 = q4[r16 + j], p2 = q4[2 * r16 + j], p3 = q4[3 * r16 + j],
+                    p4 = q4[4 * r16 + j];
+        const uint32_t w[4] = {raw.x ^ 0x88888888u, raw.y ^ 0x88888888u, raw.z ^ 0x88888888u,
+                               raw.w ^ 0x88888888u};
+        const uint32_t q0[4] = {p0.x, p0.y, p0.z, p0.w}, q1[4] = {p1.x, p1.y, p1.z, p1.w},
+                       q2[4] = {p2.x, p2.y, p2.z, p2.w}, q3[4] = {p3.x, p3.y, p3.z, p3.w},
+                       q4w[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            D0 = __builtin_amdgcn_sdot8((int)q0[d], (int)w[d], D0, false);
+            D1 = __builtin_amdgcn_sdot8((int)q1[d], (int)w[d], D1, false);
+            D2 = __builtin_amdgcn_sdot8((int)q2[d], (int)w[d], D2, false);
+            D3 = __builtin_amdgcn_sdot8((int)q3[d], (int)w[d], D3, false);
+            D4 = __builtin_amdgcn_sdot8((int)q4w[d], (int)w[d], D4, false);
+            SQ = __builtin_amdgcn_sdot8((int)w[d], (int)w[d], SQ, false);
+            SV = __builtin_amdgcn_sdot8((int)w[d], 0x11111111, SV, false);
+        }
+    }
+    __device__ __forceinline__ float finish(const ScanArgs &a, const Grp &g, bool lead)
+    {
+        double dot = 2.0 * ((double)D0 + 16.0 * (double)D1 + 256.0 * (double)D2 + 4096.0 * (double)D3 +
+                            65536.0 * (double)D4);
+        int nrm = 4 * (SQ + SV);
+        dot = grp_sum(dot, g) + a.qconst;
+        nrm = grp_sum(nrm, g);
+        const double norm = (double)nrm + a.norm_bias;
+        if (METRIC == kCosine) return -(float)(dot * a.qscale) * __frsqrt_rn((float)norm);
+        return (float)(a.qnorm2 - 2.0 * a.qscale * dot + norm);
     }
 };
 
@@ -273,8 +355,6 @@ __device__ __forceinline__ int lower_count(const uint64_t *list, int n, uint64_t
 template <int QBITS, int METRIC, int D, bool COLLECT, bool MASKED>
 __global__ __launch_bounds__(512) void scan_kernel(const ScanArgs a)
 {
-    using T = Traits<QBITS>;
-    using acc_t = typename T::acc_t;
     extern __shared__ __align__(16) uint8_t smem[];
 
     const int tid = threadIdx.x;
@@ -282,7 +362,7 @@ __global__ __launch_bounds__(512) void scan_kernel(const ScanArgs a)
     const int wave = tid >> 6;
     const int nwaves = blockDim.x >> 6;
     const int r16 = a.map.r16;
-    const int qbytes = r16 * T::E * T::QB;  // multiple of 16
+    const int qbytes = (int)query_lds_bytes(QBITS, r16);  // multiple of 16
 
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem + qbytes);
     uint64_t *mylist = lists + (size_t)wave * a.kp;
@@ -323,48 +403,9 @@ __global__ __launch_bounds__(512) void scan_kernel(const ScanArgs a)
     };
 
     // One row is done: reduce the group's L lanes, form the key, select.
-    auto finish_row = [&](uint64_t row0, bool valid, acc_t a0, acc_t a1, uint32_t nz) {
-        if (a.map.pow2) {
-            // aligned power-of-two groups: DPP inside the 16-lane row, permutes across rows
-            if (L >= 2) { a0 += dpp_xchg<0xB1>(a0); if (METRIC == kCosine) a1 += dpp_xchg<0xB1>(a1); }
-            if (L >= 4) { a0 += dpp_xchg<0x4E>(a0); if (METRIC == kCosine) a1 += dpp_xchg<0x4E>(a1); }
-            if (L >= 8) { a0 += dpp_xchg<0x141>(a0); if (METRIC == kCosine) a1 += dpp_xchg<0x141>(a1); }
-            if (L >= 16) { a0 += dpp_xchg<0x140>(a0); if (METRIC == kCosine) a1 += dpp_xchg<0x140>(a1); }
-            if (L >= 32) { a0 += __shfl_xor(a0, 16); if (METRIC == kCosine) a1 += __shfl_xor(a1, 16); }
-            if (L >= 64) { a0 += __shfl_xor(a0, 32); if (METRIC == kCosine) a1 += __shfl_xor(a1, 32); }
-        } else {
-            for (int w = L; w > 1;) {
-                const int half = (w + 1) >> 1;
-                const acc_t o0 = __shfl_down(a0, half);
-                const acc_t o1 = __shfl_down(a1, half);
-                if (lig + half < w) {
-                    a0 += o0;
-                    a1 += o1;
-                }
-                w = half;
-            }
-        }
-        float key;
-        if (METRIC == kCosine) {
-            // query is pre-normalised, so key = -cos.  A zero row is distance 1.0
-            // (collection.go:828-830) == cos -1; an underflowed norm is forced in.
-            const bool zero = a1 == (acc_t)0;
-            if (sizeof(acc_t) == 4)
-                key = -(float)a0 * __frsqrt_rn((float)a1);
-            else
-                key = (float)(-a0 / sqrt(a1));
-            if (__ballot(zero && valid && lig == 0)) {  // rare: tell true zeros from underflow
-                for (int w = L; w > 1;) {
-                    const int half = (w + 1) >> 1;
-                    const uint32_t oz = __shfl_down(nz, half);
-                    if (lig + half < w) nz |= oz;
-                    w = half;
-                }
-                if (zero) key = nz ? -2.0f : 1.0f;
-            }
-        } else {
-            key = (float)a0;
-        }
+    const Grp grp_info{L, lig, a.map.pow2 != 0};
+    auto finish_row = [&](uint64_t row0, bool valid, RowAcc<QBITS, METRIC> &acc) {
+        float key = acc.finish(a, grp_info, valid && lig == 0);
         if (!(key == key)) key = 3.0e38f;       // NaN: worst finite
         if (key > 3.0e38f) key = 3.0e38f;       // +inf (overflow): worst finite
         const uint32_t row = (uint32_t)(row0 + grp);
@@ -416,8 +457,8 @@ __global__ __launch_bounds__(512) void scan_kernel(const ScanArgs a)
     uint64_t crow0 = row_first;
     int cp = 0;
     bool cvalid = false;
-    acc_t a0 = 0, a1 = 0;
-    uint32_t nz = 0;
+    RowAcc<QBITS, METRIC> acc;
+    acc.reset();
 
 #define SZG_ISSUE(u)                                                                    \
     {                                                                                   \
@@ -445,14 +486,11 @@ __global__ __launch_bounds__(512) void scan_kernel(const ScanArgs a)
         if (cp == 0) cvalid = ok_; /* piece 0 of the group's first lane is in range */  \
         if (ok_) {                                                                      \
             const u32x4 v_ = ring[u];                                                   \
-            Piece<QBITS, METRIC>::run(make_uint4(v_.x, v_.y, v_.z, v_.w), smem, j_, r16, \
-                                      a.dim, a0, a1, nz);                               \
+            acc.piece(make_uint4(v_.x, v_.y, v_.z, v_.w), smem, j_, a);                 \
         }                                                                               \
         if (++cp == P) {                                                                \
-            finish_row(crow0, cvalid, a0, a1, nz);                                      \
-            a0 = 0;                                                                     \
-            a1 = 0;                                                                     \
-            nz = 0;                                                                     \
+            finish_row(crow0, cvalid, acc);                                             \
+            acc.reset();                                                                \
             cp = 0;                                                                     \
             crow0 += stride;                                                            \
         }                                                                               \
@@ -646,9 +684,7 @@ hipError_t launch_scan_q(int metric, const ScanArgs &a, int grid, int block, siz
 
 size_t scan_lds_bytes(int qbits, const RowMap &m, int kp, int block)
 {
-    const size_t e = 128 / qbits;
-    const size_t qb = qbits == 64 ? 8 : 4;
-    return (size_t)m.r16 * e * qb + (size_t)(block / kWave) * kp * sizeof(uint64_t);
+    return query_lds_bytes(qbits, m.r16) + (size_t)(block / kWave) * kp * sizeof(uint64_t);
 }
 
 hipError_t launch_scan(int qbits, int metric, const ScanArgs &a, int grid, int block,

@@ -124,6 +124,15 @@ struct GoHeap {
     }
 };
 
+// per-query constants of the prepared query
+struct QMeta {
+    double qnorm = 0;   // norm of the prepared (normalised / scaled) query, float paths' error bound
+    double m1 = 0;      // sum q_i^2 of the caller's query (zero-query detection)
+    double qscale = 0;  // integer paths: prepared query ~ qscale * Q
+    double qconst = 0;  // integer paths: sum Q_i
+    double qnorm2 = 0;  // integer paths, euclid: sum g_i^2
+};
+
 struct Cand {
     uint64_t row;  // index-level row
     double dist;   // reference float64 distance
@@ -158,6 +167,7 @@ struct Ctx {
     uint32_t *d_count = nullptr;
     bool timed_scan = false;
     int timed_n = 0;               // scan launches between ev_scan0 and ev_scan1
+    QMeta meta[kMaxBatch];         // constants of the staged queries
 };
 
 struct Shard {
@@ -191,6 +201,7 @@ struct szg_index {
     uint32_t row_bytes = 0, pitch = 0;
     szg::RowMap map{};
     size_t qsw_bytes = 0;
+    double norm_bias = 0;     // integer paths: sum n^2 = 4(SQ+SV) + norm_bias (padding removed)
     uint64_t row_base = 0;
     std::vector<Shard *> shards;
     // tunables
@@ -227,28 +238,83 @@ szg::RowMap choose_map(int r16)
     return best;
 }
 
-// Query as the scan wants it: float (double for 64-bit rows), pre-normalised for
-// cosine, pre-scaled by maxInt for quantized euclid, laid out [chunk][piece][4].
-void prep_query(const szg_index *ix, const double *q, uint8_t *out_sw, double *scaled_norm,
-                double *m1_out)
+// Query as the scan wants it (see RowAcc in kernels_scan.hip):
+//  * 16/32/64-bit rows: float (double for 64-bit), pre-normalised for cosine,
+//    pre-scaled by maxInt for 16-bit euclid, laid out [chunk][piece][4];
+//  * 8/4-bit rows: the prepared real query v (q/|q| for cosine, maxInt*q for
+//    euclid) quantized to integers Q_i = round(v_i / qscale) and split into
+//    balanced digit planes (3 x int8 radix 128, or 5 x int4 radix 16), one
+//    16-byte plane word per 16-byte piece of the row.
+void prep_query(const szg_index *ix, const double *q, uint8_t *out_sw, QMeta *meta)
 {
     const int dim = ix->dim, bits = ix->bits;
     const int E = 128 / bits;
     const int r16 = ix->map.r16;
     memset(out_sw, 0, ix->qsw_bytes);
+    *meta = QMeta{};
     double m1 = 0.0;
     for (int i = 0; i < dim; i++) m1 += q[i] * q[i];
-    *m1_out = m1;
+    meta->m1 = m1;
     double scale = 1.0;
     if (ix->metric == SZG_COSINE) {
         scale = m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0;
     } else if (bits <= 16) {
         scale = (double)((1u << bits) - 1u);
     }
-    double nrm = 0.0;
+    double nrm = 0.0, vmax = 0.0;
     for (int e = 0; e < dim; e++) {
         const double v = q[e] * scale;
         nrm += v * v;
+        vmax = std::max(vmax, std::fabs(v));
+    }
+    meta->qnorm = std::sqrt(nrm);
+    meta->qnorm2 = nrm;
+    if (bits == 8 || bits == 4) {
+        const double Qmax = bits == 8 ? 1000000.0 : 480000.0;
+        const double qs = (vmax > 0 && std::isfinite(vmax)) ? vmax / Qmax : 1.0;
+        meta->qscale = qs;
+        double sumQ = 0.0;
+        uint32_t *planes = reinterpret_cast<uint32_t *>(out_sw);
+        for (int e = 0; e < dim; e++) {
+            double t = std::nearbyint(q[e] * scale / qs);
+            if (!(t == t)) t = 0;
+            t = std::max(-Qmax, std::min(Qmax, t));
+            long long Q = (long long)t;
+            sumQ += (double)Q;
+            const int j = e / E, i = e % E;
+            if (bits == 8) {
+                const int d = i / 4, kb = i % 4;
+                for (int x = 2; x >= 0; x--) {  // planes: 0 = h (x16384), 1 = m (x128), 2 = l
+                    long long dig;
+                    if (x > 0) {
+                        dig = ((Q + 64) & 127) - 64;
+                        Q = (Q - dig) >> 7;
+                    } else {
+                        dig = Q;
+                    }
+                    planes[((size_t)x * r16 + j) * 4 + d] |= (uint32_t)((uint8_t)(int8_t)dig) << (8 * kb);
+                }
+            } else {
+                // byte b of the piece holds element 2b in its high nibble, 2b+1 in the low one
+                const int bb = i / 2, d = bb / 4, kb = bb % 4;
+                const int t4 = 2 * kb + ((i % 2 == 0) ? 1 : 0);
+                for (int x = 0; x < 5; x++) {  // plane x carries the digit of weight 16^x
+                    long long dig;
+                    if (x < 4) {
+                        dig = ((Q + 8) & 15) - 8;
+                        Q = (Q - dig) >> 4;
+                    } else {
+                        dig = Q;
+                    }
+                    planes[((size_t)x * r16 + j) * 4 + d] |= (uint32_t)(dig & 0xF) << (4 * t4);
+                }
+            }
+        }
+        meta->qconst = sumQ;
+        return;
+    }
+    for (int e = 0; e < dim; e++) {
+        const double v = q[e] * scale;
         const int j = e / E, i = e % E;
         if (bits == 64) {
             reinterpret_cast<double *>(out_sw)[(size_t)j * 2 + i] = v;
@@ -257,19 +323,25 @@ void prep_query(const szg_index *ix, const double *q, uint8_t *out_sw, double *s
             reinterpret_cast<float *>(out_sw)[((size_t)c * r16 + j) * 4 + m] = (float)v;
         }
     }
-    *scaled_norm = std::sqrt(nrm);
 }
 
 // Bound on |scan key - real-number key| (see DESIGN.md "certification").
-double key_eps(const szg_index *ix, double key, double qnorm)
+double key_eps(const szg_index *ix, double key, const QMeta &m)
 {
+    const double k = std::fabs(key);
+    if (ix->bits == 8 || ix->bits == 4) {
+        // integer paths: the row sums are exact; what is left is the query's
+        // quantization (|v_i - qscale*Q_i| <= qscale/2) and a few float roundings
+        const double M = (double)((1u << ix->bits) - 1u);
+        if (ix->metric == SZG_COSINE) return 0.5 * m.qscale * std::sqrt((double)ix->dim) + 0x1p-21;
+        return m.qscale * M * (double)ix->dim + 0x1p-22 * k + 1e-30;
+    }
     const double u = ix->bits == 64 ? 0x1p-53 : 0x1p-24;
     const double n = (double)ix->dim + 16.0;
     if (ix->metric == SZG_COSINE) {
         return 2.0 * n * u + (ix->bits == 64 ? 0x1p-22 : 0.0);
     }
-    const double k = std::fabs(key);
-    return 2.0 * n * u * k + 8.0 * u * qnorm * std::sqrt(k) + (ix->bits == 64 ? 0x1p-22 * k : 0.0) +
+    return 2.0 * n * u * k + 8.0 * u * m.qnorm * std::sqrt(k) + (ix->bits == 64 ? 0x1p-22 * k : 0.0) +
            1e-37;
 }
 
@@ -429,6 +501,10 @@ void fill_scan_args(const szg_index *ix, const Shard *sh, const Ctx *c, bool has
     a->query_stride = (uint32_t)ix->qsw_bytes;
     a->query = c->d_qsw + (size_t)slot * ix->qsw_bytes;
     a->n_queries = nq;
+    a->qscale = c->meta[slot].qscale;
+    a->qconst = c->meta[slot].qconst;
+    a->qnorm2 = c->meta[slot].qnorm2;
+    a->norm_bias = ix->norm_bias;
 }
 
 // Launch the fused scan for each of the batch's queries (n = a->size()) as the
@@ -666,7 +742,7 @@ int run_full_replay(szg_index *ix, std::vector<Ctx *> &ctx, int slot, const uint
 struct Ticket {
     int first = 0, nq = 0;       // queries [first, first+nq) of the call
     std::vector<Ctx *> ctx;      // one per shard
-    std::vector<double> qnorm, m1;
+    std::vector<QMeta> meta;
     int kp = 0;
 };
 
@@ -722,7 +798,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
             // the result is final once its worst key clears thr_min by the error bound
             bool certified = true;
             float kmax = -INFINITY;
-            const bool zero_query = ix->metric == SZG_COSINE && t.m1[j] == 0;  // all distances 1.0
+            const bool zero_query = ix->metric == SZG_COSINE && t.meta[j].m1 == 0;  // all distances 1.0
             if (std::isfinite(thr_min[j]) && !zero_query) {
                 std::vector<std::pair<uint64_t, float>> by_row;  // cands are sorted by row now
                 by_row.reserve(cands.size());
@@ -732,8 +808,8 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                                                std::make_pair(h.row, -INFINITY));
                     kmax = std::max(kmax, it->second);
                 }
-                const double lhs = (double)kmax + key_eps(ix, kmax, t.qnorm[j]) +
-                                   key_eps(ix, thr_min[j], t.qnorm[j]);
+                const double lhs = (double)kmax + key_eps(ix, kmax, t.meta[j]) +
+                                   key_eps(ix, thr_min[j], t.meta[j]);
                 certified = (int)res.size() == k && lhs < thr_min[j];
             }
             if (ix->force_escalate && std::isfinite(thr_min[j])) certified = false;
@@ -745,7 +821,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 double thr = INFINITY;
                 if ((int)res.size() == k && std::isfinite(kmax) && !zero_query)
                     thr = (double)kmax +
-                          2.1 * key_eps(ix, (double)kmax + key_eps(ix, kmax, t.qnorm[j]), t.qnorm[j]);
+                          2.1 * key_eps(ix, (double)kmax + key_eps(ix, kmax, t.meta[j]), t.meta[j]);
                 const float thr_f = thr >= 3.0e38 ? 3.0e38f : std::nextafter((float)thr, INFINITY);
                 cands.clear();
                 for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
@@ -793,8 +869,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
         t.nq = std::min(B, n_queries - q0);
         t.kp = kp;
         t.ctx.assign(n_sh, nullptr);
-        t.qnorm.assign(t.nq, 0.0);
-        t.m1.assign(t.nq, 0.0);
+        t.meta.assign(t.nq, QMeta{});
         // one context per shard; never block while holding in-flight work
         bool got = true;
         for (size_t s = 0; s < n_sh; s++) {
@@ -818,9 +893,11 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
         for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
             Shard *sh = ix->shards[s];
             if (sh->n_rows == 0) continue;
-            for (int j = 0; j < t.nq; j++)
+            for (int j = 0; j < t.nq; j++) {
                 prep_query(ix, q + (size_t)j * ix->dim, t.ctx[s]->h_qsw + (size_t)j * ix->qsw_bytes,
-                           &t.qnorm[j], &t.m1[j]);
+                           &t.meta[j]);
+                t.ctx[s]->meta[j] = t.meta[j];
+            }
             rc = enqueue_queries(ix, sh, t.ctx[s], q, t.nq, allow, allow_stride);
             if (rc == SZG_OK) rc = enqueue_topk(ix, sh, t.ctx[s], kp, t.nq, allow != nullptr);
         }
@@ -1011,8 +1088,12 @@ int szg_index_create(szg_index **out, int dim, int quant_bits, int metric, const
     ix->row_bytes = (uint32_t)rb;
     ix->pitch = (uint32_t)((rb + 15) & ~15ll);
     ix->map = choose_map((int)(ix->pitch / 16));
-    const size_t E = 128 / quant_bits, QB = quant_bits == 64 ? 8 : 4;
-    ix->qsw_bytes = (size_t)ix->map.r16 * E * QB;
+    ix->qsw_bytes = szg::query_lds_bytes(quant_bits, ix->map.r16);
+    if (quant_bits == 8 || quant_bits == 4) {
+        const double M = (double)((1u << quant_bits) - 1u);
+        const double slots = (double)ix->map.r16 * (128 / quant_bits);  // elements incl. padding
+        ix->norm_bias = slots - (slots - dim) * M * M;  // each padding slot decodes to n = -maxInt
+    }
     if (ix->qsw_bytes > 48u * 1024u) {
         delete ix;
         return fail(SZG_E_UNSUPPORTED, "dimension too large for the LDS-resident query");
@@ -1247,21 +1328,22 @@ int szg_search_radius(szg_index *ix, const double *query, double radius,
     if (total_rows == 0) return SZG_OK;
 
     // key threshold that surely contains every row with distance <= radius
-    double qnorm = 0, m1 = 0;
+    QMeta meta;
     std::vector<uint8_t> tmp(ix->qsw_bytes);
-    prep_query(ix, query, tmp.data(), &qnorm, &m1);
+    prep_query(ix, query, tmp.data(), &meta);
+    const double m1 = meta.m1;
     float thr_f;
     if (ix->metric == SZG_COSINE) {
         if (radius >= 1.0 || m1 == 0) {
             thr_f = 3.0e38f;  // acos(c)/pi <= 1 always; zero query -> all 1.0
         } else {
-            const double t = -std::cos(M_PI * radius) + 2.0 * key_eps(ix, 1.0, qnorm) + 1e-12;
+            const double t = -std::cos(M_PI * radius) + 2.0 * key_eps(ix, 1.0, meta) + 1e-12;
             thr_f = std::nextafter((float)t, INFINITY);
         }
     } else {
         const double scale = ix->bits <= 16 ? (double)((1u << ix->bits) - 1u) : 1.0;
         const double kk = (radius * scale) * (radius * scale);
-        const double t = kk * (1.0 + 1e-12) + 2.0 * key_eps(ix, kk, qnorm);
+        const double t = kk * (1.0 + 1e-12) + 2.0 * key_eps(ix, kk, meta);
         thr_f = t >= 3.0e38 ? 3.0e38f : std::nextafter((float)t, INFINITY);
     }
 
@@ -1272,6 +1354,7 @@ int szg_search_radius(szg_index *ix, const double *query, double radius,
         if (sh->n_rows == 0) continue;
         Ctx *c = ctx_acquire(sh);
         memcpy(c->h_qsw, tmp.data(), ix->qsw_bytes);
+        c->meta[0] = meta;
         rc = enqueue_queries(ix, sh, c, query, 1, allow_bits, (total_rows + 63) / 64);
         if (rc == SZG_OK) rc = run_collect(ix, sh, c, 0, thr_f, allow_bits != nullptr, &cands);
         ctx_release(sh, c);
