@@ -64,6 +64,19 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+def traffic_for(workload, rows_override):
+    """HBM bytes per scan launch from the PMC passes recorded in profiles/traffic.json
+    (FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE); None when no pass exists for
+    this exact workload."""
+    if rows_override:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)[workload]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,7 +206,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic_for(args.workload, args.rows),
                 "kernel": "szg::scan_kernel<%d,%d,...>" % (bits, metric),
                 "bytes_per_launch": int(bytes_per_launch),
                 "avg_launch_ms": round(scan_ms, 5),
