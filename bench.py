@@ -114,11 +114,19 @@ def main():
 
     dist = None
     torch = None
+    # rehearsal knobs (1-GPU box): SZG_BENCH_BACKEND=gloo exchanges on the CPU,
+    # SZG_BENCH_ONE_GPU=1 puts every rank's shard on device 0
+    backend = os.environ.get("SZG_BENCH_BACKEND", "nccl")
+    if os.environ.get("SZG_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         try:
             import torch  # only for torch.cuda.synchronize() around the timed region
@@ -137,7 +145,7 @@ def main():
 
     if world > 1:
         searcher = ShardedSearcher(lambda q, kk: ix.search_topk(q, kk),
-                                   device=torch.device("cuda", local_rank))
+                                   device=torch.device("cuda", local_rank) if backend == "nccl" else None)
 
         def run(q):
             outs = []
@@ -150,7 +158,7 @@ def main():
             return r, d
 
     def sync():
-        if torch is not None and torch.cuda.is_available():
+        if torch is not None and backend == "nccl" and torch.cuda.is_available():
             torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -167,7 +175,7 @@ def main():
     stats = ix.stats()
     ix.set_timing(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -206,7 +214,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic_for(args.workload, args.rows),
+                "traffic": traffic_for(args.workload, args.rows) if world == 1 else None,
                 "kernel": "szg::scan_kernel<%d,%d,...>" % (bits, metric),
                 "bytes_per_launch": int(bytes_per_launch),
                 "avg_launch_ms": round(scan_ms, 5),
