@@ -152,6 +152,8 @@ typedef struct szg_stats {
     uint64_t timed_launches;   /* launches included in scan_ms */
     uint64_t full_replays;     /* top-k queries answered by the exact full-history replay
                                   (equal distances or NaN among the best k+1 candidates) */
+    uint64_t mq_launches;      /* shared (multi-query) sweeps; each is also one scan launch */
+    uint64_t mq_queries;       /* queries answered through shared sweeps */
 } szg_stats;
 
 /* Per-kernel HIP-event timing on the library's own streams (off by default). */
@@ -162,7 +164,10 @@ int szg_reset_stats(szg_index *ix);
 /*
  * Tunables: "slack" (extra candidates kept beyond k), "blocks_per_cu",
  * "block_threads", "query_batch" (queries one scan launch walks back to back,
- * default 16), "contexts" (batches in flight per shard), "serialize_scans",
+ * default 16), "multi_query" (default 1: batches of >= "mq_min" queries on 32-bit
+ * cosine collections share ONE sweep of the corpus, the dot products going to the
+ * matrix cores; 0 = every query gets its own sweep), "contexts" (batches in
+ * flight per shard), "serialize_scans",
  * "tie_mode" (0 = default: when two of the best k+1 distances
  * are exactly equal, or one is NaN, the reference's output depends on its whole
  * heap history, so the query is re-answered by an exact replay over every row;

@@ -44,6 +44,8 @@ class SzgStats(ctypes.Structure):
         ("total_ms", ctypes.c_double),
         ("timed_launches", ctypes.c_uint64),
         ("full_replays", ctypes.c_uint64),
+        ("mq_launches", ctypes.c_uint64),
+        ("mq_queries", ctypes.c_uint64),
     ]
 
 

@@ -1,0 +1,267 @@
+// kernels_mq.hip -- multi-query sweep for gfx950: B queries per pass of the corpus.
+//
+// The single-query scan (kernels_scan.hip) is HBM-bound: every query costs one
+// full sweep.  When the caller hands over a batch (szg_search_topk with
+// n_queries > 1, the reference's concurrent Searches under RLock), the sweep is
+// shared: the corpus streams through once and the B query x row dot products
+// go to the matrix cores.
+//
+//   mq_score_kernel   v_mfma_f32_16x16x4_f32 (f32 in / f32 acc, bit-for-bit a
+//                     k-ordered fmaf chain): a wave owns a tile of 16 rows, lane l
+//                     loads 16 bytes of row (l & 15), 16-byte chunk (l >> 4) of
+//                     each 64-byte step; the same 4 floats are the B operand of 4
+//                     MFMAs per block of 16 queries, whose A operand (the
+//                     queries) comes from LDS with one ds_read_b128.  Row norms
+//                     are VALU side work.  Output: the score matrix
+//                     keys[B][n_rows] (float, the same -cos key the single-query
+//                     scan ranks by; +B*4 bytes per row of HBM writes).
+//   mq_select_kernel  per query, thresholded selection of the kp best keys
+//                     (per-wave sorted LDS lists as in the scan), one sorted list
+//                     per (query, block); the usual merge / float64 rerank /
+//                     certification tail follows.
+//
+// 32-bit rows, cosine only (the headline configuration); everything else takes
+// the single-query path.
+#include "kernels.h"
+#include "device_lists.h"
+
+namespace szg {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kRingMq = 6;
+
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ u32x4 load_nt(const uint8_t *p)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+}
+
+// LDS image of the batch: [chunk j][query block][query 16][4 floats]
+template <int NB>
+__global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int r16 = a.r16;           // 16-byte chunks per row
+    const int steps = (r16 + 3) / 4; // 64-byte steps per row
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        const int n = r16 * NB * 16;
+        for (int i = tid; i < n; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float4 *qlds = reinterpret_cast<const float4 *>(smem);
+
+    const int trow = lane & 15;
+    const int c = lane >> 4;
+    const uint64_t n_tiles = ((uint64_t)a.n_rows + 15) / 16;
+    const uint64_t tile_stride = (uint64_t)gridDim.x * nwaves;
+    const uint64_t tile_first = (uint64_t)blockIdx.x * nwaves + wave;
+    const uint64_t n_it = tile_first < n_tiles ? (n_tiles - tile_first + tile_stride - 1) / tile_stride : 0;
+    const uint64_t NP = n_it * (uint64_t)steps;
+
+    // issue cursor
+    uint64_t itile = tile_first;
+    int is = 0;
+    // consume cursor
+    uint64_t ctile = tile_first;
+    int cs = 0;
+
+    u32x4 ring[kRingMq];
+    f32x4 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float nrm = 0.f;
+    uint32_t nz = 0;
+
+#define MQ_ISSUE(u)                                                                      \
+    {                                                                                    \
+        const uint64_t row_ = itile * 16 + trow;                                         \
+        const int j_ = is * 4 + c;                                                       \
+        const bool ok_ = row_ < a.n_rows && j_ < r16;                                    \
+        ring[u] = load_nt(ok_ ? a.rows + row_ * a.pitch + (size_t)j_ * 16 : a.zero16);   \
+        if (++is == steps) {                                                             \
+            is = 0;                                                                      \
+            itile += tile_stride;                                                        \
+        }                                                                                \
+    }
+
+#define MQ_CONSUME(u)                                                                    \
+    {                                                                                    \
+        const u32x4 v_ = ring[u];                                                        \
+        const float x0 = __uint_as_float(v_.x), x1 = __uint_as_float(v_.y);              \
+        const float x2 = __uint_as_float(v_.z), x3 = __uint_as_float(v_.w);              \
+        const int j_ = min(cs * 4 + c, r16 - 1); /* out-of-range chunks carry zeros */   \
+        _Pragma("unroll") for (int b = 0; b < NB; b++)                                   \
+        {                                                                                \
+            const float4 q_ = qlds[(j_ * NB + b) * 16 + trow];                           \
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.x, x0, acc[b], 0, 0, 0);    \
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.y, x1, acc[b], 0, 0, 0);    \
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.z, x2, acc[b], 0, 0, 0);    \
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.w, x3, acc[b], 0, 0, 0);    \
+        }                                                                                \
+        nrm = fmaf(x0, x0, nrm);                                                         \
+        nrm = fmaf(x1, x1, nrm);                                                         \
+        nrm = fmaf(x2, x2, nrm);                                                         \
+        nrm = fmaf(x3, x3, nrm);                                                         \
+        nz |= (v_.x | v_.y | v_.z | v_.w) & 0x7FFFFFFFu;                                 \
+        if (++cs == steps) {                                                             \
+            finish_tile(ctile);                                                          \
+            cs = 0;                                                                      \
+            ctile += tile_stride;                                                        \
+        }                                                                                \
+    }
+
+    // a row tile is done: row norms across the 4 chunk lanes, keys out
+    auto finish_tile = [&](uint64_t tile) {
+        nrm += __shfl_xor(nrm, 16);
+        nrm += __shfl_xor(nrm, 32);
+        nz |= __shfl_xor(nz, 16);
+        nz |= __shfl_xor(nz, 32);
+        const uint64_t row = tile * 16 + trow;
+        const float inv = __frsqrt_rn(nrm);
+        // D layout of the 16x16 product: column = lane & 15 (the tile's row),
+        // row = (lane >> 4) * 4 + reg (the query inside its block of 16)
+        if (row < a.n_rows) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int q = b * 16 + c * 4 + r;
+                    float key = -acc[b][r] * inv;
+                    if (nrm == 0.f) key = nz ? -2.0f : 1.0f;  // zero row: distance 1.0 (collection.go:828-830)
+                    if (!(key == key)) key = 3.0e38f;
+                    if (key > 3.0e38f) key = 3.0e38f;
+#ifdef MQ_NO_WRITE
+                    if (q < a.n_queries && key == 123.456f) a.keys[(size_t)q * a.key_stride + row] = key;
+#else
+                    if (q < a.n_queries) a.keys[(size_t)q * a.key_stride + row] = key;
+#endif
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        nrm = 0.f;
+        nz = 0;
+    };
+
+    uint64_t issued = 0, consumed = 0;
+#pragma unroll
+    for (int u = 0; u < kRingMq; u++) {
+        if (issued < NP) {
+            MQ_ISSUE(u)
+            issued++;
+        }
+    }
+    while (consumed + 2 * kRingMq <= NP) {
+#pragma unroll
+        for (int u = 0; u < kRingMq; u++) {
+            MQ_CONSUME(u)
+            MQ_ISSUE(u)
+        }
+        consumed += kRingMq;
+        issued += kRingMq;
+    }
+    while (consumed < NP) {
+#pragma unroll
+        for (int u = 0; u < kRingMq; u++) {
+            if (consumed < NP) {
+                MQ_CONSUME(u)
+                consumed++;
+                if (issued < NP) {
+                    MQ_ISSUE(u)
+                    issued++;
+                }
+            }
+        }
+    }
+#undef MQ_ISSUE
+#undef MQ_CONSUME
+}
+
+// ---- per-query selection over the score matrix ----------------------------------
+
+// grid (blocks per query, queries).  Each lane reads 4 keys at a time (16 bytes);
+// a key that beats the wave's current kp-th best is inserted into the wave's list.
+__global__ __launch_bounds__(256) void mq_select_kernel(const float *keys, size_t key_stride,
+                                                        uint32_t n_rows, const uint64_t *live_bits,
+                                                        const uint64_t *allow_bits,
+                                                        uint32_t allow_stride, int kp,
+                                                        uint64_t *block_lists)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint64_t *lists = reinterpret_cast<uint64_t *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int q = blockIdx.y;
+    WaveList wl;
+    wl.init(lists + (size_t)wave * kp, kp, lane);
+    __syncthreads();
+    const float *kq = keys + (size_t)q * key_stride;
+    const uint64_t *allow = allow_bits ? allow_bits + (size_t)q * allow_stride : nullptr;
+    const uint32_t n4 = (n_rows + 3) / 4;  // key_stride is a multiple of 4, the tail holds +inf
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + tid; i < ((n4 + stride - 1) / stride) * stride; i += stride) {
+        float4 v = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f);
+        if (i < n4) v = reinterpret_cast<const float4 *>(kq)[i];
+        const float kk[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t row = i * 4 + e;
+            bool ok = i < n4 && row < n_rows;
+            if (ok && live_bits) ok = (live_bits[row >> 6] >> (row & 63)) & 1;
+            if (ok && allow) ok = (allow[row >> 6] >> (row & 63)) & 1;
+            const uint64_t cnd = ((uint64_t)ordered_key(kk[e]) << 32) | row;
+            wl.offer(ok, cnd, lane);
+        }
+    }
+    wl.flush(lane);
+    __syncthreads();
+    block_merge_lists(lists, nwaves, kp, block_lists + ((size_t)q * gridDim.x + blockIdx.x) * kp, tid,
+                      blockDim.x);
+}
+
+}  // namespace
+
+size_t mq_lds_bytes(int r16, int nb) { return (size_t)r16 * nb * 16 * 16; }
+
+hipError_t launch_mq_score(const MqArgs &a, int nb, int grid, hipStream_t stream)
+{
+    const size_t lds = mq_lds_bytes(a.r16, nb);
+    hipError_t e = hipSuccess;
+    if (nb == 1) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mq_score_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(mq_score_kernel<1>, dim3(grid), dim3(1024), lds, stream, a);
+    } else if (nb == 2) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mq_score_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(mq_score_kernel<2>, dim3(grid), dim3(1024), lds, stream, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_rows,
+                            const uint64_t *live_bits, const uint64_t *allow_bits,
+                            uint32_t allow_stride, int kp, int n_queries, int blocks_per_query,
+                            uint64_t *block_lists, hipStream_t stream)
+{
+    const size_t lds = (size_t)4 * kp * sizeof(uint64_t);
+    hipLaunchKernelGGL(mq_select_kernel, dim3(blocks_per_query, n_queries), dim3(256), lds, stream, keys,
+                       key_stride, n_rows, live_bits, allow_bits, allow_stride, kp, block_lists);
+    return hipGetLastError();
+}
+
+}  // namespace szg

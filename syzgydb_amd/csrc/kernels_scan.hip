@@ -14,6 +14,7 @@
 // surrogates of the reference distance (-cos or squared L2); the exact
 // float64 distance is recomputed for the few survivors by kernels_exact.hip.
 #include "kernels.h"
+#include "device_lists.h"
 
 namespace szg {
 
@@ -72,14 +73,6 @@ __device__ __forceinline__ double dpp_xchg(double v)
     const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, true);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, true);
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
-
-__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src)
-{
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = __shfl(lo, src);
-    hi = __shfl(hi, src);
-    return ((uint64_t)hi << 32) | lo;
 }
 
 // ---- row accumulators ---------------------------------------------------------
@@ -307,49 +300,6 @@ struct RowAcc<4, METRIC> {
     }
 };
 
-// ---- per-wave sorted candidate list in LDS ----------------------------------
-// Only the owning wave touches its list and DS operations of one wave complete
-// in issue order, so no s_barrier is needed; the wave barriers stop the
-// compiler from moving one lane's store across another lane's load (it only
-// reasons per thread).  Plain (non-volatile) pointers keep the accesses ds_*
-// instructions: a volatile generic pointer would turn them into flat_* ops,
-// which drain the whole global-load queue on every use.
-
-__device__ __forceinline__ uint64_t list_insert(uint64_t *list, int kp, uint64_t c, int lane)
-{
-    int pos = 0;
-    for (int base = 0; base < kp; base += kWave) {
-        const int e = base + lane;
-        const bool lt = e < kp && list[e] < c;
-        pos += __popcll(__ballot(lt));
-    }
-    // shift [pos, kp-2] one slot up, highest chunk first
-    for (int base = ((kp - 1) / kWave) * kWave; base >= 0; base -= kWave) {
-        if (base + kWave - 1 <= pos) break;
-        const int e = base + lane;
-        const bool mv = e > pos && e < kp;
-        uint64_t v = 0;
-        if (mv) v = list[e - 1];
-        __builtin_amdgcn_wave_barrier();
-        if (mv) list[e] = v;
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (lane == 0) list[pos] = c;
-    __builtin_amdgcn_wave_barrier();
-    return list[kp - 1];
-}
-
-// number of entries of sorted list[0..n) that are < c
-__device__ __forceinline__ int lower_count(const uint64_t *list, int n, uint64_t c)
-{
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (list[mid] < c) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
 // ---- the scan ---------------------------------------------------------------
 
 template <int QBITS, int METRIC, int D, bool COLLECT, bool MASKED>
@@ -384,11 +334,10 @@ __global__ __launch_bounds__(512) void scan_kernel(const ScanArgs a)
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (int i = tid; i < qbytes / 16; i += blockDim.x) dst[i] = src[i];
     }
-    if (!COLLECT)
-        for (int i = lane; i < a.kp; i += kWave) mylist[i] = kInvalidCand;
+    WaveList wl;
+    wl.init(mylist, COLLECT ? 0 : a.kp, lane);
     __syncthreads();
     const uint64_t *allow_bits = a.allow_bits ? a.allow_bits + (size_t)qi * a.allow_stride : nullptr;
-    uint64_t worst = kInvalidCand;
 
     // is the row of this lane's group at wave-row `row0` to be scanned?
     auto row_valid = [&](uint64_t row0) -> bool {
@@ -426,13 +375,7 @@ __global__ __launch_bounds__(512) void scan_kernel(const ScanArgs a)
                 }
             }
         } else {
-            uint64_t m = __ballot(leader && c < worst);
-            while (m) {
-                const int src = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const uint64_t cc = shfl_u64(c, src);
-                if (cc < worst) worst = list_insert(mylist, a.kp, cc, lane);
-            }
+            wl.offer(leader, c, lane);
         }
     };
 
@@ -533,25 +476,11 @@ __global__ __launch_bounds__(512) void scan_kernel(const ScanArgs a)
 
     if (COLLECT) continue;
 
-    // block-wide k-select: rank-merge the waves' sorted lists (entries are unique)
+    // block-wide k-select over the waves' lists
+    wl.flush(lane);
     __syncthreads();
-    uint64_t *out = a.block_lists + ((size_t)qi * gridDim.x + blockIdx.x) * a.kp;
-    for (int i = tid; i < a.kp; i += blockDim.x) out[i] = kInvalidCand;
-    __syncthreads();
-    const int total = nwaves * a.kp;
-    for (int it = tid; it < total; it += blockDim.x) {
-        const int w = it / a.kp;
-        const int i = it - w * a.kp;
-        const uint64_t c = lists[it];
-        if (c == kInvalidCand) continue;
-        int rank = i;
-        for (int w2 = 0; w2 < nwaves; w2++) {
-            if (w2 == w) continue;
-            rank += lower_count(lists + (size_t)w2 * a.kp, a.kp, c);
-            if (rank >= a.kp) break;
-        }
-        if (rank < a.kp) out[rank] = c;
-    }
+    block_merge_lists(lists, nwaves, a.kp, a.block_lists + ((size_t)qi * gridDim.x + blockIdx.x) * a.kp,
+                      tid, blockDim.x);
     }  // for qi
 }
 

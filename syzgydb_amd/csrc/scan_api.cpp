@@ -165,6 +165,11 @@ struct Ctx {
     uint64_t *d_collect = nullptr;
     size_t collect_cap = 0;        // entries
     uint32_t *d_count = nullptr;
+    // multi-query sweep: LDS image of the batch, score matrix
+    uint8_t *h_mq = nullptr, *d_mq = nullptr;
+    size_t h_mq_cap = 0, d_mq_cap = 0;
+    float *d_keys = nullptr;
+    size_t keys_cap = 0;           // floats
     bool timed_scan = false;
     int timed_n = 0;               // scan launches between ev_scan0 and ev_scan1
     QMeta meta[kMaxBatch];         // constants of the staged queries
@@ -192,6 +197,7 @@ struct Shard {
     // copy work of other batches overlap them on the contexts' own streams.
     std::mutex chain_mu;
     hipStream_t scan_stream = nullptr;
+    uint8_t *zero16 = nullptr;   // 16 zero bytes idle lanes of the multi-query sweep read
 };
 
 }  // namespace
@@ -213,6 +219,8 @@ struct szg_index {
     int force_escalate = 0;   // test hook: treat every first pass as uncertified
     int tie_mode = 0;         // 0: exact full replay on ties/NaN, 1: keep the fast answer
     int serialize_scans = 1;  // scan launches of a shard never overlap each other
+    int multi_query = 1;      // share one sweep between the queries of a batch (MFMA path)
+    int mq_min = 8;           // smallest batch worth a shared sweep
     bool timing = false;
     std::mutex stats_mu;
     szg_stats stats{};
@@ -386,6 +394,9 @@ void ctx_free(Ctx *c)
     (void)hipFree(c->d_allow);
     (void)hipFree(c->d_collect);
     (void)hipFree(c->d_count);
+    (void)hipHostFree(c->h_mq);
+    (void)hipFree(c->d_mq);
+    (void)hipFree(c->d_keys);
     delete c;
 }
 
@@ -569,6 +580,115 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
     if (rc) return rc;
 
     int n_lists = g.grid;
+    uint64_t *src = c->d_lists_a, *dst = c->d_lists_b;
+    const int fan = szg::merge_fan(kp);
+    while (n_lists > 1) {
+        HIPCHK(szg::launch_merge(src, n_lists, kp, nq, dst, c->stream));
+        n_lists = (n_lists + fan - 1) / fan;
+        std::swap(src, dst);
+    }
+    HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64, src,
+                              nullptr, (uint32_t)kp, nq, c->d_out, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp * nq,
+                          hipMemcpyDeviceToHost, c->stream));
+    if (ix->timing) HIPCHK(hipEventRecord(c->ev_all1, c->stream));
+    return SZG_OK;
+}
+
+// ---- multi-query sweep (32-bit rows, cosine): B queries share one pass ------------
+
+int mq_blocks(const szg_index *ix, int nq)
+{   // query blocks of 16 the batch needs, or 0 when the shared sweep does not apply
+    if (!ix->multi_query || ix->bits != 32 || ix->metric != SZG_COSINE || nq < ix->mq_min) return 0;
+    const int nb = nq > 16 ? 2 : 1;
+    if (szg::mq_lds_bytes(ix->map.r16, nb) > 150u * 1024u) return 0;
+    return nb;
+}
+
+// top-k pass for the nq staged queries through ONE shared sweep:
+// score matrix -> per-query selection -> merges -> rerank -> D2H (async)
+int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bool has_allow)
+{
+    HIPCHK(hipSetDevice(sh->device));
+    const int r16 = ix->map.r16;
+    const size_t img = szg::mq_lds_bytes(r16, nb);
+    int rc = ensure_host(&c->h_mq, &c->h_mq_cap, img);
+    if (rc) return rc;
+    rc = ensure_dev(&c->d_mq, &c->d_mq_cap, img);
+    if (rc) return rc;
+    const size_t key_stride = ((size_t)sh->n_rows + 3) & ~(size_t)3;
+    rc = ensure_dev(&c->d_keys, &c->keys_cap, key_stride * nq);
+    if (rc) return rc;
+    // LDS image [chunk j][query block][query 16][4 floats] from the normalised queries
+    // (h_qsw holds them as float4 per chunk: [chunk j][4])
+    float *im = reinterpret_cast<float *>(c->h_mq);
+    memset(im, 0, img);
+    for (int q = 0; q < nq; q++) {
+        const float *src = reinterpret_cast<const float *>(c->h_qsw + (size_t)q * ix->qsw_bytes);
+        const int b = q / 16, qi = q % 16;
+        for (int j = 0; j < r16; j++)
+            memcpy(im + (((size_t)j * nb + b) * 16 + qi) * 4, src + (size_t)j * 4, 16);
+    }
+    HIPCHK(hipMemcpyAsync(c->d_mq, c->h_mq, img, hipMemcpyHostToDevice, c->stream));
+
+    const int sb = 16;  // select blocks per query
+    const size_t need = (size_t)nq * sb * kp;
+    if (c->lists_cap < need) {
+        if (c->d_lists_a) HIPCHK(hipFree(c->d_lists_a));
+        if (c->d_lists_b) HIPCHK(hipFree(c->d_lists_b));
+        c->d_lists_a = c->d_lists_b = nullptr;
+        c->lists_cap = 0;
+        HIPCHK(hipMalloc((void **)&c->d_lists_a, need * sizeof(uint64_t)));
+        HIPCHK(hipMalloc((void **)&c->d_lists_b, need * sizeof(uint64_t)));
+        c->lists_cap = need;
+    }
+    rc = ensure_dev(&c->d_out, &c->d_out_cap, (size_t)nq * kp);
+    if (rc) return rc;
+    rc = ensure_host(&c->h_out, &c->h_out_cap, (size_t)nq * kp);
+    if (rc) return rc;
+
+    szg::MqArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows = sh->rows;
+    a.n_rows = (uint32_t)sh->n_rows;
+    a.pitch = ix->pitch;
+    a.r16 = r16;
+    a.queries = c->d_mq;
+    a.n_queries = nq;
+    a.keys = c->d_keys;
+    a.key_stride = key_stride;
+    a.zero16 = sh->zero16;
+    {
+        std::lock_guard<std::mutex> lk(sh->chain_mu);
+        hipStream_t st = ix->serialize_scans ? sh->scan_stream : c->stream;
+        if (st != c->stream) {
+            HIPCHK(hipEventRecord(c->ev_up, c->stream));
+            HIPCHK(hipStreamWaitEvent(st, c->ev_up, 0));
+        }
+        if (ix->timing) HIPCHK(hipEventRecord(c->ev_scan0, st));
+        HIPCHK(szg::launch_mq_score(a, nb, sh->cu_count, st));
+        if (ix->timing) {
+            HIPCHK(hipEventRecord(c->ev_scan1, st));
+            c->timed_scan = true;
+            c->timed_n = 1;
+        }
+        if (st != c->stream) {
+            HIPCHK(hipEventRecord(c->ev_scan_done, st));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_scan_done, 0));
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(ix->stats_mu);
+        ix->stats.scan_launches += 1;
+        ix->stats.scan_bytes += sh->n_rows * (uint64_t)ix->row_bytes;  // ONE pass for the batch
+        ix->stats.mq_launches += 1;
+        ix->stats.mq_queries += (uint64_t)nq;
+    }
+    HIPCHK(szg::launch_mq_select(c->d_keys, key_stride, (uint32_t)sh->n_rows,
+                                 sh->has_dead ? sh->live_bits : nullptr,
+                                 has_allow ? c->d_allow : nullptr, (uint32_t)shard_words(sh), kp, nq, sb,
+                                 c->d_lists_a, c->stream));
+    int n_lists = sb;
     uint64_t *src = c->d_lists_a, *dst = c->d_lists_b;
     const int fan = szg::merge_fan(kp);
     while (n_lists > 1) {
@@ -862,11 +982,14 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
 
     std::deque<Ticket> inflight;
     int rc = SZG_OK;
-    const int B = std::max(1, std::min(ix->query_batch, kMaxBatch));
+    const int B1 = std::max(1, std::min(ix->query_batch, kMaxBatch));
     for (int q0 = 0; q0 < n_queries && rc == SZG_OK;) {
         Ticket t;
         t.first = q0;
-        t.nq = std::min(B, n_queries - q0);
+        // batches of up to 32 share one sweep when the multi-query path applies
+        const int left = n_queries - q0;
+        const int nb = mq_blocks(ix, std::min(left, 32));
+        t.nq = nb ? std::min(left, 16 * nb) : std::min(B1, left);
         t.kp = kp;
         t.ctx.assign(n_sh, nullptr);
         t.meta.assign(t.nq, QMeta{});
@@ -899,7 +1022,9 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 t.ctx[s]->meta[j] = t.meta[j];
             }
             rc = enqueue_queries(ix, sh, t.ctx[s], q, t.nq, allow, allow_stride);
-            if (rc == SZG_OK) rc = enqueue_topk(ix, sh, t.ctx[s], kp, t.nq, allow != nullptr);
+            if (rc == SZG_OK)
+                rc = nb ? enqueue_topk_mq(ix, sh, t.ctx[s], kp, t.nq, nb, allow != nullptr)
+                        : enqueue_topk(ix, sh, t.ctx[s], kp, t.nq, allow != nullptr);
         }
         inflight.push_back(std::move(t));
         q0 += inflight.back().nq;
@@ -1132,6 +1257,10 @@ int szg_index_create(szg_index **out, int dim, int quant_bits, int metric, const
             szg_index_destroy(ix);
             return fail(SZG_E_DEVICE, "hipStreamCreate(scan stream)");
         }
+        if (hipMalloc((void **)&sh->zero16, 64) != hipSuccess || hipMemset(sh->zero16, 0, 64) != hipSuccess) {
+            szg_index_destroy(ix);
+            return fail(SZG_E_NOMEM, "hipMalloc(zero16)");
+        }
         for (int i = 0; i < ix->n_ctx; i++) {
             Ctx *c = nullptr;
             int rc = ctx_alloc(ix, sh, &c);
@@ -1156,6 +1285,7 @@ void szg_index_destroy(szg_index *ix)
         (void)hipDeviceSynchronize();
         for (Ctx *c : sh->all_ctx) ctx_free(c);
         if (sh->scan_stream) (void)hipStreamDestroy(sh->scan_stream);
+        (void)hipFree(sh->zero16);
         (void)hipFree(sh->rows);
         (void)hipFree(sh->live_bits);
         delete sh;
@@ -1478,6 +1608,11 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
                 sh->free_ctx.pop_back();
             }
         }
+    } else if (n == "multi_query") {
+        ix->multi_query = value != 0;
+    } else if (n == "mq_min") {
+        if (value < 1 || value > 32) return fail(SZG_E_INVALID, "mq_min out of range");
+        ix->mq_min = (int)value;
     } else if (n == "serialize_scans") {
         ix->serialize_scans = value != 0;
     } else if (n == "tie_mode") {

@@ -1,0 +1,83 @@
+"""The shared (multi-query, MFMA) sweep against the oracle: same bar as the
+single-query path -- ids identical, float64 distances bit-equal."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from syzgydb_amd import ScanIndex, SZG_COSINE
+
+pytestmark = pytest.mark.gpu
+
+
+def check(ix, rows, dim, Q, k, allow=None):
+    kw = {}
+    if allow is not None:
+        kw["allow"] = np.tile(allow, (Q.shape[0], 1))
+    r, d, c = ix.search_topk(Q, k, **kw)
+    for qi in range(Q.shape[0]):
+        o_rows, o_dist, _ = orc.search_exact(rows, dim, 32, 1, Q[qi], k=k,
+                                             allow=None if allow is None else allow.astype(np.uint8))
+        assert c[qi] == len(o_rows)
+        assert [int(x) for x in r[qi, : c[qi]]] == [int(x) for x in o_rows], qi
+        got, want = d[qi, : c[qi]], o_dist
+        assert ((got == want) | (np.isnan(got) & np.isnan(want))).all(), qi
+
+
+@pytest.mark.parametrize("dim,n", [(768, 3000), (384, 5000), (128, 20000), (20, 1500), (3, 700), (100, 40)])
+@pytest.mark.parametrize("nq", [32, 20, 9, 70])
+def test_shared_sweep_matches_oracle(dim, n, nq):
+    rows = orc.synth_rows(31 + dim, 0, n, dim, 32)
+    Q = orc.synth_vectors(32 + dim, 0, nq, dim)
+    with ScanIndex(dim, 32, SZG_COSINE) as ix:
+        ix.load(rows)
+        check(ix, rows, dim, Q, 10)
+        st = ix.stats()
+        shared = nq - (nq % 32 if nq % 32 < 8 else 0)   # a tail below mq_min gets its own sweeps
+        assert st["mq_queries"] == shared and st["mq_launches"] == (shared + 31) // 32
+        ix.set_option("multi_query", 0)
+        ix.reset_stats()
+        check(ix, rows, dim, Q[:9], 10)
+        assert ix.stats()["mq_queries"] == 0
+
+
+def test_shared_sweep_masks_tombstones_and_escalation():
+    dim, n = 64, 4000
+    rows = orc.synth_rows(77, 0, n, dim, 32)
+    Q = orc.synth_vectors(78, 0, 24, dim)
+    allow = np.arange(n) % 3 != 1
+    with ScanIndex(dim, 32, SZG_COSINE) as ix:
+        ix.load(rows)
+        check(ix, rows, dim, Q, 5, allow=allow)
+        r, _, _ = ix.search_topk(Q, 5)
+        dead = int(r[0, 0])
+        ix.tombstone(dead)
+        allow2 = np.ones(n, bool)
+        allow2[dead] = False
+        check(ix, rows, dim, Q, 5, allow=allow2)
+        ix.set_option("force_escalate", 1)
+        ix.reset_stats()
+        check(ix, rows, dim, Q[:16], 5, allow=allow2)
+        assert ix.stats()["escalations"] == 16 and ix.stats()["mq_queries"] == 16
+    # duplicates: ties across the candidate boundary -> escalation / exact replay
+    base = orc.synth_vectors(5, 0, 6, 16)
+    vecs = np.repeat(base, 200, axis=0)
+    rows = orc.encode_rows(vecs, 32)
+    Q = np.repeat(base[:4] + 0.01, 4, axis=0)
+    with ScanIndex(16, 32, SZG_COSINE) as ix:
+        ix.load(rows)
+        check(ix, rows, 16, Q, 10)
+        assert ix.stats()["mq_queries"] == 16
+
+
+def test_shared_sweep_zero_rows_and_zero_query():
+    dim, n = 32, 600
+    vecs = orc.synth_vectors(9, 0, n, dim)
+    vecs[5] = 0.0
+    vecs[77] = 0.0
+    rows = orc.encode_rows(vecs, 32)
+    Q = orc.synth_vectors(10, 0, 16, dim)
+    Q[3] = 0.0
+    with ScanIndex(dim, 32, SZG_COSINE) as ix:
+        ix.load(rows)
+        check(ix, rows, dim, Q, 8)
+        check(ix, rows, dim, Q, 600)  # k >= n: zero rows (distance exactly 1.0) included
