@@ -32,6 +32,13 @@ EXPORTS = [
     "szg_reset_stats", "szg_set_option", "szg_index_synth", "szg_index_set_row_base",
     "szg_merge_topk",
 ]
+# include/syzgy_pager.h
+PAGER_EXPORTS = [
+    "szg_pager_open", "szg_pager_close", "szg_pager_options", "szg_pager_count", "szg_pager_skipped",
+    "szg_pager_ids", "szg_pager_vectors", "szg_pager_metadata", "szg_pager_load",
+]
+SZG_E_IO = -8
+SZG_E_FORMAT = -9
 
 
 class SzgStats(ctypes.Structure):
@@ -125,6 +132,24 @@ def load():
     L.szg_merge_topk.restype = ctypes.c_int
     L.szg_merge_topk.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, u64p, f64p,
                                  i32p, u64p, f64p, i32p, u8p]
+    L.szg_pager_open.restype = ctypes.c_int
+    L.szg_pager_open.argtypes = [ctypes.POINTER(vp), ctypes.c_char_p, ctypes.c_int]
+    L.szg_pager_close.restype = None
+    L.szg_pager_close.argtypes = [vp]
+    L.szg_pager_options.restype = ctypes.c_int
+    L.szg_pager_options.argtypes = [vp, intp, intp, intp]
+    L.szg_pager_count.restype = ctypes.c_uint64
+    L.szg_pager_count.argtypes = [vp]
+    L.szg_pager_skipped.restype = ctypes.c_uint64
+    L.szg_pager_skipped.argtypes = [vp]
+    L.szg_pager_ids.restype = ctypes.c_int
+    L.szg_pager_ids.argtypes = [vp, u64p]
+    L.szg_pager_vectors.restype = ctypes.c_int
+    L.szg_pager_vectors.argtypes = [vp, u8p, ctypes.c_uint64]
+    L.szg_pager_metadata.restype = ctypes.c_int
+    L.szg_pager_metadata.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(u8p), u64p]
+    L.szg_pager_load.restype = ctypes.c_int
+    L.szg_pager_load.argtypes = [vp, vp]
     L.szg_debug_f64_probe.restype = ctypes.c_int
     L.szg_debug_f64_probe.argtypes = [ctypes.c_int, f64p, f64p, f64p, ctypes.c_uint64]
     _lib = L

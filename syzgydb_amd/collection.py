@@ -82,6 +82,23 @@ class Collection:
         self._meta = []      # row -> metadata bytes
         self._closed = False
 
+    @classmethod
+    def from_spanfile(cls, path, devices=None):
+        """Open an existing SyzgyDB collection file: the header record's options
+        override the caller's (collection.go:241-252), every record's packed vector
+        is paged into HBM in IterateSortedRecords order (collection.go:297-311)."""
+        from .pager import SpanfilePager
+        with SpanfilePager(path) as pg:
+            c = cls(CollectionOptions(Name=str(path), DistanceMethod=pg.metric,
+                                      DimensionCount=pg.dim, Quantization=pg.quant_bits),
+                    devices=devices)
+            pg.load_into(c._index)
+            for row, id in enumerate(pg.ids()):
+                c._row_of[int(id)] = row
+                c._id_of.append(int(id))
+                c._meta.append(pg.metadata(row))
+        return c
+
     # -- CRUD (host bookkeeping + mirror maintenance) ---------------------------
     def AddDocument(self, id: int, vector, metadata: bytes = b""):
         v = np.asarray(vector, dtype=np.float64).reshape(-1)

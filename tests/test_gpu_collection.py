@@ -173,3 +173,36 @@ def test_concurrent_searches_from_threads():
         [t.start() for t in th]
         [t.join() for t in th]
         assert not errs, errs
+
+
+@pytest.mark.parametrize("bits,metric", [(64, 0), (32, 1), (8, 1), (4, 0)])
+def test_collection_from_spanfile_end_to_end(tmp_path, bits, metric):
+    """A SyzgyDB collection file -> C++ pager -> HBM mirror -> Search, against the
+    oracle scanning the same records in the same (sorted-string) visit order."""
+    import spanfile_writer as sw
+    from syzgydb_amd import codec
+    dim, n = 24, 700
+    vecs = orc.synth_vectors(41, 0, n, dim)
+    rows = codec.encode_rows(vecs, bits)
+    ids = [3 * i + 1 for i in range(n)]
+    docs = [(ids[i], b"doc-%d" % ids[i], rows[i].tobytes()) for i in range(n)]
+    extra = [sw.span(9000, str(ids[5]), [(0, b"rewritten"), (1, rows[6].tobytes())])]
+    path = tmp_path / "coll.dat"
+    sw.collection_file(path, metric, dim, bits, docs, extra_spans=extra)
+    rows = rows.copy()
+    rows[5] = rows[6]
+    order = orc.sorted_id_order(ids)
+    visit_rows = rows[[int(i) for i in order]]
+    c = Collection.from_spanfile(path)
+    assert (c.DimensionCount, c.Quantization, c.DistanceMethod) == (dim, bits, metric)
+    assert c.GetDocumentCount() == n
+    for q in orc.synth_vectors(42, 0, 3, dim):
+        res = c.Search(SearchArgs(Vector=q, K=7, Precision="exact"))
+        o_rows, o_dist, _ = orc.search_exact(visit_rows, dim, bits, metric, q, k=7)
+        assert [r.ID for r in res.Results] == [ids[int(order[int(x)])] for x in o_rows]
+        assert [r.Distance for r in res.Results] == list(o_dist)
+        assert res.PercentSearched == 100.0
+    hit = c.Search(SearchArgs(Vector=orc.decode_vector(rows[5], dim, bits), K=2)).Results
+    assert {r.ID for r in hit} >= {ids[5]} or {r.ID for r in hit} >= {ids[6]}
+    assert any(r.Metadata == b"rewritten" for r in c.Search(SearchArgs(Offset=0, Limit=n)).Results)
+    c.Close()

@@ -46,8 +46,8 @@ def test_synth_matches_oracle(oracle):
     assert int(splitmix64(np.array([12345], dtype=np.uint64))[0]) == oracle.splitmix64(12345)
 
 
-def _declared_symbols():
-    hdr = open(os.path.join(ROOT, "include", "syzgy_scan.h")).read()
+def _declared_symbols(header="syzgy_scan.h"):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     return sorted(set(re.findall(r"\b(szg_[a-z0-9_]+)\s*\(", hdr)))
 
@@ -61,6 +61,10 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), "libsyzgy_scan.so does not export %s" % name
     assert sorted(_lib.EXPORTS) == declared
     assert L.szg_abi_version() == 1
+    pager = _declared_symbols("syzgy_pager.h")
+    assert sorted(_lib.PAGER_EXPORTS) == pager
+    for name in pager:
+        assert hasattr(L, name), "libsyzgy_scan.so does not export %s" % name
 
 
 def test_error_paths_without_gpu_work():
