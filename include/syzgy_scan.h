@@ -78,6 +78,13 @@ int szg_index_load(szg_index *ix, const uint8_t *rows, uint64_t n_rows);
 /* AddDocument (collection.go:427-457): rows go to the end of the visit order. */
 int szg_index_append(szg_index *ix, const uint8_t *rows, uint64_t n_rows);
 
+/*
+ * AddDocument for a block of float64 vectors (bulk ingest): quantize + pack on the
+ * device exactly as encodeDocument / quantize do (collection.go:713-743,
+ * quantization.go:5-23), rows go to the end of the visit order.
+ */
+int szg_index_append_f64(szg_index *ix, const double *vectors, uint64_t n_rows);
+
 /* AddDocument on an existing id rewrites the record: replace one row in place. */
 int szg_index_overwrite(szg_index *ix, uint64_t row, const uint8_t *row_bytes);
 
@@ -116,6 +123,15 @@ int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
 int szg_search_radius(szg_index *ix, const double *query, double radius,
                       const uint64_t *allow_bits, uint64_t *out_rows, double *out_dist,
                       uint64_t capacity, uint64_t *out_total);
+
+/*
+ * The reference's float64 distance (c.distance, collection.go:596, :812-832) from
+ * one query to each listed row, bit-identical to the reference: the gather-by-row
+ * primitive for re-ranking candidates of the LSH path (lshtree.go:283-351 calls
+ * consider() per candidate id) or any other candidate generator.
+ */
+int szg_distances(szg_index *ix, const double *query, const uint64_t *rows, uint64_t n_rows,
+                  double *out_dist);
 
 /*
  * Cross-shard result assembly for one-process-per-GPU sharding (host code, no

@@ -128,7 +128,7 @@ class Collection:
             for j, i in enumerate(ids):
                 self.AddDocument(i, V[j], metadatas[j] if metadatas else b"")
             return
-        self._index.append(codec.encode_rows(V, self.Quantization))
+        self._index.append_vectors(V)  # quantize + pack on the device (szg_index_append_f64)
         for j, i in enumerate(ids):
             self._row_of[i] = len(self._id_of)
             self._id_of.append(i)

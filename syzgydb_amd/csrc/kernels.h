@@ -125,9 +125,10 @@ hipError_t launch_rerank(int qbits, int metric, const uint8_t *rows, uint32_t pi
 hipError_t launch_repack(int qbits, const uint8_t *src, uint32_t row_bytes, uint8_t *dst,
                          uint32_t pitch, uint64_t n_rows, int to_reference, hipStream_t stream);
 
-// Synthetic corpus directly in the resident layout (see szg_index_synth).
+// Rows directly in the resident layout: synthetic (src == nullptr, see
+// szg_index_synth) or quantized + packed from float64 vectors on the device.
 hipError_t launch_synth(int qbits, uint8_t *dst, uint32_t pitch, int dim, uint64_t n_rows,
-                        uint64_t seed, uint64_t first_row, hipStream_t stream);
+                        uint64_t seed, uint64_t first_row, const double *src, hipStream_t stream);
 
 // device float64 primitive probe (tests)
 hipError_t launch_f64_probe(int op, const double *a, const double *b, double *out, uint64_t n,

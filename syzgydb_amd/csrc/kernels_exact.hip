@@ -240,10 +240,12 @@ __device__ __forceinline__ uint64_t quantize(double value)
     return (uint64_t)round(q);  // half away from zero, like math.Round
 }
 
-// one thread per 16-byte piece of the resident row
+// one thread per 16-byte piece of the resident row.  src == nullptr: synthetic
+// values; otherwise row-major float64 vectors (bulk AddDocument: quantize + pack on
+// the device exactly as encodeDocument does, collection.go:713-743)
 template <int QBITS>
 __global__ void synth_kernel(uint8_t *dst, uint32_t pitch, int dim, uint64_t n_rows,
-                             uint64_t seed, uint64_t first_row)
+                             uint64_t seed, uint64_t first_row, const double *src)
 {
     constexpr int E = 128 / QBITS;
     const uint32_t r16 = pitch / 16;
@@ -257,7 +259,8 @@ __global__ void synth_kernel(uint8_t *dst, uint32_t pitch, int dim, uint64_t n_r
     for (int i = 0; i < E; i++) {
         const int e = (int)j * E + i;
         if (e >= dim) break;
-        const uint64_t q = quantize<QBITS>(synth_value(seed, ebase + (uint64_t)e));
+        const double val = src ? src[row * (uint64_t)dim + (uint64_t)e] : synth_value(seed, ebase + (uint64_t)e);
+        const uint64_t q = quantize<QBITS>(val);
         if (QBITS == 64) {
             w[2 * i] = (uint32_t)q;
             w[2 * i + 1] = (uint32_t)(q >> 32);
@@ -398,18 +401,18 @@ hipError_t launch_repack(int qbits, const uint8_t *src, uint32_t row_bytes, uint
 }
 
 hipError_t launch_synth(int qbits, uint8_t *dst, uint32_t pitch, int dim, uint64_t n_rows,
-                        uint64_t seed, uint64_t first_row, hipStream_t stream)
+                        uint64_t seed, uint64_t first_row, const double *src, hipStream_t stream)
 {
     if (n_rows == 0) return hipSuccess;
     const uint64_t total = n_rows * (pitch / 16);
     const uint64_t grid = (total + 255) / 256;
     const dim3 g((unsigned)grid), b(256);
     switch (qbits) {
-    case 4: hipLaunchKernelGGL(synth_kernel<4>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row); break;
-    case 8: hipLaunchKernelGGL(synth_kernel<8>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row); break;
-    case 16: hipLaunchKernelGGL(synth_kernel<16>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row); break;
-    case 32: hipLaunchKernelGGL(synth_kernel<32>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row); break;
-    case 64: hipLaunchKernelGGL(synth_kernel<64>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row); break;
+    case 4: hipLaunchKernelGGL(synth_kernel<4>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row, src); break;
+    case 8: hipLaunchKernelGGL(synth_kernel<8>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row, src); break;
+    case 16: hipLaunchKernelGGL(synth_kernel<16>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row, src); break;
+    case 32: hipLaunchKernelGGL(synth_kernel<32>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row, src); break;
+    case 64: hipLaunchKernelGGL(synth_kernel<64>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row, src); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

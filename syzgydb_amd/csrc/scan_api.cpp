@@ -1335,7 +1335,7 @@ int szg_index_synth(szg_index *ix, uint64_t n_rows, uint64_t seed, uint64_t firs
         Shard *sh = ix->shards[s];
         HIPCHK(hipSetDevice(sh->device));
         HIPCHK(szg::launch_synth(ix->bits, sh->rows, ix->pitch, ix->dim, counts[s], seed,
-                                 first_row + sh->first, nullptr));
+                                 first_row + sh->first, nullptr, nullptr));
         HIPCHK(hipDeviceSynchronize());
         sh->n_rows = counts[s];
         sh->n_live = counts[s];
@@ -1364,6 +1364,94 @@ int szg_index_append(szg_index *ix, const uint8_t *rows, uint64_t n_rows)
     if (rc) return rc;
     sh->n_rows += n_rows;
     sh->n_live += n_rows;
+    return SZG_OK;
+}
+
+// AddDocument for a block of float64 vectors: quantize + pack on the device
+int szg_index_append_f64(szg_index *ix, const double *vectors, uint64_t n_rows)
+{
+    if (!ix || (!vectors && n_rows)) return fail(SZG_E_INVALID, "null argument");
+    if (n_rows == 0) return SZG_OK;
+    Shard *sh = ix->shards.back();
+    HIPCHK(hipSetDevice(sh->device));
+    HIPCHK(hipDeviceSynchronize());
+    if (sh->n_rows == 0) {
+        uint64_t first = 0;
+        for (Shard *o : ix->shards)
+            if (o != sh) first += o->n_rows;
+        sh->first = first;
+    }
+    int rc = shard_reserve(ix, sh, sh->n_rows + n_rows);
+    if (rc) return rc;
+    const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / ((uint64_t)ix->dim * 8));
+    double *stage = nullptr;
+    HIPCHK(hipMalloc((void **)&stage, std::min(chunk, n_rows) * (uint64_t)ix->dim * 8));
+    for (uint64_t off = 0; off < n_rows && rc == SZG_OK; off += chunk) {
+        const uint64_t m = std::min(chunk, n_rows - off);
+        hipError_t e = hipMemcpy(stage, vectors + off * (uint64_t)ix->dim, m * (uint64_t)ix->dim * 8,
+                                 hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = szg::launch_synth(ix->bits, sh->rows + (sh->n_rows + off) * ix->pitch, ix->pitch, ix->dim,
+                                  m, 0, 0, stage, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "append_f64", e);
+    }
+    (void)hipFree(stage);
+    if (rc) return rc;
+    rc = shard_set_live(sh, sh->n_rows, sh->n_rows + n_rows);
+    if (rc) return rc;
+    sh->n_rows += n_rows;
+    sh->n_live += n_rows;
+    return SZG_OK;
+}
+
+// The reference's float64 distance from one query to each listed row
+int szg_distances(szg_index *ix, const double *query, const uint64_t *rows, uint64_t n, double *out_dist)
+{
+    if (!ix || !query || (!rows && n) || (!out_dist && n)) return fail(SZG_E_INVALID, "null argument");
+    if (n == 0) return SZG_OK;
+    const uint64_t total = szg_index_rows(ix);
+    for (uint64_t i = 0; i < n; i++)
+        if (rows[i] < ix->row_base || rows[i] - ix->row_base >= total) return fail(SZG_E_RANGE, "row out of range");
+    for (Shard *sh : ix->shards) {
+        if (sh->n_rows == 0) continue;
+        std::vector<uint64_t> cands;
+        std::vector<uint64_t> where;
+        for (uint64_t i = 0; i < n; i++) {
+            const uint64_t r = rows[i] - ix->row_base;
+            if (r >= sh->first && r < sh->first + sh->n_rows) {
+                cands.push_back(r - sh->first);  // key bits 0, row in the low word
+                where.push_back(i);
+            }
+        }
+        if (cands.empty()) continue;
+        Ctx *c = ctx_acquire(sh);
+        int rc = SZG_OK;
+        auto body = [&]() -> int {
+            HIPCHK(hipSetDevice(sh->device));
+            memcpy(c->h_q64, query, sizeof(double) * ix->dim);
+            HIPCHK(hipMemcpyAsync(c->d_q64, c->h_q64, sizeof(double) * ix->dim, hipMemcpyHostToDevice,
+                                  c->stream));
+            int r2 = ensure_dev(&c->d_collect, &c->collect_cap, cands.size());
+            if (r2) return r2;
+            r2 = ensure_dev(&c->d_out, &c->d_out_cap, cands.size());
+            if (r2) return r2;
+            r2 = ensure_host(&c->h_out, &c->h_out_cap, cands.size());
+            if (r2) return r2;
+            HIPCHK(hipMemcpyAsync(c->d_collect, cands.data(), cands.size() * sizeof(uint64_t),
+                                  hipMemcpyHostToDevice, c->stream));
+            HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64,
+                                      c->d_collect, nullptr, (uint32_t)cands.size(), 1, c->d_out, c->stream));
+            HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * cands.size(),
+                                  hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            for (size_t i = 0; i < cands.size(); i++) out_dist[where[i]] = c->h_out[i].dist;
+            return SZG_OK;
+        };
+        rc = body();
+        ctx_release(sh, c);
+        if (rc) return rc;
+    }
     return SZG_OK;
 }
 

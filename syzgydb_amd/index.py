@@ -84,6 +84,23 @@ class ScanIndex:
         a, n = self._rows_arg(rows)
         check(self._L.szg_index_append(self._h, _u8(a) if n else None, n), "szg_index_append")
 
+    def append_vectors(self, vectors):
+        """Bulk AddDocument from float64 vectors: quantized and packed on the device."""
+        v = np.ascontiguousarray(vectors, dtype=np.float64).reshape(-1, self.dim)
+        check(self._L.szg_index_append_f64(self._h, _f64(v) if v.size else None, v.shape[0]),
+              "szg_index_append_f64")
+
+    def distances(self, query, rows):
+        """The reference's float64 distance from `query` to each listed row."""
+        q = np.ascontiguousarray(query, dtype=np.float64).reshape(-1)
+        if q.size != self.dim:
+            raise ValueError("query length %d != dimension %d" % (q.size, self.dim))
+        r = np.ascontiguousarray(rows, dtype=np.uint64).reshape(-1)
+        out = np.zeros(r.size, dtype=np.float64)
+        check(self._L.szg_distances(self._h, _f64(q), _u64(r) if r.size else None, r.size,
+                                    _f64(out) if r.size else None), "szg_distances")
+        return out
+
     def overwrite(self, row, row_bytes):
         a, n = self._rows_arg(row_bytes)
         if n != 1:

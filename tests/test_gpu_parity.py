@@ -161,3 +161,35 @@ def test_escalation_path_is_exact():
         assert ix.stats()["escalations"] == 1
         o_rows, o_dist, _ = orc.search_exact(rows, 24, 8, SZG_COSINE, q, k=10)
         assert_same(r[0, : c[0]], d[0, : c[0]], o_rows, o_dist)
+
+
+@pytest.mark.parametrize("bits", [4, 8, 16, 32, 64])
+def test_device_side_quantize_and_pack(bits):
+    """szg_index_append_f64 == encodeDocument on the host (collection.go:713-743)."""
+    dim, n = 19, 400
+    rng = np.random.default_rng(bits)
+    V = rng.uniform(-1.4, 1.4, (n, dim))
+    V[0, :5] = [0.0, 1.0, -1.0, 0.5, -0.5]
+    V[1, :3] = [np.nextafter(0.5, 0) * 2 / 15 - 1, 1e-300, -1e-300]
+    with ScanIndex(dim, bits, SZG_EUCLIDEAN) as ix:
+        ix.append_vectors(V[:150])
+        ix.append_vectors(V[150:])
+        assert ix.rows == n
+        assert (ix.read_rows(0, n) == orc.encode_rows(V, bits)).all()
+
+
+@pytest.mark.parametrize("bits,metric", [(4, 1), (8, 0), (32, 1), (64, 0)])
+def test_distances_for_row_lists(bits, metric):
+    """szg_distances: the gather-by-row re-rank primitive, bit-equal to the oracle."""
+    dim, n = 48, 3000
+    rows = orc.synth_rows(17, 0, n, dim, bits)
+    q = orc.synth_vectors(18, 0, 1, dim)[0]
+    want = orc.all_distances(rows, dim, bits, metric, q)
+    pick = np.array([0, 2999, 17, 17, 1500, 64, 63, 65], dtype=np.uint64)
+    for devs in (None, [0, 0]):
+        with ScanIndex(dim, bits, metric, devices=devs) as ix:
+            ix.load(rows)
+            got = ix.distances(q, pick)
+            assert (got == want[pick.astype(int)]).all()
+            with pytest.raises(Exception):
+                ix.distances(q, [n])
