@@ -37,6 +37,7 @@ struct RowMap {
     int P;    // pieces per lane per row (L*P >= r16)
     int gpw;  // rows (lane groups) per wave iteration
     int pow2; // L is a power of two (groups are aligned: DPP reductions apply)
+    int dense; // L*P == r16 and gpw*L == 64: every lane always has a piece of a row
 };
 
 // Bytes of one prepared query as the scan stages it in LDS: float32 (float64 for

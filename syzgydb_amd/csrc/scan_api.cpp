@@ -230,7 +230,7 @@ namespace {
 
 szg::RowMap choose_map(int r16)
 {   // groups of L lanes per row, P pieces per lane: maximise lane utilisation
-    szg::RowMap best{r16, 64, (r16 + 63) / 64, 1, 1};
+    szg::RowMap best{r16, 64, (r16 + 63) / 64, 1, 1, 0};
     double best_util = -1;
     const int pmax = std::max(1, (r16 + 63) / 64 + 8);
     for (int P = 1; P <= pmax; P++) {
@@ -240,9 +240,11 @@ szg::RowMap choose_map(int r16)
         const double util = (double)gpw * r16 / (64.0 * P);
         if (util > best_util + 1e-9) {
             best_util = util;
-            best = szg::RowMap{r16, L, P, gpw, (L & (L - 1)) == 0 ? 1 : 0};
+            best = szg::RowMap{r16, L, P, gpw, (L & (L - 1)) == 0 ? 1 : 0,
+                               (L * P == r16 && gpw * L == 64) ? 1 : 0};
         }
     }
+    best.dense = (best.L * best.P == r16 && best.gpw * best.L == 64) ? 1 : 0;
     return best;
 }
 
@@ -1677,8 +1679,8 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
         if (value < 1 || value > 16) return fail(SZG_E_INVALID, "blocks_per_cu out of range");
         ix->blocks_per_cu = (int)value;
     } else if (n == "block_threads") {
-        if (value != 64 && value != 128 && value != 256 && value != 512)
-            return fail(SZG_E_INVALID, "block_threads must be 64/128/256/512");
+        if (value != 64 && value != 128 && value != 256)
+            return fail(SZG_E_INVALID, "block_threads must be 64/128/256");
         ix->block_threads = (int)value;
     } else if (n == "query_batch") {
         if (value < 1 || value > kMaxBatch) return fail(SZG_E_INVALID, "query_batch out of range");
