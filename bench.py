@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--rows", type=int, default=0, help="override the workload's row count")
-    ap.add_argument("--exchange-every", type=int, default=64,
+    ap.add_argument("--exchange-every", type=int, default=256,
                     help="N>1: queries per all-gather micro-batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip cpu_baseline and the recall check")

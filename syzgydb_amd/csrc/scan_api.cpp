@@ -229,19 +229,27 @@ struct szg_index {
 namespace {
 
 szg::RowMap choose_map(int r16)
-{   // groups of L lanes per row, P pieces per lane: maximise lane utilisation
+{   // groups of L lanes per row, P pieces per lane: maximise lane utilisation, with a
+    // bonus for power-of-two groups (16-lane-row aligned: the per-row reduction is DPP
+    // instead of LDS-crossbar shuffles, which matters when rows are short)
     szg::RowMap best{r16, 64, (r16 + 63) / 64, 1, 1, 0};
-    double best_util = -1;
+    double best_score = -1;
     const int pmax = std::max(1, (r16 + 63) / 64 + 8);
     for (int P = 1; P <= pmax; P++) {
-        const int L = (r16 + P - 1) / P;
-        if (L > 64) continue;
-        const int gpw = 64 / L;
-        const double util = (double)gpw * r16 / (64.0 * P);
-        if (util > best_util + 1e-9) {
-            best_util = util;
-            best = szg::RowMap{r16, L, P, gpw, (L & (L - 1)) == 0 ? 1 : 0,
-                               (L * P == r16 && gpw * L == 64) ? 1 : 0};
+        const int need = (r16 + P - 1) / P;  // lanes a row needs at P pieces per lane
+        if (need > 64) continue;
+        int cand[2] = {need, 1};
+        while (cand[1] < need) cand[1] <<= 1;  // next power of two
+        for (int L : cand) {
+            if (L > 64) continue;
+            const int gpw = 64 / L;
+            const double util = (double)gpw * r16 / (64.0 * P);
+            const bool pow2 = (L & (L - 1)) == 0;
+            const double score = util * (pow2 ? 1.3 : 1.0);
+            if (score > best_score + 1e-9) {
+                best_score = score;
+                best = szg::RowMap{r16, L, P, gpw, pow2 ? 1 : 0, 0};
+            }
         }
     }
     best.dense = (best.L * best.P == r16 && best.gpw * best.L == 64) ? 1 : 0;
