@@ -85,7 +85,9 @@ int szg_index_append(szg_index *ix, const uint8_t *rows, uint64_t n_rows);
  */
 int szg_index_append_f64(szg_index *ix, const double *vectors, uint64_t n_rows);
 
-/* AddDocument on an existing id rewrites the record: replace one row in place. */
+/* AddDocument on an existing id rewrites the record: replace one row in place
+ * (from packed bytes, or from a float64 vector encoded on the device). */
+int szg_index_overwrite_f64(szg_index *ix, uint64_t row, const double *vector);
 int szg_index_overwrite(szg_index *ix, uint64_t row, const uint8_t *row_bytes);
 
 /* removeDocument (collection.go:511-521): the row is skipped by every later scan. */

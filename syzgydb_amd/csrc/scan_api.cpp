@@ -1415,6 +1415,27 @@ int szg_index_append_f64(szg_index *ix, const double *vectors, uint64_t n_rows)
     return SZG_OK;
 }
 
+// AddDocument on an existing id from a float64 vector: re-encode one row in place
+int szg_index_overwrite_f64(szg_index *ix, uint64_t row, const double *vector)
+{
+    if (!ix || !vector) return fail(SZG_E_INVALID, "null argument");
+    uint64_t local;
+    Shard *sh = shard_of(ix, row, &local);
+    if (!sh) return fail(SZG_E_RANGE, "row out of range");
+    HIPCHK(hipSetDevice(sh->device));
+    HIPCHK(hipDeviceSynchronize());
+    double *stage = nullptr;
+    HIPCHK(hipMalloc((void **)&stage, (size_t)ix->dim * 8));
+    hipError_t e = hipMemcpy(stage, vector, (size_t)ix->dim * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = szg::launch_synth(ix->bits, sh->rows + local * ix->pitch, ix->pitch, ix->dim, 1, 0, 0, stage,
+                              nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(stage);
+    if (e != hipSuccess) return fail(SZG_E_DEVICE, "overwrite_f64", e);
+    return SZG_OK;
+}
+
 // The reference's float64 distance from one query to each listed row
 int szg_distances(szg_index *ix, const double *query, const uint64_t *rows, uint64_t n, double *out_dist)
 {
