@@ -229,9 +229,16 @@ struct szg_index {
 namespace {
 
 szg::RowMap choose_map(int r16)
-{   // groups of L lanes per row, P pieces per lane: maximise lane utilisation, with a
-    // bonus for power-of-two groups (16-lane-row aligned: the per-row reduction is DPP
-    // instead of LDS-crossbar shuffles, which matters when rows are short)
+{   // Groups of L lanes per row, P pieces per lane.
+    // 1) Exact power-of-two groups (L*P == r16): every lane always holds a piece (the
+    //    kernel's dense phase), reductions are DPP.  The SMALLEST such L >= 8 wins: a
+    //    group still reads whole 128-byte lines per load, and the fewer lanes share a
+    //    row, the more pieces each walks between two row finishes (measured on
+    //    1M x 768 f32: L=8 6.80 TB/s, L=16 6.73, L=32 6.47, L=64 6.44; 8-bit: L=8 5.9 vs
+    //    L=16 5.75 vs L=32 3.8).  L=4 (64-byte segments) only when nothing wider is exact.
+    for (int L : {8, 16, 32, 64, 4})
+        if (r16 % L == 0) return szg::RowMap{r16, L, r16 / L, 64 / L, 1, 1};
+    // 2) Otherwise maximise lane utilisation, with a bonus for power-of-two groups.
     szg::RowMap best{r16, 64, (r16 + 63) / 64, 1, 1, 0};
     double best_score = -1;
     const int pmax = std::max(1, (r16 + 63) / 64 + 8);
@@ -1727,6 +1734,12 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
                 sh->free_ctx.pop_back();
             }
         }
+    } else if (n == "lanes_per_row") {
+        // tuning hook: force the lane-group width L (power of two, L*P >= r16)
+        const int L = (int)value, r16 = ix->map.r16;
+        if (L < 1 || L > 64 || (L & (L - 1))) return fail(SZG_E_INVALID, "lanes_per_row must be a power of two <= 64");
+        const int P = (r16 + L - 1) / L;
+        ix->map = szg::RowMap{r16, L, P, 64 / L, 1, (L * P == r16) ? 1 : 0};
     } else if (n == "multi_query") {
         ix->multi_query = value != 0;
     } else if (n == "mq_min") {
