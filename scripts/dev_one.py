@@ -6,6 +6,7 @@ from syzgydb_amd.synth import synth_vectors
 n, dim, bits, metric, k, nq = [int(x) for x in sys.argv[1:7]]
 with ScanIndex(dim, bits, metric, devices=[0]) as ix:
     ix.synth(n, 1234)
+    ix.set_option('multi_query', int(os.environ.get('SZG_MQ', '0')))
     q = synth_vectors(99, 0, nq, dim)
     r, d, c = ix.search_topk(q, k)
     print("done", r[0][:3])
