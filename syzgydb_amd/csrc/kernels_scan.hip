@@ -16,6 +16,13 @@
 #include "kernels.h"
 #include "device_lists.h"
 
+// Built six times: -DSZG_QBITS=4/8/16/32/64 each carry the scan kernels of one
+// quantization (80 instantiations in one unit took minutes to compile); the unit
+// without it (0) has the list-merge kernels and the dispatcher.
+#ifndef SZG_QBITS
+#define SZG_QBITS 0
+#endif
+
 namespace szg {
 
 namespace {
@@ -41,16 +48,18 @@ struct Traits<64> {
 
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 
-// streaming 16-byte load of one piece of a packed row (read once per scan)
+// streaming 16-byte load of one piece of a packed row (read once per scan).
+// NT (non-temporal): the corpus is far larger than L2 + Infinity Cache and each
+// byte is used once per scan -- measured 6.18 vs 5.66 TB/s on the 1M x 768 f32
+// scan.  Only when a lane group reads whole 128-byte lines per load: with
+// narrower groups (L < 8, 64-byte segments) the neighbouring piece needs the
+// same line a moment later and nt evicts it first (4-bit 384-dim rows: 4.6 TB/s
+// with nt, 5.5 plain).
+template <bool NT>
 __device__ __forceinline__ u32x4 load_piece(const uint8_t *p)
 {
-#ifdef SZG_PLAIN_LOADS
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
     return *reinterpret_cast<const u32x4 *>(p);
-#else
-    // non-temporal: the corpus is far larger than L2 + Infinity Cache and each byte
-    // is used once per scan; measured 6.18 vs 5.66 TB/s on the 1M x 768 fp32 scan
-    return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-#endif
 }
 
 // value of the lane a DPP control pairs this lane with (quad_perm xor 1 / xor 2,
@@ -248,13 +257,16 @@ struct RowAcc<8, METRIC> {
     }
     __device__ __forceinline__ float finish(const ScanArgs &a, const Grp &g, bool lead)
     {
-        double dot = 2.0 * (16384.0 * (double)H + 128.0 * (double)M + (double)L);
+        // per-lane sums are exact integers below 2^24; combining the planes in float32
+        // costs a few roundings (bounded in key_eps) and saves the float64 reduction
+        float dot = fmaf(16384.0f, (float)H, fmaf(128.0f, (float)M, (float)L));
         int nrm = 4 * (SQ + SV);
-        dot = grp_sum(dot, g) + a.qconst;
+        dot = grp_sum(dot, g);
         nrm = grp_sum(nrm, g);
-        const double norm = (double)nrm + a.norm_bias;  // padding removed, exact
-        if (METRIC == kCosine) return -(float)(dot * a.qscale) * __frsqrt_rn((float)norm);
-        return (float)(a.qnorm2 - 2.0 * a.qscale * dot + norm);
+        const float norm = (float)nrm + (float)a.norm_bias;
+        const float d2 = fmaf(2.0f, dot, (float)a.qconst);  // sum Q n
+        if (METRIC == kCosine) return -(d2 * (float)a.qscale) * __frsqrt_rn(norm);
+        return fmaf(-2.0f * (float)a.qscale, d2, (float)a.qnorm2 + norm);
     }
 };
 
@@ -289,20 +301,21 @@ struct RowAcc<4, METRIC> {
     }
     __device__ __forceinline__ float finish(const ScanArgs &a, const Grp &g, bool lead)
     {
-        double dot = 2.0 * ((double)D0 + 16.0 * (double)D1 + 256.0 * (double)D2 + 4096.0 * (double)D3 +
-                            65536.0 * (double)D4);
+        float dot = fmaf(65536.0f, (float)D4,
+                         fmaf(4096.0f, (float)D3, fmaf(256.0f, (float)D2, fmaf(16.0f, (float)D1, (float)D0))));
         int nrm = 4 * (SQ + SV);
-        dot = grp_sum(dot, g) + a.qconst;
+        dot = grp_sum(dot, g);
         nrm = grp_sum(nrm, g);
-        const double norm = (double)nrm + a.norm_bias;
-        if (METRIC == kCosine) return -(float)(dot * a.qscale) * __frsqrt_rn((float)norm);
-        return (float)(a.qnorm2 - 2.0 * a.qscale * dot + norm);
+        const float norm = (float)nrm + (float)a.norm_bias;
+        const float d2 = fmaf(2.0f, dot, (float)a.qconst);
+        if (METRIC == kCosine) return -(d2 * (float)a.qscale) * __frsqrt_rn(norm);
+        return fmaf(-2.0f * (float)a.qscale, d2, (float)a.qnorm2 + norm);
     }
 };
 
 // ---- the scan ---------------------------------------------------------------
 
-template <int QBITS, int METRIC, int D, bool COLLECT, bool MASKED>
+template <int QBITS, int METRIC, int D, bool COLLECT, bool MASKED, bool NT>
 __global__ __launch_bounds__(256, 4) void scan_kernel(const ScanArgs a)
 {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -441,7 +454,7 @@ __global__ __launch_bounds__(256, 4) void scan_kernel(const ScanArgs a)
         int ip = 0, cp = 0, jc = lig;
 #define SZG_DN_ISSUE(u)                                                                 \
     {                                                                                   \
-        ring[u] = load_piece(iptr);                                                     \
+        ring[u] = load_piece<NT>(iptr);                                                     \
         if (++ip == P) {                                                                \
             ip = 0;                                                                     \
             iptr += row_jump;                                                           \
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(256, 4) void scan_kernel(const ScanArgs a)
     {                                                                                   \
         const int j_ = ip * L + lig;                                                    \
         const bool ok_ = ivalid && j_ < r16;                                            \
-        ring[u] = load_piece(ok_ ? irp + (size_t)j_ * 16 : a.rows);                     \
+        ring[u] = load_piece<NT>(ok_ ? irp + (size_t)j_ * 16 : a.rows);                     \
         okmask = (okmask & ~(1u << (u))) | ((uint32_t)ok_ << (u));                      \
         if (++ip == P) {                                                                \
             ip = 0;                                                                     \
@@ -534,6 +547,7 @@ __global__ __launch_bounds__(256, 4) void scan_kernel(const ScanArgs a)
     }  // for qi
 }
 
+#if SZG_QBITS == 0
 // ---- merge of sorted candidate lists ----------------------------------------
 
 // minimum of a 64-bit value over the wave, returned in every lane: four DPP
@@ -632,23 +646,30 @@ __global__ __launch_bounds__(1024) void merge_kernel(const uint64_t *in, int n_l
     }
 }
 
+#endif  // SZG_QBITS == 0
+
+#if SZG_QBITS != 0
+template <int QBITS, int METRIC, bool COLLECT, bool MASKED>
+hipError_t launch_scan_qmcm(const ScanArgs &a, int grid, int block, size_t lds, hipStream_t stream)
+{
+    const dim3 g(grid), b(block);
+    if (a.map.L >= 8)  // whole lines per group per load: stream past the caches
+        hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, COLLECT, MASKED, true>), g, b, lds, stream, a);
+    else
+        hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, COLLECT, MASKED, false>), g, b, lds, stream, a);
+    return hipGetLastError();
+}
+
 template <int QBITS, int METRIC>
 hipError_t launch_scan_qm(const ScanArgs &a, int grid, int block, size_t lds, hipStream_t stream)
 {
     const bool masked = a.live_bits != nullptr || a.allow_bits != nullptr;
-    const dim3 g(grid), b(block);
     if (a.collect) {
-        if (masked)
-            hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, true, true>), g, b, lds, stream, a);
-        else
-            hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, true, false>), g, b, lds, stream, a);
-    } else {
-        if (masked)
-            hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, false, true>), g, b, lds, stream, a);
-        else
-            hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, false, false>), g, b, lds, stream, a);
+        if (masked) return launch_scan_qmcm<QBITS, METRIC, true, true>(a, grid, block, lds, stream);
+        return launch_scan_qmcm<QBITS, METRIC, true, false>(a, grid, block, lds, stream);
     }
-    return hipGetLastError();
+    if (masked) return launch_scan_qmcm<QBITS, METRIC, false, true>(a, grid, block, lds, stream);
+    return launch_scan_qmcm<QBITS, METRIC, false, false>(a, grid, block, lds, stream);
 }
 
 template <int QBITS>
@@ -659,7 +680,25 @@ hipError_t launch_scan_q(int metric, const ScanArgs &a, int grid, int block, siz
     return launch_scan_qm<QBITS, kEuclidean>(a, grid, block, lds, stream);
 }
 
+#endif  // SZG_QBITS != 0
+
 }  // namespace
+
+#if SZG_QBITS != 0
+// this translation unit carries the scan kernels of ONE quantization
+#define SZG_CAT2(a, b) a##b
+#define SZG_CAT(a, b) SZG_CAT2(a, b)
+hipError_t SZG_CAT(launch_scan_q, SZG_QBITS)(int metric, const ScanArgs &a, int grid, int block, size_t lds,
+                                             hipStream_t stream)
+{
+    return launch_scan_q<SZG_QBITS>(metric, a, grid, block, lds, stream);
+}
+#else
+hipError_t launch_scan_q4(int, const ScanArgs &, int, int, size_t, hipStream_t);
+hipError_t launch_scan_q8(int, const ScanArgs &, int, int, size_t, hipStream_t);
+hipError_t launch_scan_q16(int, const ScanArgs &, int, int, size_t, hipStream_t);
+hipError_t launch_scan_q32(int, const ScanArgs &, int, int, size_t, hipStream_t);
+hipError_t launch_scan_q64(int, const ScanArgs &, int, int, size_t, hipStream_t);
 
 size_t scan_lds_bytes(int qbits, const RowMap &m, int kp, int block)
 {
@@ -671,11 +710,11 @@ hipError_t launch_scan(int qbits, int metric, const ScanArgs &a, int grid, int b
 {
     const size_t lds = scan_lds_bytes(qbits, a.map, a.collect ? 0 : a.kp, block);
     switch (qbits) {
-    case 4: return launch_scan_q<4>(metric, a, grid, block, lds, stream);
-    case 8: return launch_scan_q<8>(metric, a, grid, block, lds, stream);
-    case 16: return launch_scan_q<16>(metric, a, grid, block, lds, stream);
-    case 32: return launch_scan_q<32>(metric, a, grid, block, lds, stream);
-    case 64: return launch_scan_q<64>(metric, a, grid, block, lds, stream);
+    case 4: return launch_scan_q4(metric, a, grid, block, lds, stream);
+    case 8: return launch_scan_q8(metric, a, grid, block, lds, stream);
+    case 16: return launch_scan_q16(metric, a, grid, block, lds, stream);
+    case 32: return launch_scan_q32(metric, a, grid, block, lds, stream);
+    case 64: return launch_scan_q64(metric, a, grid, block, lds, stream);
     default: return hipErrorInvalidValue;
     }
 }
@@ -702,5 +741,7 @@ hipError_t launch_merge(const uint64_t *in, int n_lists, int kp, int n_queries, 
     hipLaunchKernelGGL(merge_kernel, grid, dim3(block), lds, stream, in, n_lists, kp, fan, out);
     return hipGetLastError();
 }
+
+#endif  // SZG_QBITS
 
 }  // namespace szg

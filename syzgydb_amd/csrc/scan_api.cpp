@@ -355,11 +355,19 @@ double key_eps(const szg_index *ix, double key, const QMeta &m)
 {
     const double k = std::fabs(key);
     if (ix->bits == 8 || ix->bits == 4) {
-        // integer paths: the row sums are exact; what is left is the query's
-        // quantization (|v_i - qscale*Q_i| <= qscale/2) and a few float roundings
+        // integer paths: the per-lane sums are exact.  What is left is (a) the query's
+        // quantization, |v_i - qscale*Q_i| <= qscale/2, and (b) the float32 roundings of
+        // the row finish: the plane combination and the reduction over the lanes act on
+        // terms bounded by sum |Q_i||v'_i| <= Qmax*V*dim (V = 128 resp. 8), i.e. an
+        // absolute error <= 16*2^-24 * qscale*Qmax*V*dim in units of sum v n.
         const double M = (double)((1u << ix->bits) - 1u);
-        if (ix->metric == SZG_COSINE) return 0.5 * m.qscale * std::sqrt((double)ix->dim) + 0x1p-21;
-        return m.qscale * M * (double)ix->dim + 0x1p-22 * k + 1e-30;
+        const double V = ix->bits == 8 ? 128.0 : 8.0;
+        const double Qmax = ix->bits == 8 ? 1000000.0 : 480000.0;
+        const double fl = 16.0 * 0x1p-24 * m.qscale * Qmax * V * (double)ix->dim;
+        if (ix->metric == SZG_COSINE)  // divided by |n| >= sqrt(dim) (every n is odd)
+            return 0.5 * m.qscale * std::sqrt((double)ix->dim) + fl / std::sqrt((double)ix->dim) + 0x1p-21;
+        return m.qscale * M * (double)ix->dim + 2.0 * fl +
+               0x1p-21 * (k + m.qnorm2 + M * M * (double)ix->dim) + 1e-30;
     }
     const double u = ix->bits == 64 ? 0x1p-53 : 0x1p-24;
     const double n = (double)ix->dim + 16.0;
