@@ -230,7 +230,9 @@ def main():
     # ---- shared multi-query sweep (MFMA), 32-bit cosine only, N=1 -----------------
     if world == 1 and bits == 32 and metric == 1 and args.steps >= 64:
         ix.set_option("multi_query", 1)
-        ix.search_topk(qt[:64], k)
+        # untimed warm-up with the same call: the first full-size shared-sweep call after
+        # allocation runs ~1.7x slower (buffer first use); steady state is what is reported
+        ix.search_topk(qt, k)
         ix.set_timing(True)
         ix.reset_stats()
         t0 = time.perf_counter()
@@ -246,7 +248,7 @@ def main():
         out["batched"] = {
             "queries_per_sweep": round(per_sweep, 2),
             "value": round(qps_b, 1), "unit": "queries/s",
-            "kernel": "szg::mq_score_kernel<2> (v_mfma_f32_16x16x4_f32)",
+            "kernel": "szg::mq_score_kernel<3> (v_mfma_f32_16x16x4_f32)",
             "avg_sweep_ms": round(sweep_ms, 5),
             "hbm_GBps": round(n_rows * ix.row_bytes / (sweep_ms * 1e-3) / 1e9, 1),
             "mfma_TFLOPs": round(flops / (sweep_ms * 1e-3) / 1e12, 2),

@@ -8,7 +8,7 @@ with ScanIndex(dim, 32, 1, devices=[0]) as ix:
     ix.synth(n, 1234)
     q = synth_vectors(99, 0, 1024, dim)
     ix.set_timing(True)
-    for B in (9, 16, 17, 32):
+    for B in (16, 32, 48):
         # batches of exactly B: feed B queries per call
         ix.search_topk(q[:B], 10)
         ix.reset_stats()

@@ -250,6 +250,11 @@ hipError_t launch_mq_score(const MqArgs &a, int nb, int grid, hipStream_t stream
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(mq_score_kernel<2>, dim3(grid), dim3(1024), lds, stream, a);
+    } else if (nb == 3) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mq_score_kernel<3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(mq_score_kernel<3>, dim3(grid), dim3(1024), lds, stream, a);
     } else {
         return hipErrorInvalidValue;
     }

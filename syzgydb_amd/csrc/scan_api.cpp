@@ -221,6 +221,7 @@ struct szg_index {
     int serialize_scans = 1;  // scan launches of a shard never overlap each other
     int multi_query = 1;      // share one sweep between the queries of a batch (MFMA path)
     int mq_min = 8;           // smallest batch worth a shared sweep
+    int mq_blocks_max = 3;    // query blocks of 16 per shared sweep (LDS image permitting)
     bool timing = false;
     std::mutex stats_mu;
     szg_stats stats{};
@@ -625,8 +626,8 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
 int mq_blocks(const szg_index *ix, int nq)
 {   // query blocks of 16 the batch needs, or 0 when the shared sweep does not apply
     if (!ix->multi_query || ix->bits != 32 || ix->metric != SZG_COSINE || nq < ix->mq_min) return 0;
-    const int nb = nq > 16 ? 2 : 1;
-    if (szg::mq_lds_bytes(ix->map.r16, nb) > 150u * 1024u) return 0;
+    int nb = std::min((nq + 15) / 16, ix->mq_blocks_max);
+    while (nb > 0 && szg::mq_lds_bytes(ix->map.r16, nb) > 150u * 1024u) nb--;  // query image must fit LDS
     return nb;
 }
 
@@ -683,6 +684,10 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     a.keys = c->d_keys;
     a.key_stride = key_stride;
     a.zero16 = sh->zero16;
+    // The sweep wants every CU to itself (one 1024-thread block and up to 144 KiB of
+    // LDS per CU), so the whole batch -- sweep, selection, merges, rerank, copy --
+    // goes onto the shard's scan stream, one batch after the other; only uploads
+    // overlap on the context's stream.
     {
         std::lock_guard<std::mutex> lk(sh->chain_mu);
         hipStream_t st = ix->serialize_scans ? sh->scan_stream : c->stream;
@@ -697,6 +702,22 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
             c->timed_scan = true;
             c->timed_n = 1;
         }
+        HIPCHK(szg::launch_mq_select(c->d_keys, key_stride, (uint32_t)sh->n_rows,
+                                     sh->has_dead ? sh->live_bits : nullptr,
+                                     has_allow ? c->d_allow : nullptr, (uint32_t)shard_words(sh), kp, nq,
+                                     sb, c->d_lists_a, st));
+        int n_lists = sb;
+        uint64_t *src = c->d_lists_a, *dst = c->d_lists_b;
+        const int fan = szg::merge_fan(kp);
+        while (n_lists > 1) {
+            HIPCHK(szg::launch_merge(src, n_lists, kp, nq, dst, st));
+            n_lists = (n_lists + fan - 1) / fan;
+            std::swap(src, dst);
+        }
+        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64, src,
+                                  nullptr, (uint32_t)kp, nq, c->d_out, st));
+        HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp * nq,
+                              hipMemcpyDeviceToHost, st));
         if (st != c->stream) {
             HIPCHK(hipEventRecord(c->ev_scan_done, st));
             HIPCHK(hipStreamWaitEvent(c->stream, c->ev_scan_done, 0));
@@ -709,22 +730,6 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
         ix->stats.mq_launches += 1;
         ix->stats.mq_queries += (uint64_t)nq;
     }
-    HIPCHK(szg::launch_mq_select(c->d_keys, key_stride, (uint32_t)sh->n_rows,
-                                 sh->has_dead ? sh->live_bits : nullptr,
-                                 has_allow ? c->d_allow : nullptr, (uint32_t)shard_words(sh), kp, nq, sb,
-                                 c->d_lists_a, c->stream));
-    int n_lists = sb;
-    uint64_t *src = c->d_lists_a, *dst = c->d_lists_b;
-    const int fan = szg::merge_fan(kp);
-    while (n_lists > 1) {
-        HIPCHK(szg::launch_merge(src, n_lists, kp, nq, dst, c->stream));
-        n_lists = (n_lists + fan - 1) / fan;
-        std::swap(src, dst);
-    }
-    HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64, src,
-                              nullptr, (uint32_t)kp, nq, c->d_out, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp * nq,
-                          hipMemcpyDeviceToHost, c->stream));
     if (ix->timing) HIPCHK(hipEventRecord(c->ev_all1, c->stream));
     return SZG_OK;
 }
@@ -1013,7 +1018,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
         t.first = q0;
         // batches of up to 32 share one sweep when the multi-query path applies
         const int left = n_queries - q0;
-        const int nb = mq_blocks(ix, std::min(left, 32));
+        const int nb = mq_blocks(ix, std::min(left, 16 * ix->mq_blocks_max));
         t.nq = nb ? std::min(left, 16 * nb) : std::min(B1, left);
         t.kp = kp;
         t.ctx.assign(n_sh, nullptr);
@@ -1750,6 +1755,9 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
         ix->map = szg::RowMap{r16, L, P, 64 / L, 1, (L * P == r16) ? 1 : 0};
     } else if (n == "multi_query") {
         ix->multi_query = value != 0;
+    } else if (n == "mq_blocks") {
+        if (value < 1 || value > 3) return fail(SZG_E_INVALID, "mq_blocks must be 1..3");
+        ix->mq_blocks_max = (int)value;
     } else if (n == "mq_min") {
         if (value < 1 || value > 32) return fail(SZG_E_INVALID, "mq_min out of range");
         ix->mq_min = (int)value;

@@ -24,7 +24,7 @@ def check(ix, rows, dim, Q, k, allow=None):
 
 
 @pytest.mark.parametrize("dim,n", [(768, 3000), (384, 5000), (128, 20000), (20, 1500), (3, 700), (100, 40)])
-@pytest.mark.parametrize("nq", [32, 20, 9, 70])
+@pytest.mark.parametrize("nq", [32, 20, 9, 70, 101])
 def test_shared_sweep_matches_oracle(dim, n, nq):
     rows = orc.synth_rows(31 + dim, 0, n, dim, 32)
     Q = orc.synth_vectors(32 + dim, 0, nq, dim)
@@ -32,8 +32,8 @@ def test_shared_sweep_matches_oracle(dim, n, nq):
         ix.load(rows)
         check(ix, rows, dim, Q, 10)
         st = ix.stats()
-        shared = nq - (nq % 32 if nq % 32 < 8 else 0)   # a tail below mq_min gets its own sweeps
-        assert st["mq_queries"] == shared and st["mq_launches"] == (shared + 31) // 32
+        shared = nq - (nq % 48 if nq % 48 < 8 else 0)   # a tail below mq_min gets its own sweeps
+        assert st["mq_queries"] == shared and st["mq_launches"] == (shared + 47) // 48
         ix.set_option("multi_query", 0)
         ix.reset_stats()
         check(ix, rows, dim, Q[:9], 10)
