@@ -148,10 +148,8 @@ def main():
                                    device=torch.device("cuda", local_rank) if backend == "nccl" else None)
 
         def run(q):
-            outs = []
-            for i in range(0, q.shape[0], args.exchange_every):
-                outs.append(searcher.search(q[i:i + args.exchange_every], k))
-            return (np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs]))
+            r, d, _, _ = searcher.search_stream(q, k, args.exchange_every)
+            return r, d
     else:
         def run(q):
             r, d, _ = ix.search_topk(q, k)

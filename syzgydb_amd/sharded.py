@@ -68,13 +68,17 @@ class ShardedSearcher:
         self.device = device  # torch device of the exchange buffers ("cuda:N" for nccl)
 
     def search(self, queries, k):
-        import torch
         q = np.ascontiguousarray(queries, dtype=np.float64)
         if q.ndim == 1:
             q = q.reshape(1, -1)
-        nq = q.shape[0]
-        kk = k + 1  # one extra per shard so equal distances at the k boundary are visible
-        rows, dist, count = self.local_search(q, kk)
+        # one extra per shard so equal distances at the k boundary are visible
+        return self.exchange(self.local_search(q, k + 1), k)
+
+    def exchange(self, local, k):
+        """All-gather the ranks' local (rows, dist, count) top-(k+1) lists and merge."""
+        import torch
+        rows, dist, count = local
+        nq, kk = rows.shape
         # one int64 record per query: kk rows | kk distance bit patterns | count
         rec = np.zeros((nq, 2 * kk + 1), dtype=np.int64)
         rec[:, :kk] = rows.view(np.int64)
@@ -92,3 +96,17 @@ class ShardedSearcher:
         g_dist = np.ascontiguousarray(g[:, :, kk:2 * kk]).view(np.float64)
         g_count = np.ascontiguousarray(g[:, :, 2 * kk]).astype(np.int32)
         return merge_topk(k, g_rows, g_dist, g_count)
+
+    def search_stream(self, queries, k, chunk):
+        """Pipelined form for throughput: the local sweeps of chunk i+1 run in a worker
+        thread (the C call releases the GIL) while this thread exchanges and merges
+        chunk i.  Every rank must call it with the same chunking."""
+        from concurrent.futures import ThreadPoolExecutor
+        q = np.ascontiguousarray(queries, dtype=np.float64)
+        chunks = [q[i:i + chunk] for i in range(0, q.shape[0], chunk)]
+        outs = []
+        with ThreadPoolExecutor(max_workers=1) as ex:
+            futs = [ex.submit(self.local_search, c, k + 1) for c in chunks]
+            for f in futs:
+                outs.append(self.exchange(f.result(), k))
+        return tuple(np.concatenate([o[i] for o in outs]) for i in range(4))

@@ -36,6 +36,8 @@ for i in range(Q.shape[0]):
     er, ed, _ = orc.search_exact(rows, dim, bits, metric, Q[i], k=k)
     assert [int(x) for x in r[i, :c[i]]] == [int(x) for x in er], (rank, i)
     assert (d[i, :c[i]] == ed).all()
+r2, d2, c2, _ = s.search_stream(Q, k, 4)
+assert (r2 == r).all() and (d2 == d).all() and (c2 == c).all()
 dist.barrier()
 if rank == 0:
     print("SHARDED_OK world=%%d" %% world)
