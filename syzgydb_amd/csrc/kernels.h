@@ -87,20 +87,21 @@ size_t scan_lds_bytes(int qbits, const RowMap &m, int kp, int block);
 
 // Merge n_lists sorted lists of kp candidates into ceil(n_lists/merge_fan(kp)) lists.
 int merge_fan(int kp);
-// ---- multi-query sweep (kernels_mq.hip): 32-bit rows, cosine --------------------
+// ---- multi-query sweep (kernels_mq.hip): 4/8/16/32-bit rows, cosine -------------
 struct MqArgs {
     const uint8_t *rows;      // resident mirror
     uint32_t n_rows;
     uint32_t pitch;
-    int r16;                  // 16-byte chunks per row
-    const void *queries;      // device: LDS image [chunk][query block][16 queries][4 floats]
+    int r16;                  // 16-byte pieces per row
+    int dim;
+    const void *queries;      // device: LDS image [piece][query block][group of 4][16 queries][4 floats]
     int n_queries;            // <= 16 * query blocks
     float *keys;              // out: [n_queries][key_stride] ranking keys (-cos)
     size_t key_stride;        // floats, multiple of 4, >= n_rows
     const uint8_t *zero16;    // 16 zero bytes (address idle lanes read)
 };
-size_t mq_lds_bytes(int r16, int nb);
-hipError_t launch_mq_score(const MqArgs &a, int nb, int grid, hipStream_t stream);
+size_t mq_lds_bytes(int qbits, int r16, int nb);
+hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStream_t stream);
 hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_rows,
                             const uint64_t *live_bits, const uint64_t *allow_bits,
                             uint32_t allow_stride, int kp, int n_queries, int blocks_per_query,

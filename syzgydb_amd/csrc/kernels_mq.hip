@@ -20,8 +20,8 @@
 //                     per (query, block); the usual merge / float64 rerank /
 //                     certification tail follows.
 //
-// 32-bit rows, cosine only (the headline configuration); everything else takes
-// the single-query path.
+// 4/8/16/32-bit rows, cosine; 64-bit rows and the Euclidean metric take the
+// single-query path.
 #include "kernels.h"
 #include "device_lists.h"
 
@@ -43,21 +43,55 @@ __device__ __forceinline__ u32x4 load_nt(const uint8_t *p)
     return *reinterpret_cast<const u32x4 *>(p);
 }
 
-// LDS image of the batch: [chunk j][query block][query 16][4 floats]
-template <int NB>
+// Elements of one 16-byte piece as exact float32 values.  Float rows as they are;
+// quantized rows as the odd integer n = 2v - maxInt (dequantize(v) = n / maxInt up
+// to rounding; the common 1/maxInt cancels in -cos).  Elements past `dim` (row
+// padding) read as 0.
+template <int QBITS>
+__device__ __forceinline__ void decode_dword(uint32_t w, int e0, int dim, float *x)
+{
+    constexpr int N = 32 / QBITS;  // elements per dword
+    if (QBITS == 32) {
+        x[0] = __uint_as_float(w);
+    } else if (QBITS == 16) {
+        x[0] = fmaf((float)(w & 0xFFFFu), 2.0f, -65535.0f);
+        x[1] = fmaf((float)(w >> 16), 2.0f, -65535.0f);
+    } else if (QBITS == 8) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = fmaf((float)((w >> (8 * k)) & 0xFFu), 2.0f, -255.0f);
+    } else {  // 4-bit: byte b holds element 2b in its high nibble, 2b+1 in its low nibble
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t byte = (w >> (8 * k)) & 0xFFu;
+            x[2 * k] = fmaf((float)(byte >> 4), 2.0f, -15.0f);
+            x[2 * k + 1] = fmaf((float)(byte & 0xFu), 2.0f, -15.0f);
+        }
+    }
+    if (QBITS != 32 && e0 + N > dim) {
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            if (e0 + i >= dim) x[i] = 0.0f;
+    }
+}
+
+// LDS image of the batch: [piece j][query block][group of 4 elements][query 16][4 floats]
+template <int NB, int QBITS>
 __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 {
+    constexpr int E = 128 / QBITS;  // elements per 16-byte piece
+    constexpr int G4 = E / 4;       // groups of 4 elements per piece
+    constexpr int N = 32 / QBITS;   // elements per dword
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int nwaves = blockDim.x >> 6;
-    const int r16 = a.r16;           // 16-byte chunks per row
+    const int r16 = a.r16;           // 16-byte pieces per row
     const int steps = (r16 + 3) / 4; // 64-byte steps per row
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        const int n = r16 * NB * 16;
+        const int n = r16 * NB * G4 * 16;
         for (int i = tid; i < n; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
@@ -97,31 +131,44 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
         }                                                                                \
     }
 
+    // One 16-byte piece: every decoded element is the B operand of one MFMA per query
+    // block; the A operands (4 consecutive elements of 16 queries) come from LDS with
+    // one ds_read_b128 per block.  Lanes whose piece is out of range hold the dummy
+    // zero piece; for quantized rows that decodes to -maxInt, so they are skipped by
+    // multiplying with a zero query (the image is zero there) and masked out of the norm.
 #define MQ_CONSUME(u)                                                                    \
     {                                                                                    \
         const u32x4 v_ = ring[u];                                                        \
-        const float x0 = __uint_as_float(v_.x), x1 = __uint_as_float(v_.y);              \
-        const float x2 = __uint_as_float(v_.z), x3 = __uint_as_float(v_.w);              \
-        const int j_ = min(cs * 4 + c, r16 - 1); /* out-of-range chunks carry zeros */   \
-        _Pragma("unroll") for (int b = 0; b < NB; b++)                                   \
+        const uint32_t w_[4] = {v_.x, v_.y, v_.z, v_.w};                                 \
+        const int jraw_ = cs * 4 + c;                                                    \
+        const bool in_ = jraw_ < r16;                                                    \
+        const int j_ = in_ ? jraw_ : r16 - 1;                                            \
+        float x_[E];                                                                     \
+        _Pragma("unroll") for (int d = 0; d < 4; d++)                                    \
+            decode_dword<QBITS>(w_[d], in_ ? j_ * E + d * N : a.dim, a.dim, x_ + d * N); \
+        _Pragma("unroll") for (int i = 0; i < E; i++) nrm = fmaf(x_[i], x_[i], nrm);     \
+        _Pragma("unroll") for (int g = 0; g < G4; g++)                                   \
         {                                                                                \
-            const float4 q_ = qlds[(j_ * NB + b) * 16 + trow];                           \
-            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.x, x0, acc[b], 0, 0, 0);    \
-            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.y, x1, acc[b], 0, 0, 0);    \
-            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.z, x2, acc[b], 0, 0, 0);    \
-            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.w, x3, acc[b], 0, 0, 0);    \
+            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
+            {                                                                            \
+                const float4 q_ = qlds[((j_ * NB + b) * G4 + g) * 16 + trow];            \
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.x, x_[4 * g], acc[b], 0, 0, 0);     \
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.y, x_[4 * g + 1], acc[b], 0, 0, 0); \
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.z, x_[4 * g + 2], acc[b], 0, 0, 0); \
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.w, x_[4 * g + 3], acc[b], 0, 0, 0); \
+            }                                                                            \
         }                                                                                \
-        nrm = fmaf(x0, x0, nrm);                                                         \
-        nrm = fmaf(x1, x1, nrm);                                                         \
-        nrm = fmaf(x2, x2, nrm);                                                         \
-        nrm = fmaf(x3, x3, nrm);                                                         \
-        nz |= (v_.x | v_.y | v_.z | v_.w) & 0x7FFFFFFFu;                                 \
+        if (QBITS == 32)                                                                 \
+            nz |= (v_.x | v_.y | v_.z | v_.w) & 0x7FFFFFFFu;                             \
+        else                                                                             \
+            nz |= in_ ? 1u : 0u; /* quantized elements are never zero */                 \
         if (++cs == steps) {                                                             \
             finish_tile(ctile);                                                          \
             cs = 0;                                                                      \
             ctile += tile_stride;                                                        \
         }                                                                                \
     }
+
 
     // a row tile is done: row norms across the 4 chunk lanes, keys out
     auto finish_tile = [&](uint64_t tile) {
@@ -143,11 +190,7 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
                     if (nrm == 0.f) key = nz ? -2.0f : 1.0f;  // zero row: distance 1.0 (collection.go:828-830)
                     if (!(key == key)) key = 3.0e38f;
                     if (key > 3.0e38f) key = 3.0e38f;
-#ifdef MQ_NO_WRITE
-                    if (q < a.n_queries && key == 123.456f) a.keys[(size_t)q * a.key_stride + row] = key;
-#else
                     if (q < a.n_queries) a.keys[(size_t)q * a.key_stride + row] = key;
-#endif
                 }
             }
         }
@@ -234,31 +277,40 @@ __global__ __launch_bounds__(256) void mq_select_kernel(const float *keys, size_
 
 }  // namespace
 
-size_t mq_lds_bytes(int r16, int nb) { return (size_t)r16 * nb * 16 * 16; }
+size_t mq_lds_bytes(int qbits, int r16, int nb) { return (size_t)r16 * nb * (128 / qbits) * 16 * 4; }
 
-hipError_t launch_mq_score(const MqArgs &a, int nb, int grid, hipStream_t stream)
+namespace {
+template <int NB, int QBITS>
+hipError_t launch_mq_score_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
-    const size_t lds = mq_lds_bytes(a.r16, nb);
-    hipError_t e = hipSuccess;
-    if (nb == 1) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mq_score_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(mq_score_kernel<1>, dim3(grid), dim3(1024), lds, stream, a);
-    } else if (nb == 2) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mq_score_kernel<2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(mq_score_kernel<2>, dim3(grid), dim3(1024), lds, stream, a);
-    } else if (nb == 3) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mq_score_kernel<3>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(mq_score_kernel<3>, dim3(grid), dim3(1024), lds, stream, a);
-    } else {
-        return hipErrorInvalidValue;
-    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mq_score_kernel<NB, QBITS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((mq_score_kernel<NB, QBITS>), dim3(grid), dim3(1024), lds, stream, a);
     return hipGetLastError();
+}
+template <int QBITS>
+hipError_t launch_mq_score_q(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
+{
+    switch (nb) {
+    case 1: return launch_mq_score_t<1, QBITS>(a, grid, lds, stream);
+    case 2: return launch_mq_score_t<2, QBITS>(a, grid, lds, stream);
+    case 3: return launch_mq_score_t<3, QBITS>(a, grid, lds, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+}  // namespace
+
+hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStream_t stream)
+{
+    const size_t lds = mq_lds_bytes(qbits, a.r16, nb);
+    switch (qbits) {
+    case 4: return launch_mq_score_q<4>(a, nb, grid, lds, stream);
+    case 8: return launch_mq_score_q<8>(a, nb, grid, lds, stream);
+    case 16: return launch_mq_score_q<16>(a, nb, grid, lds, stream);
+    case 32: return launch_mq_score_q<32>(a, nb, grid, lds, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_rows,

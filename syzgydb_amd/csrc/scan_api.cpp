@@ -625,9 +625,9 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
 
 int mq_blocks(const szg_index *ix, int nq)
 {   // query blocks of 16 the batch needs, or 0 when the shared sweep does not apply
-    if (!ix->multi_query || ix->bits != 32 || ix->metric != SZG_COSINE || nq < ix->mq_min) return 0;
+    if (!ix->multi_query || ix->bits == 64 || ix->metric != SZG_COSINE || nq < ix->mq_min) return 0;
     int nb = std::min((nq + 15) / 16, ix->mq_blocks_max);
-    while (nb > 0 && szg::mq_lds_bytes(ix->map.r16, nb) > 150u * 1024u) nb--;  // query image must fit LDS
+    while (nb > 0 && szg::mq_lds_bytes(ix->bits, ix->map.r16, nb) > 150u * 1024u) nb--;  // image must fit LDS
     return nb;
 }
 
@@ -637,7 +637,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
 {
     HIPCHK(hipSetDevice(sh->device));
     const int r16 = ix->map.r16;
-    const size_t img = szg::mq_lds_bytes(r16, nb);
+    const size_t img = szg::mq_lds_bytes(ix->bits, r16, nb);
     int rc = ensure_host(&c->h_mq, &c->h_mq_cap, img);
     if (rc) return rc;
     rc = ensure_dev(&c->d_mq, &c->d_mq_cap, img);
@@ -645,15 +645,21 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     const size_t key_stride = ((size_t)sh->n_rows + 3) & ~(size_t)3;
     rc = ensure_dev(&c->d_keys, &c->keys_cap, key_stride * nq);
     if (rc) return rc;
-    // LDS image [chunk j][query block][query 16][4 floats] from the normalised queries
-    // (h_qsw holds them as float4 per chunk: [chunk j][4])
+    // LDS image [piece j][query block][group of 4 elements][query 16][4 floats] of the
+    // normalised queries (q / |q|, so the key is -cos; quantized rows decode to
+    // n = maxInt * d and the common factor cancels)
     float *im = reinterpret_cast<float *>(c->h_mq);
     memset(im, 0, img);
+    const int E = 128 / ix->bits, G4 = E / 4;
     for (int q = 0; q < nq; q++) {
-        const float *src = reinterpret_cast<const float *>(c->h_qsw + (size_t)q * ix->qsw_bytes);
+        const double *src = c->h_q64 + (size_t)q * ix->dim;
+        const double m1 = c->meta[q].m1;
+        const double scale = m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0;
         const int b = q / 16, qi = q % 16;
-        for (int j = 0; j < r16; j++)
-            memcpy(im + (((size_t)j * nb + b) * 16 + qi) * 4, src + (size_t)j * 4, 16);
+        for (int e = 0; e < ix->dim; e++) {
+            const int j = e / E, i = e % E, g4 = i / 4, m = i % 4;
+            im[((((size_t)j * nb + b) * G4 + g4) * 16 + qi) * 4 + m] = (float)(src[e] * scale);
+        }
     }
     HIPCHK(hipMemcpyAsync(c->d_mq, c->h_mq, img, hipMemcpyHostToDevice, c->stream));
 
@@ -679,6 +685,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     a.n_rows = (uint32_t)sh->n_rows;
     a.pitch = ix->pitch;
     a.r16 = r16;
+    a.dim = ix->dim;
     a.queries = c->d_mq;
     a.n_queries = nq;
     a.keys = c->d_keys;
@@ -696,7 +703,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
             HIPCHK(hipStreamWaitEvent(st, c->ev_up, 0));
         }
         if (ix->timing) HIPCHK(hipEventRecord(c->ev_scan0, st));
-        HIPCHK(szg::launch_mq_score(a, nb, sh->cu_count, st));
+        HIPCHK(szg::launch_mq_score(ix->bits, a, nb, sh->cu_count, st));
         if (ix->timing) {
             HIPCHK(hipEventRecord(c->ev_scan1, st));
             c->timed_scan = true;

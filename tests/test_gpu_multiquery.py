@@ -9,13 +9,13 @@ from syzgydb_amd import ScanIndex, SZG_COSINE
 pytestmark = pytest.mark.gpu
 
 
-def check(ix, rows, dim, Q, k, allow=None):
+def check(ix, rows, dim, Q, k, allow=None, bits=32):
     kw = {}
     if allow is not None:
         kw["allow"] = np.tile(allow, (Q.shape[0], 1))
     r, d, c = ix.search_topk(Q, k, **kw)
     for qi in range(Q.shape[0]):
-        o_rows, o_dist, _ = orc.search_exact(rows, dim, 32, 1, Q[qi], k=k,
+        o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, 1, Q[qi], k=k,
                                              allow=None if allow is None else allow.astype(np.uint8))
         assert c[qi] == len(o_rows)
         assert [int(x) for x in r[qi, : c[qi]]] == [int(x) for x in o_rows], qi
@@ -38,6 +38,30 @@ def test_shared_sweep_matches_oracle(dim, n, nq):
         ix.reset_stats()
         check(ix, rows, dim, Q[:9], 10)
         assert ix.stats()["mq_queries"] == 0
+
+
+@pytest.mark.parametrize("bits", [4, 8, 16])
+@pytest.mark.parametrize("dim,n", [(768, 2000), (384, 3000), (100, 4000), (37, 900), (3, 500)])
+def test_shared_sweep_quantized_rows(bits, dim, n):
+    """The MFMA sweep on 4/8/16-bit rows (decoded to exact integers in float32)."""
+    rows = orc.synth_rows(131 + dim + bits, 0, n, dim, bits)
+    Q = orc.synth_vectors(132 + dim, 0, 40, dim)
+    allow = np.arange(n) % 4 != 2
+    with ScanIndex(dim, bits, SZG_COSINE) as ix:
+        ix.load(rows)
+        check(ix, rows, dim, Q, 10, bits=bits)
+        assert ix.stats()["mq_queries"] == 40
+        check(ix, rows, dim, Q[:20], 7, allow=allow, bits=bits)
+
+
+def test_shared_sweep_two_shards():
+    dim, n = 96, 6000
+    rows = orc.synth_rows(55, 0, n, dim, 32)
+    Q = orc.synth_vectors(56, 0, 48, dim)
+    with ScanIndex(dim, 32, SZG_COSINE, devices=[0, 0]) as ix:
+        ix.load(rows)
+        check(ix, rows, dim, Q, 10)
+        assert ix.stats()["mq_launches"] == 2  # one shared sweep per shard
 
 
 def test_shared_sweep_masks_tombstones_and_escalation():
