@@ -171,7 +171,7 @@ class ScanIndex:
         if q.size != self.dim:
             raise ValueError("query length %d != dimension %d" % (q.size, self.dim))
         keep, allow_p = self._allow_arg(allow, 1)
-        cap = int(capacity) if capacity is not None else 1024
+        cap = int(capacity) if capacity is not None else 1 << 16  # a too-small buffer costs a second sweep
         while True:
             out_rows = np.zeros(max(cap, 1), dtype=np.uint64)
             out_dist = np.zeros(max(cap, 1), dtype=np.float64)
