@@ -279,6 +279,13 @@ def main():
                           nq, sample_rows, n_rows, cores, secs, n_rows),
             "single_thread": round(1.0 / per_query * scale, 4),
         }
+        # the reference also CRCs and re-parses each record's span and allocates a decode
+        # buffer on every visit (spanfile.go:757, collection.go:769): one query with that
+        # per-record work included, single thread, on a smaller sample
+        fs_rows = min(sample_rows, 20_000)
+        fsecs, frows = orc.bench_topk_faithful(rows_host[:fs_rows], dim, bits, metric, qt[:1], k)
+        out["cpu_baseline"]["single_thread_with_span_crc_parse_alloc"] = round(
+            1.0 / fsecs * (fs_rows / float(n_rows)), 4)
         log("cpu_baseline leg: %.1f s" % (time.time() - t0))
         # parity on the FULL corpus for a few queries: ids identical, distances bit-equal
         nv = min(args.verify, len(qt))

@@ -226,7 +226,7 @@ public:
             if (numRecords == 0) {
                 n = 0;
             } else if (args.Radius > 0) {  // K is ignored (:598-605)
-                uint64_t cap = 1024, totalHits = 0;
+                uint64_t cap = 1u << 16, totalHits = 0;  // a truncated call costs a second sweep
                 for (;;) {
                     rows.assign(cap, 0);
                     dist.assign(cap, 0);

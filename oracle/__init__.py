@@ -81,6 +81,12 @@ def lib():
         L.orc_bench_topk.argtypes = [u8p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, f64p, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, u64p]
+        L.orc_spans_build.restype = ctypes.c_uint64
+        L.orc_spans_build.argtypes = [u8p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      u8p, ctypes.c_uint64, u64p]
+        L.orc_bench_topk_faithful.restype = ctypes.c_double
+        L.orc_bench_topk_faithful.argtypes = [u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, f64p, ctypes.c_int, ctypes.c_int, u64p]
         _lib = L
     return _lib
 
@@ -221,4 +227,26 @@ def bench_topk(rows, dim, bits, metric, queries, k, threads):
     secs = lib().orc_bench_topk(_p(rows, ctypes.c_uint8), n_rows, dim, bits, metric,
                                 _p(Q, ctypes.c_double), Q.shape[0], k, int(threads),
                                 _p(out, ctypes.c_uint64))
+    return float(secs), out
+
+
+def bench_topk_faithful(rows, dim, bits, metric, queries, k, meta_len=16):
+    """Single-thread exact top-k with the reference's per-record overheads (CRC32 of the
+    span, span parse, fresh decode buffer); returns (seconds, rows[n_queries,k])."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    rb = vector_size(bits, dim)
+    n_rows = rows.size // rb
+    cap = n_rows * (rb + meta_len + 64)
+    spans = np.zeros(cap, dtype=np.uint8)
+    offsets = np.zeros(n_rows, dtype=np.uint64)
+    used = lib().orc_spans_build(_p(rows, ctypes.c_uint8), n_rows, dim, bits, meta_len,
+                                 _p(spans, ctypes.c_uint8), cap, _p(offsets, ctypes.c_uint64))
+    assert used > 0
+    Q = _f64(queries).reshape(-1, dim)
+    out = np.zeros((Q.shape[0], k), dtype=np.uint64)
+    secs = lib().orc_bench_topk_faithful(_p(spans, ctypes.c_uint8), _p(offsets, ctypes.c_uint64), n_rows,
+                                         dim, bits, metric, _p(Q, ctypes.c_double), Q.shape[0], k,
+                                         _p(out, ctypes.c_uint64))
+    if secs < 0:
+        raise RuntimeError("faithful baseline: span failed to parse")
     return float(secs), out

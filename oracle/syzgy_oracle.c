@@ -496,3 +496,137 @@ double orc_bench_topk(const uint8_t *rows, uint64_t n_rows, int dim, int bits, i
     clock_gettime(CLOCK_MONOTONIC, &t1);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ------------------------------------------------- faithful per-record baseline */
+
+static uint32_t crc_table[256];
+static int crc_ready = 0;
+
+static uint32_t crc32_ieee(const uint8_t *p, size_t n)
+{   /* hash/crc32.ChecksumIEEE (spanfile.go:836-838); byte-at-a-time table */
+    if (!crc_ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            crc_table[i] = c;
+        }
+        crc_ready = 1;
+    }
+    uint32_t c = 0xFFFFFFFFu;
+    while (n--) c = crc_table[(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
+static size_t put7(uint8_t *o, uint64_t n)
+{   /* write7Code, spanfile.go:568-625 (up to 4 bytes is all that is needed here) */
+    if (n < 0x7f) { o[0] = (uint8_t)n; return 1; }
+    if (n < 0x3fff) { o[0] = (uint8_t)(((n >> 7) & 0x7f) | 0x80); o[1] = (uint8_t)(n & 0x7f); return 2; }
+    if (n < 0x1fffff) {
+        o[0] = (uint8_t)(((n >> 14) & 0x7f) | 0x80); o[1] = (uint8_t)(((n >> 7) & 0x7f) | 0x80);
+        o[2] = (uint8_t)(n & 0x7f); return 3;
+    }
+    o[0] = (uint8_t)(((n >> 21) & 0x7f) | 0x80); o[1] = (uint8_t)(((n >> 14) & 0x7f) | 0x80);
+    o[2] = (uint8_t)(((n >> 7) & 0x7f) | 0x80); o[3] = (uint8_t)(n & 0x7f); return 4;
+}
+
+static int get7(const uint8_t *b, size_t len, size_t *at, uint64_t *out)
+{   /* read7Code, spanfile.go:627-636 */
+    uint64_t r = 0;
+    for (size_t o = *at; o < len; o++) {
+        uint64_t d = b[o];
+        r = (r << 7) | (d & 0x7f);
+        if ((d & 0x80) == 0) { *at = o + 1; *out = r; return 1; }
+    }
+    return 0;
+}
+
+uint64_t orc_spans_build(const uint8_t *rows, uint64_t n_rows, int dim, int bits, int meta_len,
+                         uint8_t *out, uint64_t out_cap, uint64_t *offsets)
+{
+    int64_t rb = orc_vector_size(bits, dim);
+    if (rb < 0) return 0;
+    uint64_t at = 0;
+    for (uint64_t r = 0; r < n_rows; r++) {
+        char id[24];
+        int idl = snprintf(id, sizeof(id), "%llu", (unsigned long long)r);
+        uint8_t hdr[64];
+        size_t h = 8;
+        h += put7(hdr + h, r + 2);          /* sequence number */
+        h += put7(hdr + h, (uint64_t)idl);  /* record id */
+        memcpy(hdr + h, id, (size_t)idl); h += (size_t)idl;
+        hdr[h++] = 2;                       /* stream count */
+        hdr[h++] = 0;                       /* stream 0 = metadata */
+        h += put7(hdr + h, (uint64_t)meta_len);
+        uint8_t s1[8];
+        size_t s1n = 0;
+        s1[s1n++] = 1;                      /* stream 1 = packed vector */
+        s1n += put7(s1 + s1n, (uint64_t)rb);
+        uint64_t len = h + (uint64_t)meta_len + s1n + (uint64_t)rb + 4;
+        if (at + len > out_cap) return 0;
+        uint8_t *o = out + at;
+        memcpy(o, hdr, h);
+        o[0] = 0x53; o[1] = 0x50; o[2] = 0x41; o[3] = 0x4E;  /* 'SPAN' */
+        o[4] = (uint8_t)(len >> 24); o[5] = (uint8_t)(len >> 16); o[6] = (uint8_t)(len >> 8); o[7] = (uint8_t)len;
+        memset(o + h, 'm', (size_t)meta_len);
+        memcpy(o + h + meta_len, s1, s1n);
+        memcpy(o + h + meta_len + s1n, rows + r * (uint64_t)rb, (size_t)rb);
+        uint32_t crc = crc32_ieee(o, (size_t)len - 4);
+        o[len - 4] = (uint8_t)(crc >> 24); o[len - 3] = (uint8_t)(crc >> 16);
+        o[len - 2] = (uint8_t)(crc >> 8); o[len - 1] = (uint8_t)crc;
+        offsets[r] = at;
+        at += len;
+    }
+    return at;
+}
+
+double orc_bench_topk_faithful(const uint8_t *spans, const uint64_t *offsets, uint64_t n_rows, int dim,
+                               int bits, int metric, const double *queries, int n_queries, int k,
+                               uint64_t *out_rows)
+{
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int q = 0; q < n_queries; q++) {
+        const double *query = queries + (size_t)q * (size_t)dim;
+        orc_pq pq = {0, 0, 0};
+        for (uint64_t r = 0; r < n_rows; r++) {
+            /* getDocument -> ReadRecord -> parseSpan (spanfile.go:730-818) */
+            const uint8_t *d = spans + offsets[r];
+            uint32_t len = (uint32_t)d[4] << 24 | (uint32_t)d[5] << 16 | (uint32_t)d[6] << 8 | d[7];
+            uint32_t want = (uint32_t)d[len - 4] << 24 | (uint32_t)d[len - 3] << 16 |
+                            (uint32_t)d[len - 2] << 8 | d[len - 1];
+            if (crc32_ieee(d, len - 4) != want) { free(pq.a); return -1.0; }  /* :757 */
+            size_t at = 8;
+            uint64_t seq, idl, sl;
+            if (!get7(d, len, &at, &seq) || !get7(d, len, &at, &idl)) { free(pq.a); return -1.0; }
+            at += (size_t)idl;
+            int ns = d[at++];
+            const uint8_t *vec = NULL;
+            for (int i = 0; i < ns; i++) {
+                at++;  /* stream id */
+                if (!get7(d, len, &at, &sl)) { free(pq.a); return -1.0; }
+                if (i == 1) vec = d + at;  /* streams by position (collection.go:476-477) */
+                at += (size_t)sl;
+            }
+            /* decodeVector allocates a fresh []float64 per record (collection.go:769) */
+            double *v = (double *)malloc(sizeof(double) * (size_t)dim);
+            orc_decode_vector(vec, dim, bits, v);
+            double distance = distance_fn(metric, query, v, dim);
+            free(v);
+            if (pq.len <= k) {
+                if (pq.len < k || pq.a[0].priority > distance) {
+                    orc_item it = {r, distance};
+                    heap_push(&pq, it);
+                    if (pq.len > k) heap_pop(&pq);
+                }
+            }
+        }
+        int64_t n = pq.len;
+        for (int64_t i = n - 1; i >= 0; i--) {
+            orc_item it = heap_pop(&pq);
+            if (out_rows && i < k) out_rows[(size_t)q * (size_t)k + (size_t)i] = it.row;
+        }
+        free(pq.a);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -102,6 +102,24 @@ double orc_bench_topk(const uint8_t *rows, uint64_t n_rows, int dim, int bits, i
                       const double *queries, int n_queries, int k, int threads,
                       uint64_t *out_rows /* n_queries*k */);
 
+/*
+ * "Faithful" CPU baseline: the per-record work the reference does on EVERY visited
+ * record of an exact search, not just the arithmetic -- getDocument -> ReadRecord ->
+ * parseSpan with a CRC32-IEEE over the whole span (spanfile.go:730-818, :757),
+ * stream walk, decodeVector into a freshly allocated []float64
+ * (collection.go:470-484, :768-794), then distance and heap.  orc_spans_build
+ * serialises the given rows as spans (spanfile.go:1-22 grammar, metadata stream of
+ * meta_len bytes) into `out` and returns the bytes used (0 if out_cap is too small);
+ * offsets[i] receives the start of record i's span.
+ */
+uint64_t orc_spans_build(const uint8_t *rows, uint64_t n_rows, int dim, int bits, int meta_len,
+                         uint8_t *out, uint64_t out_cap, uint64_t *offsets);
+/* One exact top-k search over those spans, single thread; returns wall seconds, or < 0
+ * if a span fails its checksum / parse. */
+double orc_bench_topk_faithful(const uint8_t *spans, const uint64_t *offsets, uint64_t n_rows, int dim,
+                               int bits, int metric, const double *queries, int n_queries, int k,
+                               uint64_t *out_rows /* n_queries*k */);
+
 #ifdef __cplusplus
 }
 #endif

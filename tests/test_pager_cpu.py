@@ -83,3 +83,28 @@ def test_pager_errors(tmp_path):
     p.write_bytes(sw.span(1, "5", [(0, b"m"), (1, b"\x00" * 8)]) + b"\x00" * 64)
     with pytest.raises(SzgError):
         SpanfilePager(p)
+
+
+def test_oracle_span_builder_is_read_by_the_pager(tmp_path, oracle):
+    """The spans the faithful CPU baseline walks are real spanfile spans: prepend a
+    header record and the C++ pager reads every vector back."""
+    import ctypes
+    dim, bits, n = 10, 16, 200
+    rows = oracle.synth_rows(21, 0, n, dim, bits)
+    rb = rows.shape[1]
+    spans = np.zeros(n * (rb + 80), dtype=np.uint8)
+    offs = np.zeros(n, dtype=np.uint64)
+    used = oracle.lib().orc_spans_build(rows.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n, dim, bits, 7,
+                                        spans.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), spans.size,
+                                        offs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+    assert used > 0
+    path = tmp_path / "orc.dat"
+    path.write_bytes(sw.header_span(1, "orc", 0, dim, bits) + spans[:used].tobytes() + b"\x00" * 64)
+    with SpanfilePager(path) as pg:
+        assert pg.count == n and pg.skipped == 0
+        ids = [int(x) for x in pg.ids()]
+        assert (pg.vectors() == rows[ids]).all()
+        assert pg.metadata(0) == b"m" * 7
+    s1, r1 = oracle.bench_topk(rows, dim, bits, 0, oracle.synth_vectors(22, 0, 2, dim), 5, 1)
+    s2, r2 = oracle.bench_topk_faithful(rows, dim, bits, 0, oracle.synth_vectors(22, 0, 2, dim), 5, meta_len=7)
+    assert (r1 == r2).all()
