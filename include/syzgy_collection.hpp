@@ -190,6 +190,28 @@ public:
         row_of_.erase(it);
     }
 
+    // collection.go:348-400; intn(n) plays rand.Intn
+    double computeAverageDistance(int samples, const std::function<int(int)> &intn)
+    {
+        if (samples <= 0) return 0.0;
+        const std::vector<uint64_t> ids = GetAllIDs();
+        if (ids.size() < 2) return 0.0;
+        std::vector<uint64_t> a, b;
+        for (int i = 0; i < samples; i++) {
+            const uint64_t id1 = ids[(size_t)intn((int)ids.size())];
+            const uint64_t id2 = ids[(size_t)intn((int)ids.size())];
+            if (id1 == id2) continue;
+            a.push_back(row_of_[id1]);
+            b.push_back(row_of_[id2]);
+        }
+        if (a.empty()) return 0.0;
+        std::vector<double> d(a.size());
+        check(szg_pair_distances(ix_, a.data(), b.data(), a.size(), d.data()), "szg_pair_distances");
+        double totalDistance = 0.0;
+        for (double x : d) totalDistance += x;
+        return totalDistance / (double)a.size();
+    }
+
     // collection.go:569-711
     SearchResults Search(const SearchArgs &args)
     {

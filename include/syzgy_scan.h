@@ -136,6 +136,15 @@ int szg_distances(szg_index *ix, const double *query, const uint64_t *rows, uint
                   double *out_dist);
 
 /*
+ * c.distance(doc_a.Vector, doc_b.Vector) for stored rows: the primitive under
+ * computeAverageDistance (collection.go:348-400), which the Go side keeps (it owns the
+ * math/rand pair selection and the in-order float64 sum, :372-398).  out_dist[i] is the
+ * reference's float64 distance between the decoded rows rows_a[i] and rows_b[i].
+ */
+int szg_pair_distances(szg_index *ix, const uint64_t *rows_a, const uint64_t *rows_b, uint64_t n_pairs,
+                       double *out_dist);
+
+/*
  * Cross-shard result assembly for one-process-per-GPU sharding (host code, no
  * device work).  Every rank answers the batch on its own row range with
  * szg_search_topk asking for list_len = k+1 results (rows made global with

@@ -30,7 +30,7 @@ EXPORTS = [
     "szg_index_live_rows", "szg_index_read_rows", "szg_search_topk", "szg_search_radius",
     "szg_strerror", "szg_last_error", "szg_abi_version", "szg_set_timing", "szg_get_stats",
     "szg_reset_stats", "szg_set_option", "szg_index_synth", "szg_index_set_row_base",
-    "szg_merge_topk", "szg_index_append_f64", "szg_distances", "szg_index_overwrite_f64",
+    "szg_merge_topk", "szg_index_append_f64", "szg_distances", "szg_pair_distances", "szg_index_overwrite_f64",
 ]
 # include/syzgy_pager.h
 PAGER_EXPORTS = [
@@ -138,6 +138,8 @@ def load():
     L.szg_index_overwrite_f64.argtypes = [vp, ctypes.c_uint64, f64p]
     L.szg_distances.restype = ctypes.c_int
     L.szg_distances.argtypes = [vp, f64p, u64p, ctypes.c_uint64, f64p]
+    L.szg_pair_distances.restype = ctypes.c_int
+    L.szg_pair_distances.argtypes = [vp, u64p, u64p, ctypes.c_uint64, f64p]
     L.szg_pager_open.restype = ctypes.c_int
     L.szg_pager_open.argtypes = [ctypes.POINTER(vp), ctypes.c_char_p, ctypes.c_int]
     L.szg_pager_close.restype = None

@@ -162,6 +162,34 @@ class Collection:
     def GetAllIDs(self):
         return sorted(self._row_of)
 
+    def computeAverageDistance(self, samples: int, intn=None) -> float:
+        """collection.go:348-400: mean distance over up to `samples` random pairs of
+        distinct documents.  `intn(n)` plays rand.Intn (Go's generator is the caller's);
+        the pairs' distances come from one szg_pair_distances call, the in-order float64
+        sum and the division stay here as in the reference (:389-398)."""
+        if samples <= 0:
+            return 0.0
+        ids = self.GetAllIDs()
+        if len(ids) < 2:
+            return 0.0
+        if intn is None:
+            import random
+            intn = random.randrange
+        a, b = [], []
+        for _ in range(samples):
+            id1 = ids[intn(len(ids))]
+            id2 = ids[intn(len(ids))]
+            if id1 == id2:
+                continue  # :375-377
+            a.append(self._row_of[id1])
+            b.append(self._row_of[id2])
+        if not a:
+            return 0.0
+        total = 0.0
+        for d in self._index.pair_distances(a, b):
+            total += float(d)
+        return total / float(len(a))
+
     def Close(self):
         if not self._closed:
             self._index.close()

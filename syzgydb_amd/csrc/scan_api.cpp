@@ -1513,6 +1513,65 @@ int szg_distances(szg_index *ix, const double *query, const uint64_t *rows, uint
     return SZG_OK;
 }
 
+// decodeVector + dequantize on the host (collection.go:768-794, quantization.go:25-36);
+// integer -> float64 conversions, one correctly rounded division, exact *2 and -1
+static void decode_row_host(const uint8_t *data, int dim, int q, double *out)
+{
+    for (int i = 0; i < dim; i++) {
+        uint64_t v = 0;
+        switch (q) {
+        case 4: v = (i % 2 == 0) ? (uint64_t)(data[i / 2] >> 4) : (uint64_t)(data[i / 2] & 0x0F); break;
+        case 8: v = data[i]; break;
+        case 16: v = ((uint64_t)data[i * 2] << 8) | data[i * 2 + 1]; break;
+        case 32: for (int b = 0; b < 4; b++) v = (v << 8) | data[i * 4 + b]; break;
+        default: for (int b = 0; b < 8; b++) v = (v << 8) | data[i * 8 + b]; break;
+        }
+        if (q == 32) {
+            const uint32_t u = (uint32_t)v;
+            float f;
+            memcpy(&f, &u, 4);
+            out[i] = (double)f;
+        } else if (q == 64) {
+            memcpy(&out[i], &v, 8);
+        } else {
+            const double maxInt = (double)((1ull << q) - 1);
+            const double t = (double)v / maxInt;
+            out[i] = t * 2 - 1;
+        }
+    }
+}
+
+int szg_pair_distances(szg_index *ix, const uint64_t *rows_a, const uint64_t *rows_b, uint64_t n_pairs,
+                       double *out_dist)
+{
+    if (!ix || ((!rows_a || !rows_b || !out_dist) && n_pairs)) return fail(SZG_E_INVALID, "null argument");
+    if (n_pairs == 0) return SZG_OK;
+    // pairs sharing a left row go down in one szg_distances call with that row as the query
+    std::vector<uint64_t> order(n_pairs);
+    for (uint64_t i = 0; i < n_pairs; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) { return rows_a[x] < rows_a[y]; });
+    std::vector<uint8_t> bytes((size_t)szg_row_bytes(ix->bits, ix->dim));
+    std::vector<double> vec(ix->dim), d;
+    std::vector<uint64_t> rhs;
+    for (uint64_t s = 0; s < n_pairs;) {
+        uint64_t e = s;
+        while (e < n_pairs && rows_a[order[e]] == rows_a[order[s]]) e++;
+        const uint64_t a = rows_a[order[s]];
+        if (a < ix->row_base) return fail(SZG_E_RANGE, "row out of range");
+        int rc = szg_index_read_rows(ix, a - ix->row_base, 1, bytes.data());
+        if (rc) return rc;
+        decode_row_host(bytes.data(), ix->dim, ix->bits, vec.data());
+        rhs.clear();
+        for (uint64_t i = s; i < e; i++) rhs.push_back(rows_b[order[i]]);
+        d.assign(rhs.size(), 0.0);
+        rc = szg_distances(ix, vec.data(), rhs.data(), rhs.size(), d.data());
+        if (rc) return rc;
+        for (uint64_t i = s; i < e; i++) out_dist[order[i]] = d[i - s];
+        s = e;
+    }
+    return SZG_OK;
+}
+
 int szg_index_overwrite(szg_index *ix, uint64_t row, const uint8_t *row_bytes)
 {
     if (!ix || !row_bytes) return fail(SZG_E_INVALID, "null argument");

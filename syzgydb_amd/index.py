@@ -101,6 +101,18 @@ class ScanIndex:
                                     _f64(out) if r.size else None), "szg_distances")
         return out
 
+    def pair_distances(self, rows_a, rows_b):
+        """The reference's float64 distance between stored rows a[i] and b[i]."""
+        a = np.ascontiguousarray(rows_a, dtype=np.uint64).reshape(-1)
+        b = np.ascontiguousarray(rows_b, dtype=np.uint64).reshape(-1)
+        if a.size != b.size:
+            raise ValueError("rows_a and rows_b differ in length")
+        out = np.zeros(a.size, dtype=np.float64)
+        if a.size:
+            check(self._L.szg_pair_distances(self._h, _u64(a), _u64(b), a.size, _f64(out)),
+                  "szg_pair_distances")
+        return out
+
     def overwrite(self, row, row_bytes):
         a, n = self._rows_arg(row_bytes)
         if n != 1:

@@ -97,6 +97,43 @@ class ShardedSearcher:
         g_count = np.ascontiguousarray(g[:, :, 2 * kk]).astype(np.int32)
         return merge_topk(k, g_rows, g_dist, g_count)
 
+    def search_radius(self, local_radius, query, radius):
+        """Radius search over the sharded corpus (config #5's mode).
+
+        local_radius(query, radius) -> (rows uint64 GLOBAL, dist float64) is the rank's own
+        szg_search_radius.  The ranks all-gather their hit counts, then one padded
+        all-gather of (row, distance-bits) records; every rank replays the reference's
+        push-all / pop-all heap (collection.go:598-603, :694-697) over the union in row
+        order, so the returned order is the single-collection one, ties included.
+        """
+        import torch
+        q = np.ascontiguousarray(query, dtype=np.float64).reshape(-1)
+        rows, dist = local_radius(q, float(radius))
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        dist = np.ascontiguousarray(dist, dtype=np.float64)
+        n = torch.tensor([rows.size], dtype=torch.int64)
+        if self.device is not None:
+            n = n.to(self.device)
+        counts = torch.empty(self.world, dtype=torch.int64, device=n.device)
+        self._dist.all_gather_into_tensor(counts, n, group=self.group)
+        counts = counts.cpu().numpy()
+        total, m = int(counts.sum()), int(counts.max())
+        if total == 0:
+            return np.zeros(0, np.uint64), np.zeros(0, np.float64)
+        rec = np.zeros((m, 2), dtype=np.int64)
+        rec[:rows.size, 0] = rows.view(np.int64)
+        rec[:rows.size, 1] = dist.view(np.int64)
+        mine = torch.from_numpy(rec)
+        if self.device is not None:
+            mine = mine.to(self.device)
+        gathered = torch.empty((self.world * m, 2), dtype=torch.int64, device=mine.device)
+        self._dist.all_gather_into_tensor(gathered, mine, group=self.group)
+        g = gathered.cpu().numpy().reshape(self.world, 1, m, 2)
+        g_rows = np.ascontiguousarray(g[..., 0]).view(np.uint64)
+        g_dist = np.ascontiguousarray(g[..., 1]).view(np.float64)
+        r, d, c, _ = merge_topk(total, g_rows, g_dist, counts.astype(np.int32).reshape(self.world, 1))
+        return r[0, :c[0]], d[0, :c[0]]
+
     def search_stream(self, queries, k, chunk):
         """Pipelined form for throughput: the local sweeps of chunk i+1 run in a worker
         thread (the C call releases the GIL) while this thread exchanges and merges

@@ -132,9 +132,34 @@ static void TestOpenCollectionFile(const char *path, uint64_t expect_best, doubl
     CHECK(r.Results[0].ID == expect_best && r.Results[0].Distance == expect_dist);
 }
 
+static void TestComputeAverageDistance()  // collection_test.go:105-142
+{
+    CollectionOptions o;
+    o.DistanceMethod = Euclidean;
+    o.DimensionCount = 3;
+    auto c = Collection::NewCollection(o);
+    uint64_t s = 12345;
+    auto rnd = [&s]() {  // any generator: the reference's draws come from its own math/rand
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        return (double)(s >> 11) / 9007199254740992.0;
+    };
+    for (int i = 0; i < 100; i++) c->AddDocument((uint64_t)i, {rnd() * 100, rnd() * 100, rnd() * 100}, "metadata");
+    const double avg = c->computeAverageDistance(50, [&](int n) { return (int)(rnd() * n); });
+    CHECK(avg > 0);
+    // two fixed documents: the mean over one pair is their reference distance (:12-21 KAT)
+    auto d = Collection::NewCollection(o);
+    d->AddDocument(1, {1, 2, 3}, "");
+    d->AddDocument(2, {4, 5, 6}, "");
+    int turn = 0;
+    CHECK(d->computeAverageDistance(1, [&](int) { return turn++ & 1; }) == 5.196152422706632);
+    CHECK(d->computeAverageDistance(0, [&](int) { return 0; }) == 0.0);
+    CHECK(d->computeAverageDistance(3, [&](int) { return 0; }) == 0.0);  // id1 == id2 every time
+}
+
 int main(int argc, char **argv)
 {
     TestExhaustiveSearch();
+    TestComputeAverageDistance();
     TestCollectionSearch();
     TestCrudAndQuantization();
     if (argc >= 4) TestOpenCollectionFile(argv[1], std::strtoull(argv[2], nullptr, 10), std::strtod(argv[3], nullptr));

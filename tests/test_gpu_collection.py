@@ -213,3 +213,42 @@ def test_collection_from_spanfile_end_to_end(tmp_path, bits, metric):
     assert ((got == o_dist) | (np.isnan(got) & np.isnan(o_dist))).all()
     assert any(r.Metadata == b"rewritten" for r in c.Search(SearchArgs(Offset=0, Limit=n)).Results)
     c.Close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,metric", [(4, 1), (8, 0), (16, 1), (32, 1), (64, 0)])
+def test_pair_distances_and_average_distance(bits, metric):
+    """szg_pair_distances == c.distance(doc1.Vector, doc2.Vector) bit for bit; the
+    computeAverageDistance mirror (collection.go:348-400) sums them in pair order."""
+    dim, n = 37, 600
+    rows = orc.synth_rows(77 + bits, 0, n, dim, bits)
+    c = Collection(CollectionOptions(Name="avg", DistanceMethod=metric, DimensionCount=dim,
+                                     Quantization=bits), devices=[0, 0])
+    c._index.load(rows)
+    for i in range(n):
+        c._row_of[1000 + i] = i
+        c._id_of.append(1000 + i)
+        c._meta.append(b"")
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, n, 300).astype(np.uint64)
+    b = rng.integers(0, n, 300).astype(np.uint64)
+    a[:5] = b[:5]                        # self pairs
+    got = c._index.pair_distances(a, b)
+    vec = [orc.decode_vector(rows[i], dim, bits) for i in range(n)]
+    fn = orc.angular if metric == 1 else orc.euclidean
+    want = np.array([fn(vec[int(x)], vec[int(y)]) for x, y in zip(a, b)])
+    assert np.array_equal(got, want, equal_nan=True)
+
+    draws = [int(x) for x in rng.integers(0, n, 200)]
+    it = iter(draws)
+    avg = c.computeAverageDistance(100, intn=lambda m: next(it))
+    total, count = 0.0, 0
+    for i in range(100):
+        r1, r2 = draws[2 * i], draws[2 * i + 1]
+        if r1 == r2:
+            continue
+        total += fn(vec[r1], vec[r2])
+        count += 1
+    assert avg == total / count
+    assert c.computeAverageDistance(0) == 0.0
+    c.Close()

@@ -38,6 +38,24 @@ for i in range(Q.shape[0]):
     assert (d[i, :c[i]] == ed).all()
 r2, d2, c2, _ = s.search_stream(Q, k, 4)
 assert (r2 == r).all() and (d2 == d).all() and (c2 == c).all()
+
+# radius mode: counts + padded gather; order (incl. ties: 8-bit dim-2 corpus) is the reference's
+def local_radius(q, radius, rows=rows, dim=dim, bits=bits, metric=metric):
+    lo, hi = shard_range(rows.shape[0], rank, world)
+    r, d, _ = orc.search_exact(rows[lo:hi], dim, bits, metric, q, radius=radius)
+    return r + np.uint64(lo), d
+for radius in (0.3, 0.42, 1e-9):
+    r, d = s.search_radius(local_radius, Q[0], radius)
+    er, ed, _ = orc.search_exact(rows, dim, bits, metric, Q[0], radius=radius)
+    assert [int(x) for x in r] == [int(x) for x in er], (rank, radius, len(r), len(er))
+    assert (d == ed).all()
+trows = orc.synth_rows(13, 0, 500, 2, 4)   # many equal distances
+tq = orc.synth_vectors(14, 0, 1, 2)[0]
+def tie_radius(q, radius):
+    return local_radius(q, radius, rows=trows, dim=2, bits=4, metric=0)
+r, d = s.search_radius(tie_radius, tq, 0.8)
+er, ed, _ = orc.search_exact(trows, 2, 4, 0, tq, radius=0.8)
+assert len(er) > 50 and [int(x) for x in r] == [int(x) for x in er] and (d == ed).all()
 dist.barrier()
 if rank == 0:
     print("SHARDED_OK world=%%d" %% world)
