@@ -64,15 +64,16 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def traffic_for(workload, rows_override):
+def traffic_for(workload, rows_override, sweeps_per_launch):
     """HBM bytes per scan launch from the PMC passes recorded in profiles/traffic.json
-    (FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE); None when no pass exists for
-    this exact workload."""
+    (FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE), scaled from the sweeps per
+    launch of the PMC run to this run's; None when no pass exists for this exact workload."""
     if rows_override:
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f)[workload]["hbm_bytes_per_launch"]
+            e = json.load(f)[workload]
+        return int(e["hbm_bytes_per_launch"] / float(e.get("sweeps_per_launch", 1)) * sweeps_per_launch)
     except Exception:
         return None
 
@@ -186,6 +187,7 @@ def main():
         scan_ms = stats["scan_ms"] / max(stats["timed_launches"], 1)
         bytes_per_launch = stats["scan_bytes"] / max(stats["scan_launches"], 1)
         achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        sweeps_per_launch = bytes_per_launch / float(max((hi - lo) * ix.row_bytes, 1))
         out = {
             "metric": "queries/sec, exact scan 1M x 768 cosine k=10" if args.workload == "headline"
             else "queries/sec, exact scan (%s)" % args.workload,
@@ -215,9 +217,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic_for(args.workload, args.rows) if world == 1 else None,
+                "traffic": traffic_for(args.workload, args.rows, sweeps_per_launch) if world == 1 else None,
                 "kernel": "szg::scan_kernel<%d,%d,...>" % (bits, metric),
                 "bytes_per_launch": int(bytes_per_launch),
+                "sweeps_per_launch": round(sweeps_per_launch, 2),
                 "avg_launch_ms": round(scan_ms, 5),
                 "launches": int(stats["timed_launches"]),
             },

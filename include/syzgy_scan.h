@@ -190,8 +190,10 @@ int szg_reset_stats(szg_index *ix);
 
 /*
  * Tunables: "slack" (extra candidates kept beyond k), "blocks_per_cu",
- * "block_threads", "query_batch" (queries one scan launch walks back to back,
- * default 16), "multi_query" (default 1: batches of >= "mq_min" queries on 32-bit
+ * "block_threads", "query_batch" (queries staged, merged, re-ranked and copied back
+ * together, default 16), "queries_per_launch" (sweeps one scan launch walks back to
+ * back, query-major, default 16: no launch gap or chip-wide tail between the sweeps of
+ * a batch; 1 = one launch per sweep), "multi_query" (default 1: batches of >= "mq_min" queries on 32-bit
  * cosine collections share ONE sweep of the corpus, the dot products going to the
  * matrix cores; 0 = every query gets its own sweep), "contexts" (batches in
  * flight per shard), "serialize_scans",

@@ -54,6 +54,13 @@ __host__ __device__ inline size_t query_lds_bytes(int qbits, int r16)
     }
 }
 
+constexpr int kMaxSweepsPerLaunch = 16;
+
+// per-query constants of the integer paths, as the row finish consumes them
+struct QConst {
+    float qscale, qconst, qnorm2, norm_bias;
+};
+
 struct ScanArgs {
     const uint8_t *rows;        // resident mirror: n_rows x pitch bytes, little-endian elements
     uint32_t n_rows;
@@ -68,7 +75,8 @@ struct ScanArgs {
     uint32_t allow_stride;      // words between consecutive queries' allow masks
     // integer paths (4/8-bit rows): query ~ qscale * Q, qconst = sum Q, norm_bias turns
     // the row's integer sums into sum n^2 without the padding; qnorm2 = sum g^2 (euclid)
-    double qscale, qconst, qnorm2, norm_bias;
+    float qscale[kMaxSweepsPerLaunch], qconst[kMaxSweepsPerLaunch], qnorm2[kMaxSweepsPerLaunch];
+    double norm_bias;
     int kp;                     // candidates kept per list (top-k mode)
     uint64_t *block_lists;      // [n_queries][grid][kp] sorted ascending (top-k mode)
     // collect mode (radius search / escalation): every row with key <= thr is appended

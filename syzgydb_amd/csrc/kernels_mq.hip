@@ -29,7 +29,6 @@ namespace szg {
 
 namespace {
 
-constexpr int kWave = 64;
 constexpr int kRingMq = 6;
 
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;

@@ -31,19 +31,15 @@ constexpr int kWave = 64;
 #ifndef SZG_RING
 #define SZG_RING 8
 #endif
-constexpr int kRing = SZG_RING;  // 16-byte loads each lane keeps in flight
+[[maybe_unused]] constexpr int kRing = SZG_RING;  // 16-byte loads each lane keeps in flight
 
 template <int QBITS>
 struct Traits {
-    static constexpr int E = 128 / QBITS;  // elements per 16-byte piece
     using acc_t = float;
-    static constexpr int QB = 4;  // bytes per query element in LDS
 };
 template <>
 struct Traits<64> {
-    static constexpr int E = 2;
     using acc_t = double;
-    static constexpr int QB = 8;
 };
 
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
@@ -204,7 +200,7 @@ struct RowAcc {
             add4(q4[a.map.r16 + j], n[4], n[5], n[6], n[7]);
         }
     }
-    __device__ __forceinline__ float finish(const ScanArgs &a, const Grp &g, bool lead)
+    __device__ __forceinline__ float finish(const QConst &a, const Grp &g, bool lead)
     {
         a0 = grp_sum(a0, g);
         if (METRIC != kCosine) return (float)a0;
@@ -255,7 +251,7 @@ struct RowAcc<8, METRIC> {
             SV = __builtin_amdgcn_sdot4((int)w[d], 0x01010101, SV, false);
         }
     }
-    __device__ __forceinline__ float finish(const ScanArgs &a, const Grp &g, bool lead)
+    __device__ __forceinline__ float finish(const QConst &a, const Grp &g, bool lead)
     {
         // per-lane sums are exact integers below 2^24; combining the planes in float32
         // costs a few roundings (bounded in key_eps) and saves the float64 reduction
@@ -263,10 +259,10 @@ struct RowAcc<8, METRIC> {
         int nrm = 4 * (SQ + SV);
         dot = grp_sum(dot, g);
         nrm = grp_sum(nrm, g);
-        const float norm = (float)nrm + (float)a.norm_bias;
-        const float d2 = fmaf(2.0f, dot, (float)a.qconst);  // sum Q n
-        if (METRIC == kCosine) return -(d2 * (float)a.qscale) * __frsqrt_rn(norm);
-        return fmaf(-2.0f * (float)a.qscale, d2, (float)a.qnorm2 + norm);
+        const float norm = (float)nrm + a.norm_bias;
+        const float d2 = fmaf(2.0f, dot, a.qconst);  // sum Q n
+        if (METRIC == kCosine) return -(d2 * a.qscale) * __frsqrt_rn(norm);
+        return fmaf(-2.0f * a.qscale, d2, a.qnorm2 + norm);
     }
 };
 
@@ -299,17 +295,17 @@ struct RowAcc<4, METRIC> {
             SV = __builtin_amdgcn_sdot8((int)w[d], 0x11111111, SV, false);
         }
     }
-    __device__ __forceinline__ float finish(const ScanArgs &a, const Grp &g, bool lead)
+    __device__ __forceinline__ float finish(const QConst &a, const Grp &g, bool lead)
     {
         float dot = fmaf(65536.0f, (float)D4,
                          fmaf(4096.0f, (float)D3, fmaf(256.0f, (float)D2, fmaf(16.0f, (float)D1, (float)D0))));
         int nrm = 4 * (SQ + SV);
         dot = grp_sum(dot, g);
         nrm = grp_sum(nrm, g);
-        const float norm = (float)nrm + (float)a.norm_bias;
-        const float d2 = fmaf(2.0f, dot, (float)a.qconst);
-        if (METRIC == kCosine) return -(d2 * (float)a.qscale) * __frsqrt_rn(norm);
-        return fmaf(-2.0f * (float)a.qscale, d2, (float)a.qnorm2 + norm);
+        const float norm = (float)nrm + a.norm_bias;
+        const float d2 = fmaf(2.0f, dot, a.qconst);
+        if (METRIC == kCosine) return -(d2 * a.qscale) * __frsqrt_rn(norm);
+        return fmaf(-2.0f * a.qscale, d2, a.qnorm2 + norm);
     }
 };
 
@@ -351,6 +347,7 @@ __global__ __launch_bounds__(256, 4) void scan_kernel(const ScanArgs a)
     wl.init(mylist, COLLECT ? 0 : a.kp, lane);
     __syncthreads();
     const uint64_t *allow_bits = a.allow_bits ? a.allow_bits + (size_t)qi * a.allow_stride : nullptr;
+    const QConst qc{a.qscale[qi], a.qconst[qi], a.qnorm2[qi], (float)a.norm_bias};
 
     // is the row of this lane's group at wave-row `row0` to be scanned?
     auto row_valid = [&](uint64_t row0) -> bool {
@@ -367,7 +364,7 @@ __global__ __launch_bounds__(256, 4) void scan_kernel(const ScanArgs a)
     // One row is done: reduce the group's L lanes, form the key, select.
     const Grp grp_info{L, lig, a.map.pow2 != 0};
     auto finish_row = [&](uint64_t row0, bool valid, RowAcc<QBITS, METRIC> &acc) {
-        float key = acc.finish(a, grp_info, valid && lig == 0);
+        float key = acc.finish(qc, grp_info, valid && lig == 0);
         if (!(key == key)) key = 3.0e38f;       // NaN: worst finite
         if (key > 3.0e38f) key = 3.0e38f;       // +inf (overflow): worst finite
         const uint32_t row = (uint32_t)(row0 + grp);

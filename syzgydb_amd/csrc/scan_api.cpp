@@ -216,6 +216,7 @@ struct szg_index {
     int blocks_per_cu = 4;
     int block_threads = 256;
     int query_batch = 16;     // queries per scan launch
+    int queries_per_launch = 16;  // sweeps one scan launch walks back to back (query-major)
     int force_escalate = 0;   // test hook: treat every first pass as uncertified
     int tie_mode = 0;         // 0: exact full replay on ties/NaN, 1: keep the fast answer
     int serialize_scans = 1;  // scan launches of a shard never overlap each other
@@ -538,9 +539,11 @@ void fill_scan_args(const szg_index *ix, const Shard *sh, const Ctx *c, bool has
     a->query_stride = (uint32_t)ix->qsw_bytes;
     a->query = c->d_qsw + (size_t)slot * ix->qsw_bytes;
     a->n_queries = nq;
-    a->qscale = c->meta[slot].qscale;
-    a->qconst = c->meta[slot].qconst;
-    a->qnorm2 = c->meta[slot].qnorm2;
+    for (int j = 0; j < nq && j < szg::kMaxSweepsPerLaunch; j++) {
+        a->qscale[j] = (float)c->meta[slot + j].qscale;
+        a->qconst[j] = (float)c->meta[slot + j].qconst;
+        a->qnorm2[j] = (float)c->meta[slot + j].qnorm2;
+    }
     a->norm_bias = ix->norm_bias;
 }
 
@@ -571,8 +574,10 @@ int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg
         }
     }
     std::lock_guard<std::mutex> lk(ix->stats_mu);
+    uint64_t sweeps = 0;
+    for (const szg::ScanArgs &x : a) sweeps += (uint64_t)x.n_queries;
     ix->stats.scan_launches += n;
-    ix->stats.scan_bytes += (uint64_t)n * sh->n_rows * (uint64_t)ix->row_bytes;
+    ix->stats.scan_bytes += sweeps * sh->n_rows * (uint64_t)ix->row_bytes;
     return SZG_OK;
 }
 
@@ -596,11 +601,13 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
     rc = ensure_host(&c->h_out, &c->h_out_cap, (size_t)nq * kp);
     if (rc) return rc;
 
-    std::vector<szg::ScanArgs> args(nq);
-    for (int j = 0; j < nq; j++) {  // one sweep per query, results side by side
-        fill_scan_args(ix, sh, c, has_allow, j, 1, &args[j]);
-        args[j].kp = kp;
-        args[j].block_lists = c->d_lists_a + (size_t)j * g.grid * kp;
+    const int qpl = std::max(1, ix->queries_per_launch);
+    std::vector<szg::ScanArgs> args((nq + qpl - 1) / qpl);
+    for (int j = 0; j < nq; j += qpl) {  // one sweep per query, results side by side
+        szg::ScanArgs &a = args[j / qpl];
+        fill_scan_args(ix, sh, c, has_allow, j, std::min(qpl, nq - j), &a);
+        a.kp = kp;
+        a.block_lists = c->d_lists_a + (size_t)j * g.grid * kp;
     }
     rc = launch_scans_chained(ix, sh, c, args, g);
     if (rc) return rc;
@@ -1797,6 +1804,10 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
         if (value != 64 && value != 128 && value != 256)
             return fail(SZG_E_INVALID, "block_threads must be 64/128/256");
         ix->block_threads = (int)value;
+    } else if (n == "queries_per_launch") {
+        if (value < 1 || value > szg::kMaxSweepsPerLaunch)
+            return fail(SZG_E_INVALID, "queries_per_launch out of range");
+        ix->queries_per_launch = (int)value;
     } else if (n == "query_batch") {
         if (value < 1 || value > kMaxBatch) return fail(SZG_E_INVALID, "query_batch out of range");
         ix->query_batch = (int)value;

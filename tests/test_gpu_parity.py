@@ -193,3 +193,28 @@ def test_distances_for_row_lists(bits, metric):
             assert (got == want[pick.astype(int)]).all()
             with pytest.raises(Exception):
                 ix.distances(q, [n])
+
+
+@pytest.mark.parametrize("qpl", [1, 5, 16])
+@pytest.mark.parametrize("bits,metric", [(4, 0), (4, 1), (8, 0), (8, 1), (16, 0), (32, 1), (64, 0)])
+def test_query_major_launches(bits, metric, qpl):
+    """One scan launch walks several queries' sweeps back to back ("queries_per_launch"):
+    per-query constants of the integer paths, per-query filter masks and result slots
+    must follow the query, whatever the grouping."""
+    dim, n, k, nq = 40, 6000, 7, 37
+    rows = orc.synth_rows(SEED + 300 + bits, 0, n, dim, bits)
+    queries = orc.synth_vectors(SEED + 301, 0, nq, dim)
+    queries[3] *= 40.0          # very different scales -> different qscale per query
+    queries[4] *= 1e-3
+    rng = np.random.default_rng(8)
+    allow = rng.random((nq, n)) < 0.5
+    with ScanIndex(dim, bits, metric) as ix:
+        ix.load(rows)
+        ix.set_option("multi_query", 0)
+        ix.set_option("queries_per_launch", qpl)
+        for masks in (None, allow):
+            r, d, c = ix.search_topk(queries, k, allow=masks)
+            for qi in range(nq):
+                o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, queries[qi], k=k,
+                                                     allow=None if masks is None else masks[qi].astype(np.uint8))
+                assert_same(r[qi, : c[qi]], d[qi, : c[qi]], o_rows, o_dist)
