@@ -189,7 +189,8 @@ int szg_get_stats(szg_index *ix, szg_stats *out);
 int szg_reset_stats(szg_index *ix);
 
 /*
- * Tunables: "slack" (extra candidates kept beyond k), "blocks_per_cu",
+ * Tunables: "slack" (extra candidates kept beyond k), "blocks_per_cu" (0 = default:
+ * chosen from the row format, 8-16 waves per CU),
  * "block_threads", "query_batch" (queries staged, merged, re-ranked and copied back
  * together, default 16), "queries_per_launch" (sweeps one scan launch walks back to
  * back, query-major, default 16: no launch gap or chip-wide tail between the sweeps of

@@ -31,6 +31,9 @@ constexpr int kWave = 64;
 #ifndef SZG_RING
 #define SZG_RING 8
 #endif
+#ifndef SZG_MIN_BLOCKS
+#define SZG_MIN_BLOCKS 4  // 256-thread blocks per CU the register budget allows
+#endif
 [[maybe_unused]] constexpr int kRing = SZG_RING;  // 16-byte loads each lane keeps in flight
 
 template <int QBITS>
@@ -312,7 +315,7 @@ struct RowAcc<4, METRIC> {
 // ---- the scan ---------------------------------------------------------------
 
 template <int QBITS, int METRIC, int D, bool COLLECT, bool MASKED, bool NT>
-__global__ __launch_bounds__(256, 4) void scan_kernel(const ScanArgs a)
+__global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArgs a)
 {
     extern __shared__ __align__(16) uint8_t smem[];
 

@@ -213,7 +213,7 @@ struct szg_index {
     // tunables
     int slack_min = 16;
     int n_ctx = 3;
-    int blocks_per_cu = 4;
+    int blocks_per_cu = 0;    // 0 = choose from the row format (scan_geometry)
     int block_threads = 256;
     int query_batch = 16;     // queries per scan launch
     int queries_per_launch = 16;  // sweeps one scan launch walks back to back (query-major)
@@ -489,7 +489,21 @@ LaunchGeom scan_geometry(const szg_index *ix, const Shard *sh, int kp)
     const int nwaves = block / 64;
     const uint64_t rows_per_block = (uint64_t)nwaves * ix->map.gpw;
     uint64_t need = (sh->n_rows + rows_per_block - 1) / rows_per_block;
-    uint64_t grid = (uint64_t)sh->cu_count * ix->blocks_per_cu;
+    int waves_per_cu = ix->blocks_per_cu * nwaves;
+    if (ix->blocks_per_cu <= 0) {
+        // Measured on MI355X (scripts/dev_bpc.sh, scripts/readbw): HBM streams fastest with
+        // about 6 MB of reads in flight -- 8 waves per CU when the row walk is pure float
+        // FMAs; more requests in flight only lengthen the DRAM queues.  The integer /
+        // 16-bit decodes and short rows need 12 waves to hide their ALU work, the
+        // LDS-resident candidate lists (kp > 64) 16.
+        if (kp > 64)
+            waves_per_cu = 16;
+        else if (ix->bits >= 32 && ix->row_bytes >= 1024)
+            waves_per_cu = 8;
+        else
+            waves_per_cu = 12;
+    }
+    uint64_t grid = (uint64_t)sh->cu_count * (uint64_t)std::max(1, waves_per_cu / nwaves);
     if (need < grid) grid = need;
     if (grid < 1) grid = 1;
     return LaunchGeom{(int)grid, block};
@@ -1798,7 +1812,7 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
         if (value < 0 || value > 4096) return fail(SZG_E_INVALID, "slack out of range");
         ix->slack_min = (int)value;
     } else if (n == "blocks_per_cu") {
-        if (value < 1 || value > 16) return fail(SZG_E_INVALID, "blocks_per_cu out of range");
+        if (value < 0 || value > 16) return fail(SZG_E_INVALID, "blocks_per_cu out of range");
         ix->blocks_per_cu = (int)value;
     } else if (n == "block_threads") {
         if (value != 64 && value != 128 && value != 256)
