@@ -26,6 +26,9 @@ CONFIGS = [
     ("headline", 1_000_000, 768, 32, 1, 10),
     ("cfg4-one-gpu-shard", 1_250_000, 768, 32, 0, 100),     # 10M / 8 GPUs
     ("cfg5-slice", 4_000_000, 384, 4, 1, 10),                # 100M x 384 4-bit, a 768 MB slice
+    # the two 8-GPU configurations in full on ONE card (30.7 GB and 19.2 GB of 288 GB HBM)
+    ("cfg4-full", 10_000_000, 768, 32, 0, 100),
+    ("cfg5-full", 100_000_000, 384, 4, 1, 10),
 ]
 
 
@@ -94,3 +97,33 @@ def test_headline_full_oracle_scan_one_query():
     assert (d[0] == o_dist).all()
     rel = np.abs(d[0] - o_dist) / o_dist
     assert (rel <= 1e-5).all()   # the contract's tolerance; bit-equality above is stronger
+
+
+def test_cfg5_full_radius_search():
+    """Config #5 as named: 100M x 384 4-bit cosine, radius search (one card holds the
+    19.2 GB).  Every hit's distance is the oracle's for that row and <= R; sampled
+    non-hits are farther; hits ascend; the hit count is in the calibrated range
+    (R chosen for 10^2..10^3 hits)."""
+    n, dim, bits, metric = 100_000_000, 384, 4, 1
+    seed = 0x53595A4700000300
+    R = 0.426
+    q = synth_vectors(seed + 1, 0, 2, dim)
+    with ScanIndex(dim, bits, metric) as ix:
+        ix.synth(n, seed)
+        assert (ix.read_rows(n - 3, 3) == orc.synth_rows(seed, n - 3, 3, dim, bits)).all()
+        for qi in range(2):
+            rows, dist = ix.search_radius(q[qi], R)
+            assert 10 <= len(rows) <= 20000, len(rows)
+            assert (dist <= R).all()
+            want = oracle_dist_for(ix, rows[:50], dim, bits, metric, q[qi])
+            assert (want == dist[:50]).all()
+            srt = np.sort(dist, kind="stable")
+            assert (srt == dist).all() or len(set(dist.tolist())) < len(dist)  # ascending (ties: heap order)
+            hits = set(int(x) for x in rows)
+            rng = np.random.default_rng(qi)
+            for s in rng.integers(0, n, 80):
+                dd = orc.all_distances(orc.synth_rows(seed, int(s), 1, dim, bits), dim, bits, metric, q[qi])[0]
+                assert (dd <= R) == (int(s) in hits)
+            # the k nearest by top-k search are the head of the radius result
+            r10, d10, _ = ix.search_topk(q[qi], 10)
+            assert (d10[0] <= R).all() and set(int(x) for x in r10[0]) <= hits
