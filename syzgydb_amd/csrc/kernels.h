@@ -77,6 +77,7 @@ struct ScanArgs {
     // the row's integer sums into sum n^2 without the padding; qnorm2 = sum g^2 (euclid)
     float qscale[kMaxSweepsPerLaunch], qconst[kMaxSweepsPerLaunch], qnorm2[kMaxSweepsPerLaunch];
     double norm_bias;
+    int no_shape_kernels;       // tuning hook: always take the any-shape kernel
     int kp;                     // candidates kept per list (top-k mode)
     uint64_t *block_lists;      // [n_queries][grid][kp] sorted ascending (top-k mode)
     // collect mode (radius search / escalation): every row with key <= thr is appended

@@ -162,7 +162,7 @@ struct RowAcc {
             a0 = fmaf(d3, d3, a0);
         }
     }
-    __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const ScanArgs &a)
+    __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const int r16, const int dim)
     {
         if (QBITS == 32) {  // resident elements are little-endian IEEE floats
             const float4 qv = reinterpret_cast<const float4 *>(q)[j];
@@ -193,14 +193,14 @@ struct RowAcc {
                 n[2 * d + 1] = fmaf((float)(w[d] >> 16), 2.0f, -65535.0f);
             }
             const int e0 = j * 8;
-            if (e0 + 8 > a.dim) {  // tail piece: padding decodes to -maxInt, mask it
+            if (e0 + 8 > dim) {  // tail piece: padding decodes to -maxInt, mask it
 #pragma unroll
                 for (int i = 0; i < 8; i++)
-                    if (e0 + i >= a.dim) n[i] = 0.0f;
+                    if (e0 + i >= dim) n[i] = 0.0f;
             }
             const float4 *q4 = reinterpret_cast<const float4 *>(q);
             add4(q4[j], n[0], n[1], n[2], n[3]);
-            add4(q4[a.map.r16 + j], n[4], n[5], n[6], n[7]);
+            add4(q4[r16 + j], n[4], n[5], n[6], n[7]);
         }
     }
     __device__ __forceinline__ float finish(const QConst &a, const Grp &g, bool lead)
@@ -235,10 +235,9 @@ template <int METRIC>
 struct RowAcc<8, METRIC> {
     int H, M, L, SQ, SV;
     __device__ __forceinline__ void reset() { H = M = L = SQ = SV = 0; }
-    __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const ScanArgs &a)
+    __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const int r16, const int dim)
     {
         const uint4 *q4 = reinterpret_cast<const uint4 *>(q);
-        const int r16 = a.map.r16;
 #ifdef SZG_X_NOQ
         const uint4 qh = raw, qm = raw, ql = raw;
         (void)q4; (void)r16;
@@ -283,10 +282,9 @@ template <int METRIC>
 struct RowAcc<4, METRIC> {
     int D0, D1, D2, D3, D4, SQ, SV;
     __device__ __forceinline__ void reset() { D0 = D1 = D2 = D3 = D4 = SQ = SV = 0; }
-    __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const ScanArgs &a)
+    __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const int r16, const int dim)
     {
         const uint4 *q4 = reinterpret_cast<const uint4 *>(q);
-        const int r16 = a.map.r16;
 #ifdef SZG_X_NOQ
         const uint4 p0 = raw, p1 = raw, p2 = raw, p3 = raw, p4 = raw;
         (void)q4; (void)r16;
@@ -328,21 +326,25 @@ struct RowAcc<4, METRIC> {
 
 // ---- the scan ---------------------------------------------------------------
 
-template <int QBITS, int METRIC, int D, bool COLLECT, bool MASKED, bool NT>
+// LL, PP > 0: the row shape (lanes per row, pieces per lane) is a compile-time constant
+// -- the common dims (384, 768, ...) get kernels whose addressing, reductions and query
+// offsets are folded; 0, 0 = any shape, from a.map.
+template <int QBITS, int METRIC, int D, bool COLLECT, bool MASKED, bool NT, int LL = 0, int PP = 0>
 __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArgs a)
 {
+    static_assert((LL == 0) == (PP == 0), "shape is fixed as a whole or not at all");
     extern __shared__ __align__(16) uint8_t smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
     const int nwaves = blockDim.x >> 6;
-    const int r16 = a.map.r16;
+    const int r16 = LL ? LL * PP : a.map.r16;
     const int qbytes = (int)query_lds_bytes(QBITS, r16);  // multiple of 16
 
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem + qbytes);
     uint64_t *mylist = lists + (size_t)wave * a.kp;
-    const int L = a.map.L, P = a.map.P, gpw = a.map.gpw;
+    const int L = LL ? LL : a.map.L, P = PP ? PP : a.map.P, gpw = LL ? kWave / LL : a.map.gpw;
     const int grp = lane / L;
     const int lig = lane - grp * L;
     const bool active = grp < gpw;
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
     };
 
     // One row is done: reduce the group's L lanes, form the key, select.
-    const Grp grp_info{L, lig, a.map.pow2 != 0};
+    const Grp grp_info{L, lig, LL ? true : a.map.pow2 != 0};
     auto finish_row = [&](uint64_t row0, bool valid, RowAcc<QBITS, METRIC> &acc) {
         float key = acc.finish(qc, grp_info, valid && lig == 0);
         if (!(key == key)) key = 3.0e38f;       // NaN: worst finite
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
     // range.  No predicates at all: pointer-increment addressing, unconditional
     // accumulation.  Covers all but (at most) the wave's last row step.
     uint64_t it_dense = 0;
-    if (!MASKED && a.map.dense && row_first + (uint64_t)gpw <= a.n_rows)
+    if (!MASKED && (LL || a.map.dense) && row_first + (uint64_t)gpw <= a.n_rows)
         it_dense = (a.n_rows - (uint64_t)gpw - row_first) / stride + 1;
     uint64_t crow0 = row_first;
     if (it_dense) {
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
 #define SZG_DN_CONSUME(u)                                                               \
     {                                                                                   \
         const u32x4 v_ = ring[u];                                                       \
-        acc.piece(make_uint4(v_.x, v_.y, v_.z, v_.w), smem, jc, a);                     \
+        acc.piece(make_uint4(v_.x, v_.y, v_.z, v_.w), smem, jc, r16, a.dim);                     \
         if (++cp == P) {                                                                \
             finish_row(crow0, true, acc);                                               \
             acc.reset();                                                                \
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
         if (cp == 0) cvalid = ok_; /* piece 0 of the group's first lane is in range */  \
         if (ok_) {                                                                      \
             const u32x4 v_ = ring[u];                                                   \
-            acc.piece(make_uint4(v_.x, v_.y, v_.z, v_.w), smem, j_, a);                 \
+            acc.piece(make_uint4(v_.x, v_.y, v_.z, v_.w), smem, j_, r16, a.dim);                 \
         }                                                                               \
         if (++cp == P) {                                                                \
             finish_row(crow0, cvalid, acc);                                             \
@@ -663,10 +665,36 @@ __global__ __launch_bounds__(1024) void merge_kernel(const uint64_t *in, int n_l
 #endif  // SZG_QBITS == 0
 
 #if SZG_QBITS != 0
+// Row shapes that get their own kernels: the 4-bit path is instruction-bound, and folding
+// the shape (P = 3 with L = 4 / 8: 384 / 768 dims) buys 5-11 % there; measured no gain for
+// the wider element types (scripts/dev_shape.sh), which therefore keep the any-shape kernel.
+template <int QBITS> struct Shapes { [[maybe_unused]] static constexpr int LA = 0; [[maybe_unused]] static constexpr int LB = 0; };
+template <> struct Shapes<4> { [[maybe_unused]] static constexpr int LA = 4; [[maybe_unused]] static constexpr int LB = 8; };
+
+template <int QBITS, int METRIC, bool COLLECT, int LL>
+void launch_shaped(const ScanArgs &a, dim3 g, dim3 b, size_t lds, hipStream_t stream)
+{
+    hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, COLLECT, false, (LL >= 8), LL, 3>), g, b, lds, stream, a);
+}
+
 template <int QBITS, int METRIC, bool COLLECT, bool MASKED>
 hipError_t launch_scan_qmcm(const ScanArgs &a, int grid, int block, size_t lds, hipStream_t stream)
 {
     const dim3 g(grid), b(block);
+    if constexpr (!MASKED) {
+        if (a.map.dense && a.map.P == 3 && a.map.L * a.map.gpw == kWave && !a.no_shape_kernels) {
+            if constexpr (Shapes<QBITS>::LA != 0)
+                if (a.map.L == Shapes<QBITS>::LA) {
+                    launch_shaped<QBITS, METRIC, COLLECT, Shapes<QBITS>::LA>(a, g, b, lds, stream);
+                    return hipGetLastError();
+                }
+            if constexpr (Shapes<QBITS>::LB != 0)
+                if (a.map.L == Shapes<QBITS>::LB) {
+                    launch_shaped<QBITS, METRIC, COLLECT, Shapes<QBITS>::LB>(a, g, b, lds, stream);
+                    return hipGetLastError();
+                }
+        }
+    }
     if (a.map.L >= 8)  // whole lines per group per load: stream past the caches
         hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, COLLECT, MASKED, true>), g, b, lds, stream, a);
     else

@@ -216,6 +216,7 @@ struct szg_index {
     int blocks_per_cu = 0;    // 0 = choose from the row format (scan_geometry)
     int block_threads = 256;
     int query_batch = 16;     // queries per scan launch
+    int shape_kernels = 1;    // use the row-shape-specialised scan kernels where they exist
     int queries_per_launch = 16;  // sweeps one scan launch walks back to back (query-major)
     int force_escalate = 0;   // test hook: treat every first pass as uncertified
     int tie_mode = 0;         // 0: exact full replay on ties/NaN, 1: keep the fast answer
@@ -559,6 +560,7 @@ void fill_scan_args(const szg_index *ix, const Shard *sh, const Ctx *c, bool has
         a->qnorm2[j] = (float)c->meta[slot + j].qnorm2;
     }
     a->norm_bias = ix->norm_bias;
+    a->no_shape_kernels = ix->shape_kernels ? 0 : 1;
 }
 
 // Launch the fused scan for each of the batch's queries (n = a->size()) as the
@@ -1818,6 +1820,8 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
         if (value != 64 && value != 128 && value != 256)
             return fail(SZG_E_INVALID, "block_threads must be 64/128/256");
         ix->block_threads = (int)value;
+    } else if (n == "shape_kernels") {
+        ix->shape_kernels = value != 0;
     } else if (n == "queries_per_launch") {
         if (value < 1 || value > szg::kMaxSweepsPerLaunch)
             return fail(SZG_E_INVALID, "queries_per_launch out of range");

@@ -218,3 +218,25 @@ def test_query_major_launches(bits, metric, qpl):
                 o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, queries[qi], k=k,
                                                      allow=None if masks is None else masks[qi].astype(np.uint8))
                 assert_same(r[qi, : c[qi]], d[qi, : c[qi]], o_rows, o_dist)
+
+
+@pytest.mark.parametrize("dim", [384, 768])
+@pytest.mark.parametrize("metric", [SZG_EUCLIDEAN, SZG_COSINE])
+def test_shape_specialised_kernels_match_any_shape(dim, metric):
+    """4-bit rows of 384 / 768 dims take row-shape-specialised kernels (top-k and collect);
+    both kernels must give the oracle's answer."""
+    bits, n, k = 4, 30000, 10
+    rows = orc.synth_rows(SEED + 400 + dim, 0, n, dim, bits)
+    queries = orc.synth_vectors(SEED + 401, 0, 3, dim)
+    with ScanIndex(dim, bits, metric) as ix:
+        ix.load(rows)
+        for shaped in (1, 0):
+            ix.set_option("shape_kernels", shaped)
+            r, d, c = ix.search_topk(queries, k)
+            for qi in range(3):
+                o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, queries[qi], k=k)
+                assert_same(r[qi, : c[qi]], d[qi, : c[qi]], o_rows, o_dist)
+            radius = float(d[0, k - 1])
+            rr, dd = ix.search_radius(queries[0], radius)
+            o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, queries[0], radius=radius)
+            assert_same(rr, dd, o_rows, o_dist)
