@@ -251,6 +251,10 @@ struct RowAcc<8, METRIC> {
         const uint32_t l[4] = {ql.x, ql.y, ql.z, ql.w};
 #pragma unroll
         for (int d = 0; d < 4; d++) {
+#ifdef SZG_X_NODOT
+            H += (int)(w[d] ^ h[d] ^ m[d] ^ l[d]);
+            continue;
+#endif
             H = __builtin_amdgcn_sdot4((int)h[d], (int)w[d], H, false);
             M = __builtin_amdgcn_sdot4((int)m[d], (int)w[d], M, false);
             L = __builtin_amdgcn_sdot4((int)l[d], (int)w[d], L, false);
@@ -299,6 +303,10 @@ struct RowAcc<4, METRIC> {
                        q4w[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
         for (int d = 0; d < 4; d++) {
+#ifdef SZG_X_NODOT
+            D0 += (int)(w[d] ^ q0[d] ^ q1[d] ^ q2[d] ^ q3[d] ^ q4w[d]);
+            continue;
+#endif
             D0 = __builtin_amdgcn_sdot8((int)q0[d], (int)w[d], D0, false);
             D1 = __builtin_amdgcn_sdot8((int)q1[d], (int)w[d], D1, false);
             D2 = __builtin_amdgcn_sdot8((int)q2[d], (int)w[d], D2, false);
