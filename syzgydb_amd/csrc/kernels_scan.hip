@@ -673,34 +673,39 @@ __global__ __launch_bounds__(1024) void merge_kernel(const uint64_t *in, int n_l
 #endif  // SZG_QBITS == 0
 
 #if SZG_QBITS != 0
-// Row shapes that get their own kernels: the 4-bit path is instruction-bound, and folding
-// the shape (P = 3 with L = 4 / 8: 384 / 768 dims) buys 5-11 % there; measured no gain for
-// the wider element types (scripts/dev_shape.sh), which therefore keep the any-shape kernel.
-template <int QBITS> struct Shapes { [[maybe_unused]] static constexpr int LA = 0; [[maybe_unused]] static constexpr int LB = 0; };
-template <> struct Shapes<4> { [[maybe_unused]] static constexpr int LA = 4; [[maybe_unused]] static constexpr int LB = 8; };
+// Row shapes (lanes per row, pieces per lane) that get their own kernels.  Only the 4-bit
+// rows gain from it: their rows are short (3 pieces per lane at 384 and 768 dims, choose_map
+// in scan_api.cpp), so the shape-dependent bookkeeping around each row finish weighs 5-11 %.
+// The shapes of 8/16/32-bit rows at those widths, (8,3) (8,6) (8,12) (8,24), measured no gain
+// (scripts/dev_shape.sh) and stay on the any-shape kernel.
+template <int QBITS> struct Shapes {
+    [[maybe_unused]] static constexpr int LA = 0, PA = 0, LB = 0, PB = 0;
+};
+template <> struct Shapes<4> {
+    [[maybe_unused]] static constexpr int LA = 4, PA = 3, LB = 8, PB = 3;
+};
 
-template <int QBITS, int METRIC, bool COLLECT, int LL>
+template <int QBITS, int METRIC, bool COLLECT, int LL, int PP>
 void launch_shaped(const ScanArgs &a, dim3 g, dim3 b, size_t lds, hipStream_t stream)
 {
-    hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, COLLECT, false, (LL >= 8), LL, 3>), g, b, lds, stream, a);
+    hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, COLLECT, false, (LL >= 8), LL, PP>), g, b, lds, stream, a);
 }
 
 template <int QBITS, int METRIC, bool COLLECT, bool MASKED>
 hipError_t launch_scan_qmcm(const ScanArgs &a, int grid, int block, size_t lds, hipStream_t stream)
 {
     const dim3 g(grid), b(block);
-    if constexpr (!MASKED) {
-        if (a.map.dense && a.map.P == 3 && a.map.L * a.map.gpw == kWave && !a.no_shape_kernels) {
-            if constexpr (Shapes<QBITS>::LA != 0)
-                if (a.map.L == Shapes<QBITS>::LA) {
-                    launch_shaped<QBITS, METRIC, COLLECT, Shapes<QBITS>::LA>(a, g, b, lds, stream);
-                    return hipGetLastError();
-                }
-            if constexpr (Shapes<QBITS>::LB != 0)
-                if (a.map.L == Shapes<QBITS>::LB) {
-                    launch_shaped<QBITS, METRIC, COLLECT, Shapes<QBITS>::LB>(a, g, b, lds, stream);
-                    return hipGetLastError();
-                }
+    if constexpr (!MASKED && Shapes<QBITS>::LA != 0) {
+        using S = Shapes<QBITS>;
+        if (a.map.dense && a.map.L * a.map.gpw == kWave && !a.no_shape_kernels) {
+            if (a.map.L == S::LA && a.map.P == S::PA) {
+                launch_shaped<QBITS, METRIC, COLLECT, S::LA, S::PA>(a, g, b, lds, stream);
+                return hipGetLastError();
+            }
+            if (a.map.L == S::LB && a.map.P == S::PB) {
+                launch_shaped<QBITS, METRIC, COLLECT, S::LB, S::PB>(a, g, b, lds, stream);
+                return hipGetLastError();
+            }
         }
     }
     if (a.map.L >= 8)  // whole lines per group per load: stream past the caches
