@@ -174,7 +174,7 @@ func (m *gpuMirror) searchExact(c *Collection, args SearchArgs) (results []Searc
 	var dist []C.double
 	n := 0
 	if args.Radius > 0 { // K is ignored (collection.go:598-605)
-		capacity := 1024
+		capacity := 1 << 16 // a truncated call costs a second sweep
 		for {
 			rows = make([]C.uint64_t, capacity)
 			dist = make([]C.double, capacity)
@@ -214,4 +214,48 @@ func (m *gpuMirror) searchExact(c *Collection, args SearchArgs) (results []Searc
 	}
 	_ = keep
 	return results, true
+}
+
+// distancesTo is the gather-by-row primitive for candidate generators: the
+// reference's float64 c.distance(query, doc.Vector) for each listed document, bit
+// for bit (szg_distances).  The LSH path (lshtree.go:283-351) can collect a leaf's
+// ids and score them in one call instead of one consider() per id.
+func (m *gpuMirror) distancesTo(query []float64, ids []uint64) ([]float64, bool) {
+	if m.dirty || len(ids) == 0 {
+		return nil, false
+	}
+	rows := make([]C.uint64_t, len(ids))
+	for i, id := range ids {
+		row, ok := m.rowOf[id]
+		if !ok {
+			return nil, false
+		}
+		rows[i] = C.uint64_t(row)
+	}
+	out := make([]float64, len(ids))
+	rc := C.szg_distances(m.h, (*C.double)(unsafe.Pointer(&query[0])), &rows[0], C.uint64_t(len(rows)),
+		(*C.double)(unsafe.Pointer(&out[0])))
+	return out, rc == C.SZG_OK
+}
+
+// pairDistances is c.distance(doc1.Vector, doc2.Vector) for stored documents
+// (szg_pair_distances): computeAverageDistance (collection.go:348-400) keeps its
+// rand.Intn pair selection and its in-order sum, and gets the distances from here.
+func (m *gpuMirror) pairDistances(a, b []uint64) ([]float64, bool) {
+	if m.dirty || len(a) == 0 || len(a) != len(b) {
+		return nil, false
+	}
+	ra := make([]C.uint64_t, len(a))
+	rb := make([]C.uint64_t, len(b))
+	for i := range a {
+		x, okA := m.rowOf[a[i]]
+		y, okB := m.rowOf[b[i]]
+		if !okA || !okB {
+			return nil, false
+		}
+		ra[i], rb[i] = C.uint64_t(x), C.uint64_t(y)
+	}
+	out := make([]float64, len(a))
+	rc := C.szg_pair_distances(m.h, &ra[0], &rb[0], C.uint64_t(len(a)), (*C.double)(unsafe.Pointer(&out[0])))
+	return out, rc == C.SZG_OK
 }
