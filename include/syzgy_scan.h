@@ -194,9 +194,9 @@ int szg_reset_stats(szg_index *ix);
  * "block_threads", "query_batch" (queries staged, merged, re-ranked and copied back
  * together, default 16), "queries_per_launch" (sweeps one scan launch walks back to
  * back, query-major, default 16: no launch gap or chip-wide tail between the sweeps of
- * a batch; 1 = one launch per sweep), "multi_query" (default 1: batches of >= "mq_min" queries on 32-bit
- * cosine collections share ONE sweep of the corpus, the dot products going to the
- * matrix cores; 0 = every query gets its own sweep), "contexts" (batches in
+ * a batch; 1 = one launch per sweep), "multi_query" (default 1: batches of >= "mq_min" queries on
+ * 4/8/16/32-bit collections, either metric, share ONE sweep of the corpus, the dot
+ * products going to the matrix cores; 0 = every query gets its own sweep), "contexts" (batches in
  * flight per shard), "serialize_scans",
  * "tie_mode" (0 = default: when two of the best k+1 distances
  * are exactly equal, or one is NaN, the reference's output depends on its whole

@@ -105,12 +105,15 @@ struct MqArgs {
     int dim;
     const void *queries;      // device: LDS image [piece][query block][group of 4][16 queries][4 floats]
     int n_queries;            // <= 16 * query blocks
-    float *keys;              // out: [n_queries][key_stride] ranking keys (-cos)
+    int metric;               // kCosine: image = q/|q|, key = -cos.  kEuclidean: image = the scan's
+                              // prepared query (maxInt*q for quantized rows), key = |n - image|^2
+    float qnorm2[48];         // euclid: |image_q|^2 per query
+    float *keys;              // out: [n_queries][key_stride] ranking keys
     size_t key_stride;        // floats, multiple of 4, >= n_rows
     const uint8_t *zero16;    // 16 zero bytes (address idle lanes read)
 };
 size_t mq_lds_bytes(int qbits, int r16, int nb);
-hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStream_t stream);
+hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStream_t stream);  // a.metric picks the key
 hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_rows,
                             const uint64_t *live_bits, const uint64_t *allow_bits,
                             uint32_t allow_stride, int kp, int n_queries, int blocks_per_query,

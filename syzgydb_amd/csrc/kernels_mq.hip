@@ -74,7 +74,7 @@ __device__ __forceinline__ void decode_dword(uint32_t w, int e0, int dim, float 
 }
 
 // LDS image of the batch: [piece j][query block][group of 4 elements][query 16][4 floats]
-template <int NB, int QBITS>
+template <int NB, int QBITS, int METRIC>
 __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 {
     constexpr int E = 128 / QBITS;  // elements per 16-byte piece
@@ -185,8 +185,13 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int q = b * 16 + c * 4 + r;
-                    float key = -acc[b][r] * inv;
-                    if (nrm == 0.f) key = nz ? -2.0f : 1.0f;  // zero row: distance 1.0 (collection.go:828-830)
+                    float key;
+                    if (METRIC == kCosine) {
+                        key = -acc[b][r] * inv;
+                        if (nrm == 0.f) key = nz ? -2.0f : 1.0f;  // zero row: distance 1.0 (collection.go:828-830)
+                    } else {  // |x - q|^2 = |x|^2 - 2 x.q + |q|^2 (the error bound knows: key_eps, mq)
+                        key = fmaf(-2.0f, acc[b][r], nrm + a.qnorm2[q < 48 ? q : 47]);
+                    }
                     if (!(key == key)) key = 3.0e38f;
                     if (key > 3.0e38f) key = 3.0e38f;
                     if (q < a.n_queries) a.keys[(size_t)q * a.key_stride + row] = key;
@@ -279,22 +284,28 @@ __global__ __launch_bounds__(256) void mq_select_kernel(const float *keys, size_
 size_t mq_lds_bytes(int qbits, int r16, int nb) { return (size_t)r16 * nb * (128 / qbits) * 16 * 4; }
 
 namespace {
-template <int NB, int QBITS>
+template <int NB, int QBITS, int METRIC>
 hipError_t launch_mq_score_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mq_score_kernel<NB, QBITS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mq_score_kernel<NB, QBITS, METRIC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mq_score_kernel<NB, QBITS>), dim3(grid), dim3(1024), lds, stream, a);
+    hipLaunchKernelGGL((mq_score_kernel<NB, QBITS, METRIC>), dim3(grid), dim3(1024), lds, stream, a);
     return hipGetLastError();
+}
+template <int NB, int QBITS>
+hipError_t launch_mq_score_m(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
+{
+    if (a.metric == kCosine) return launch_mq_score_t<NB, QBITS, kCosine>(a, grid, lds, stream);
+    return launch_mq_score_t<NB, QBITS, kEuclidean>(a, grid, lds, stream);
 }
 template <int QBITS>
 hipError_t launch_mq_score_q(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
 {
     switch (nb) {
-    case 1: return launch_mq_score_t<1, QBITS>(a, grid, lds, stream);
-    case 2: return launch_mq_score_t<2, QBITS>(a, grid, lds, stream);
-    case 3: return launch_mq_score_t<3, QBITS>(a, grid, lds, stream);
+    case 1: return launch_mq_score_m<1, QBITS>(a, grid, lds, stream);
+    case 2: return launch_mq_score_m<2, QBITS>(a, grid, lds, stream);
+    case 3: return launch_mq_score_m<3, QBITS>(a, grid, lds, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -130,7 +130,8 @@ struct QMeta {
     double m1 = 0;      // sum q_i^2 of the caller's query (zero-query detection)
     double qscale = 0;  // integer paths: prepared query ~ qscale * Q
     double qconst = 0;  // integer paths: sum Q_i
-    double qnorm2 = 0;  // integer paths, euclid: sum g_i^2
+    double qnorm2 = 0;  // euclid: sum g_i^2 of the prepared query g
+    bool mq = false;    // answered by the shared float32 MFMA sweep (its own error bound)
 };
 
 struct Cand {
@@ -357,6 +358,18 @@ void prep_query(const szg_index *ix, const double *q, uint8_t *out_sw, QMeta *me
 double key_eps(const szg_index *ix, double key, const QMeta &m)
 {
     const double k = std::fabs(key);
+    if (m.mq) {
+        // shared sweep: float32 everywhere (quantized rows decode to exact integers first).
+        // cosine: dot and norm each carry <= (dim+16) u relative error.  euclid: the key is
+        // |x|^2 - 2 x.g + |g|^2, three float32 sums whose magnitudes are bounded by
+        // (|x| + |g|)^2 <= (2|g| + sqrt(key))^2 -- an absolute bound, far looser than the
+        // difference form's when rows sit far from the origin; certification then simply
+        // escalates more often.
+        const double u = 0x1p-24, n = (double)ix->dim + 16.0;
+        if (ix->metric == SZG_COSINE) return 2.0 * n * u;
+        const double s = 2.0 * m.qnorm + std::sqrt(k);
+        return 1.5 * n * u * s * s + 1e-30;
+    }
     if (ix->bits == 8 || ix->bits == 4) {
         // integer paths: the per-lane sums are exact.  What is left is (a) the query's
         // quantization, |v_i - qscale*Q_i| <= qscale/2, and (b) the float32 roundings of
@@ -648,7 +661,7 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
 
 int mq_blocks(const szg_index *ix, int nq)
 {   // query blocks of 16 the batch needs, or 0 when the shared sweep does not apply
-    if (!ix->multi_query || ix->bits == 64 || ix->metric != SZG_COSINE || nq < ix->mq_min) return 0;
+    if (!ix->multi_query || ix->bits == 64 || nq < ix->mq_min) return 0;
     int nb = std::min((nq + 15) / 16, ix->mq_blocks_max);
     while (nb > 0 && szg::mq_lds_bytes(ix->bits, ix->map.r16, nb) > 150u * 1024u) nb--;  // image must fit LDS
     return nb;
@@ -668,16 +681,18 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     const size_t key_stride = ((size_t)sh->n_rows + 3) & ~(size_t)3;
     rc = ensure_dev(&c->d_keys, &c->keys_cap, key_stride * nq);
     if (rc) return rc;
-    // LDS image [piece j][query block][group of 4 elements][query 16][4 floats] of the
-    // normalised queries (q / |q|, so the key is -cos; quantized rows decode to
-    // n = maxInt * d and the common factor cancels)
+    // LDS image [piece j][query block][group of 4 elements][query 16][4 floats].  Cosine:
+    // the normalised queries (q / |q|, so the key is -cos; quantized rows decode to
+    // n = maxInt * d and the common factor cancels).  Euclid: maxInt * q for quantized
+    // rows (key = |n - maxInt q|^2 = maxInt^2 |d - q|^2, the single-query path's unit).
     float *im = reinterpret_cast<float *>(c->h_mq);
     memset(im, 0, img);
     const int E = 128 / ix->bits, G4 = E / 4;
     for (int q = 0; q < nq; q++) {
         const double *src = c->h_q64 + (size_t)q * ix->dim;
         const double m1 = c->meta[q].m1;
-        const double scale = m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0;
+        double scale = m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0;
+        if (ix->metric != SZG_COSINE) scale = ix->bits <= 16 ? (double)((1u << ix->bits) - 1u) : 1.0;
         const int b = q / 16, qi = q % 16;
         for (int e = 0; e < ix->dim; e++) {
             const int j = e / E, i = e % E, g4 = i / 4, m = i % 4;
@@ -711,6 +726,8 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     a.dim = ix->dim;
     a.queries = c->d_mq;
     a.n_queries = nq;
+    a.metric = ix->metric;
+    for (int q = 0; q < nq && q < 48; q++) a.qnorm2[q] = (float)c->meta[q].qnorm2;
     a.keys = c->d_keys;
     a.key_stride = key_stride;
     a.zero16 = sh->zero16;
@@ -1079,6 +1096,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
             for (int j = 0; j < t.nq; j++) {
                 prep_query(ix, q + (size_t)j * ix->dim, t.ctx[s]->h_qsw + (size_t)j * ix->qsw_bytes,
                            &t.meta[j]);
+                t.meta[j].mq = nb > 0;
                 t.ctx[s]->meta[j] = t.meta[j];
             }
             rc = enqueue_queries(ix, sh, t.ctx[s], q, t.nq, allow, allow_stride);

@@ -4,18 +4,18 @@ import numpy as np
 import pytest
 
 import oracle as orc
-from syzgydb_amd import ScanIndex, SZG_COSINE
+from syzgydb_amd import ScanIndex, SZG_COSINE, SZG_EUCLIDEAN
 
 pytestmark = pytest.mark.gpu
 
 
-def check(ix, rows, dim, Q, k, allow=None, bits=32):
+def check(ix, rows, dim, Q, k, allow=None, bits=32, metric=1):
     kw = {}
     if allow is not None:
         kw["allow"] = np.tile(allow, (Q.shape[0], 1))
     r, d, c = ix.search_topk(Q, k, **kw)
     for qi in range(Q.shape[0]):
-        o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, 1, Q[qi], k=k,
+        o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, Q[qi], k=k,
                                              allow=None if allow is None else allow.astype(np.uint8))
         assert c[qi] == len(o_rows)
         assert [int(x) for x in r[qi, : c[qi]]] == [int(x) for x in o_rows], qi
@@ -105,3 +105,35 @@ def test_shared_sweep_zero_rows_and_zero_query():
         ix.load(rows)
         check(ix, rows, dim, Q, 8)
         check(ix, rows, dim, Q, 600)  # k >= n: zero rows (distance exactly 1.0) included
+
+
+@pytest.mark.parametrize("bits", [4, 8, 16, 32])
+@pytest.mark.parametrize("dim,n", [(768, 2500), (384, 3000), (100, 4000), (3, 500)])
+def test_shared_sweep_euclidean(bits, dim, n):
+    """Euclidean metric through the MFMA sweep: key = |x|^2 - 2 x.q + |q|^2 in float32,
+    certified with its own (looser) error bound; ids and float64 distances as the oracle's."""
+    rows = orc.synth_rows(231 + dim + bits, 0, n, dim, bits)
+    Q = orc.synth_vectors(232 + dim, 0, 50, dim)
+    Q[5] *= 30.0     # a query far outside the corpus
+    Q[6] *= 1e-4     # and one at the origin
+    allow = np.arange(n) % 5 != 1
+    with ScanIndex(dim, bits, SZG_EUCLIDEAN) as ix:
+        ix.load(rows)
+        check(ix, rows, dim, Q, 10, bits=bits, metric=0)
+        assert ix.stats()["mq_queries"] == 48   # the tail of 2 (< mq_min) gets its own sweeps
+        check(ix, rows, dim, Q[:24], 100, allow=allow, bits=bits, metric=0)
+
+
+def test_shared_sweep_euclidean_far_from_origin():
+    """Rows clustered far from the origin: the expanded form loses digits to cancellation,
+    the bound notices, and the queries escalate to the exact collect sweep -- same answers."""
+    dim, n = 64, 5000
+    rng = np.random.default_rng(9)
+    vec = 50.0 + 1e-3 * rng.standard_normal((n, dim))
+    rows = orc.encode_rows(vec, 32)
+    Q = 50.0 + 1e-3 * rng.standard_normal((16, dim))
+    with ScanIndex(dim, 32, SZG_EUCLIDEAN) as ix:
+        ix.load(rows)
+        check(ix, rows, dim, Q, 10, metric=0)
+        st = ix.stats()
+        assert st["mq_queries"] == 16 and st["escalations"] > 0
