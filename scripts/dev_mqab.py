@@ -1,0 +1,20 @@
+"""Shared-sweep throughput of the loaded library (A/B via SZG_LIB_PATH)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from syzgydb_amd import ScanIndex
+from syzgydb_amd.synth import synth_vectors
+n, dim, bits, metric, k = 1000000, int(os.environ.get('SZG_DIM', '768')), int(os.environ.get('SZG_BITS', '32')), int(os.environ.get('SZG_METRIC', '1')), 10
+nq = 960
+q = synth_vectors(99, 0, nq, dim)
+with ScanIndex(dim, bits, metric, devices=[0]) as ix:
+    ix.synth(n, 1234)
+    ix.search_topk(q, k); ix.search_topk(q, k)
+    for rep in range(3):
+        ix.set_timing(False)
+        t0 = time.perf_counter(); ix.search_topk(q, k); wall = time.perf_counter() - t0
+        ix.set_timing(True); ix.reset_stats(); ix.search_topk(q, k); s = ix.stats()
+        ms = s["scan_ms"] / max(s["timed_launches"], 1)
+        per = s["mq_queries"] / max(s["mq_launches"], 1)
+        print("%s bits=%d metric=%d: %.0f QPS  sweep %.3f ms  %.1f TFLOP/s  (%.1f q/pass)" % (
+            os.path.basename(os.environ.get("SZG_LIB_PATH", "default")), bits, metric, nq / wall, ms,
+            2.0 * n * dim * per / (ms * 1e-3) / 1e12, per), flush=True)

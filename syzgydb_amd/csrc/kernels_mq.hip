@@ -198,6 +198,12 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
                 }
             }
         }
+        // gfx9 counts loads and stores in ONE vmcnt and they retire out of order with
+        // respect to each other, so with a key store possibly pending the compiler can only
+        // wait for a ring slot with vmcnt(0) -- which also waits for the load just issued
+        // and serialises the ring.  Draining here, once per tile, lets every wait inside
+        // the tile be a counted one.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
 #pragma unroll
         for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
         nrm = 0.f;

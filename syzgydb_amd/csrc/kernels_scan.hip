@@ -464,12 +464,51 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
         }                                                                               \
     }
 
+// The dense phase's ring: at least 2*D pieces, so the prologue is unconditional and the
+// compiler can see that slot u's load is always the oldest of D in flight (counted
+// s_waitcnt vmcnt(D-1) instead of draining the queue; the sched barriers keep the issue
+// order it is counting on).
+#define SZG_RUN_RING_DENSE(NPX, ISSUE, CONSUME)                                         \
+    {                                                                                   \
+        const uint64_t np_ = (NPX);                                                     \
+        uint64_t issued_ = D, consumed_ = 0;                                            \
+        _Pragma("unroll") for (int u = 0; u < D; u++)                                   \
+        {                                                                               \
+            ISSUE(u)                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                          \
+        }                                                                               \
+        while (consumed_ + 2 * D <= np_) {                                              \
+            _Pragma("unroll") for (int u = 0; u < D; u++)                               \
+            {                                                                           \
+                CONSUME(u)                                                              \
+                ISSUE(u)                                                                \
+                __builtin_amdgcn_sched_barrier(0);                                      \
+            }                                                                           \
+            consumed_ += D;                                                             \
+            issued_ += D;                                                               \
+        }                                                                               \
+        while (consumed_ < np_) {                                                       \
+            _Pragma("unroll") for (int u = 0; u < D; u++)                               \
+            {                                                                           \
+                if (consumed_ < np_) {                                                  \
+                    CONSUME(u)                                                          \
+                    consumed_++;                                                        \
+                    if (issued_ < np_) {                                                \
+                        ISSUE(u)                                                        \
+                        issued_++;                                                      \
+                    }                                                                   \
+                }                                                                       \
+            }                                                                           \
+        }                                                                               \
+    }
+
     // ---- dense phase: no masks, L*P == r16, gpw*L == 64, every group's row in
     // range.  No predicates at all: pointer-increment addressing, unconditional
     // accumulation.  Covers all but (at most) the wave's last row step.
     uint64_t it_dense = 0;
     if (!MASKED && (LL || a.map.dense) && row_first + (uint64_t)gpw <= a.n_rows)
         it_dense = (a.n_rows - (uint64_t)gpw - row_first) / stride + 1;
+    if (it_dense * (uint64_t)P < 2 * D) it_dense = 0;  // too short for the ring: general phase
     uint64_t crow0 = row_first;
     if (it_dense) {
         const uint8_t *iptr = a.rows + (row_first + grp) * (uint64_t)a.pitch + (size_t)lig * 16;
@@ -500,7 +539,7 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
             jc += L;                                                                    \
         }                                                                               \
     }
-        SZG_RUN_RING(it_dense * (uint64_t)P, SZG_DN_ISSUE, SZG_DN_CONSUME)
+        SZG_RUN_RING_DENSE(it_dense * (uint64_t)P, SZG_DN_ISSUE, SZG_DN_CONSUME)
 #undef SZG_DN_ISSUE
 #undef SZG_DN_CONSUME
     }
@@ -560,6 +599,7 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
 #undef SZG_CONSUME
     }
 #undef SZG_RUN_RING
+#undef SZG_RUN_RING_DENSE
 
     if (COLLECT) continue;
 
@@ -568,6 +608,11 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
     __syncthreads();
     block_merge_lists(lists, nwaves, a.kp, a.block_lists + ((size_t)qi * gridDim.x + blockIdx.x) * a.kp,
                       tid, blockDim.x);
+    // gfx9 counts loads and stores in one vmcnt and retires them out of order with respect
+    // to each other: with the list stores above possibly pending at the top of the next
+    // query's sweep, every ring wait would have to be vmcnt(0) -- which also waits for the
+    // load just issued.  Drain here, once per query, so the ring gets counted waits.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt, lgkmcnt untouched
     }  // for qi
 }
 

@@ -495,7 +495,7 @@ struct LaunchGeom {
     int grid, block;
 };
 
-LaunchGeom scan_geometry(const szg_index *ix, const Shard *sh, int kp)
+LaunchGeom scan_geometry(const szg_index *ix, const Shard *sh, int kp, bool plain_topk = false)
 {
     int block = ix->block_threads;
     // keep query + per-wave lists within 64 KiB of LDS
@@ -506,13 +506,13 @@ LaunchGeom scan_geometry(const szg_index *ix, const Shard *sh, int kp)
     int waves_per_cu = ix->blocks_per_cu * nwaves;
     if (ix->blocks_per_cu <= 0) {
         // Measured on MI355X (scripts/dev_bpc.sh, scripts/readbw): HBM streams fastest with
-        // about 6 MB of reads in flight -- 8 waves per CU when the row walk is pure float
-        // FMAs; more requests in flight only lengthen the DRAM queues.  The integer /
-        // 16-bit decodes and short rows need 12 waves to hide their ALU work, the
-        // LDS-resident candidate lists (kp > 64) 16.
-        if (kp > 64)
-            waves_per_cu = 16;
-        else if (ix->bits >= 32 && ix->row_bytes >= 1024)
+        // 6-8 MB of reads in flight; more requests only lengthen the DRAM queues.  8 waves
+        // per CU for float rows of >= 1 KB and for LDS-resident candidate lists (kp > 64);
+        // the integer / 16-bit decodes and short rows need 12 to hide their ALU work.
+        // (4 waves per CU is another 0.5 % faster on 3 KB rows at 1M rows but 10 % slower
+        // on a 125 K-row shard, where the sweep's ramp-up and tail weigh more.)
+        (void)plain_topk;
+        if (kp > 64 || (ix->bits >= 32 && ix->row_bytes >= 1024))
             waves_per_cu = 8;
         else
             waves_per_cu = 12;
@@ -614,7 +614,7 @@ int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg
 int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allow)
 {
     HIPCHK(hipSetDevice(sh->device));
-    const LaunchGeom g = scan_geometry(ix, sh, kp);
+    const LaunchGeom g = scan_geometry(ix, sh, kp, !has_allow && !sh->has_dead);
     const size_t need = (size_t)nq * g.grid * kp;
     if (c->lists_cap < need) {  // both ping-pong buffers grow together
         if (c->d_lists_a) HIPCHK(hipFree(c->d_lists_a));
