@@ -117,6 +117,9 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
     for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     float nrm = 0.f;
     uint32_t nz = 0;
+    float4 qn[NB];  // A operands of the group about to be multiplied (one ahead)
+#pragma unroll
+    for (int b = 0; b < NB; b++) qn[b] = qlds[((min(c, r16 - 1) * NB + b) * G4) * 16 + trow];
 
 #define MQ_ISSUE(u)                                                                      \
     {                                                                                    \
@@ -146,11 +149,21 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
         _Pragma("unroll") for (int d = 0; d < 4; d++)                                    \
             decode_dword<QBITS>(w_[d], in_ ? j_ * E + d * N : a.dim, a.dim, x_ + d * N); \
         _Pragma("unroll") for (int i = 0; i < E; i++) nrm = fmaf(x_[i], x_[i], nrm);     \
+        /* the A operands of the NEXT group of 4 elements (or of the next piece's first   \
+           group) are fetched from LDS before this group's MFMAs issue, so the reads'    \
+           latency hides behind 4*NB MFMAs instead of stalling them */                   \
+        const int csn_ = cs + 1 == steps ? 0 : cs + 1;                                   \
+        const int jn_ = min(csn_ * 4 + c, r16 - 1);                                      \
         _Pragma("unroll") for (int g = 0; g < G4; g++)                                   \
         {                                                                                \
+            float4 qc_[NB];                                                              \
+            _Pragma("unroll") for (int b = 0; b < NB; b++) qc_[b] = qn[b];               \
+            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
+                qn[b] = g + 1 < G4 ? qlds[((j_ * NB + b) * G4 + g + 1) * 16 + trow]      \
+                                   : qlds[((jn_ * NB + b) * G4) * 16 + trow];            \
             _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
             {                                                                            \
-                const float4 q_ = qlds[((j_ * NB + b) * G4 + g) * 16 + trow];            \
+                const float4 q_ = qc_[b];                                                \
                 acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.x, x_[4 * g], acc[b], 0, 0, 0);     \
                 acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.y, x_[4 * g + 1], acc[b], 0, 0, 0); \
                 acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.z, x_[4 * g + 2], acc[b], 0, 0, 0); \
@@ -210,19 +223,21 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
         nz = 0;
     };
 
-    uint64_t issued = 0, consumed = 0;
+    // Unconditional prologue (a load past the wave's share reads the dummy piece and is
+    // never consumed) and pinned issue order: the compiler can then wait for slot u with
+    // vmcnt(kRingMq - 1) instead of draining the queue.
+    uint64_t issued = kRingMq, consumed = 0;
 #pragma unroll
     for (int u = 0; u < kRingMq; u++) {
-        if (issued < NP) {
-            MQ_ISSUE(u)
-            issued++;
-        }
+        MQ_ISSUE(u)
+        __builtin_amdgcn_sched_barrier(0);
     }
     while (consumed + 2 * kRingMq <= NP) {
 #pragma unroll
         for (int u = 0; u < kRingMq; u++) {
             MQ_CONSUME(u)
             MQ_ISSUE(u)
+            __builtin_amdgcn_sched_barrier(0);
         }
         consumed += kRingMq;
         issued += kRingMq;
