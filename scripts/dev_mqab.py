@@ -8,6 +8,8 @@ nq = 960
 q = synth_vectors(99, 0, nq, dim)
 with ScanIndex(dim, bits, metric, devices=[0]) as ix:
     ix.synth(n, 1234)
+    for o, val in [x.split('=') for x in os.environ.get('SZG_OPTS', '').split(',') if x]:
+        ix.set_option(o, int(val))
     ix.search_topk(q, k); ix.search_topk(q, k)
     for rep in range(3):
         ix.set_timing(False)
@@ -15,6 +17,6 @@ with ScanIndex(dim, bits, metric, devices=[0]) as ix:
         ix.set_timing(True); ix.reset_stats(); ix.search_topk(q, k); s = ix.stats()
         ms = s["scan_ms"] / max(s["timed_launches"], 1)
         per = s["mq_queries"] / max(s["mq_launches"], 1)
-        print("%s bits=%d metric=%d: %.0f QPS  sweep %.3f ms  %.1f TFLOP/s  (%.1f q/pass)" % (
-            os.path.basename(os.environ.get("SZG_LIB_PATH", "default")), bits, metric, nq / wall, ms,
+        print("%s %s bits=%d metric=%d: %.0f QPS  sweep %.3f ms  %.1f TFLOP/s  (%.1f q/pass)" % (
+            os.path.basename(os.environ.get("SZG_LIB_PATH", "default")), os.environ.get("SZG_OPTS", ""), bits, metric, nq / wall, ms,
             2.0 * n * dim * per / (ms * 1e-3) / 1e12, per), flush=True)

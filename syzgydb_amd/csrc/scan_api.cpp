@@ -223,6 +223,7 @@ struct szg_index {
     int tie_mode = 0;         // 0: exact full replay on ties/NaN, 1: keep the fast answer
     int serialize_scans = 1;  // scan launches of a shard never overlap each other
     int multi_query = 1;      // share one sweep between the queries of a batch (MFMA path)
+    int mq_tail_overlap = 0;  // shared sweep: post-processing of a batch beside the next batch's sweep
     int mq_min = 8;           // smallest batch worth a shared sweep
     int mq_blocks_max = 3;    // query blocks of 16 per shared sweep (LDS image permitting)
     bool timing = false;
@@ -749,23 +750,32 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
             c->timed_scan = true;
             c->timed_n = 1;
         }
+        // The selection, merges, rerank and copy-back of this batch either follow on the scan
+        // stream (default) or, with "mq_tail_overlap", on the context's stream, where they run
+        // beside the NEXT batch's sweep (the sweep is MFMA-bound and leaves wave slots free).
+        hipStream_t tail = st;
+        if (ix->mq_tail_overlap && st != c->stream) {
+            HIPCHK(hipEventRecord(c->ev_scan_done, st));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_scan_done, 0));
+            tail = c->stream;
+        }
         HIPCHK(szg::launch_mq_select(c->d_keys, key_stride, (uint32_t)sh->n_rows,
                                      sh->has_dead ? sh->live_bits : nullptr,
                                      has_allow ? c->d_allow : nullptr, (uint32_t)shard_words(sh), kp, nq,
-                                     sb, c->d_lists_a, st));
+                                     sb, c->d_lists_a, tail));
         int n_lists = sb;
         uint64_t *src = c->d_lists_a, *dst = c->d_lists_b;
         const int fan = szg::merge_fan(kp);
         while (n_lists > 1) {
-            HIPCHK(szg::launch_merge(src, n_lists, kp, nq, dst, st));
+            HIPCHK(szg::launch_merge(src, n_lists, kp, nq, dst, tail));
             n_lists = (n_lists + fan - 1) / fan;
             std::swap(src, dst);
         }
         HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64, src,
-                                  nullptr, (uint32_t)kp, nq, c->d_out, st));
+                                  nullptr, (uint32_t)kp, nq, c->d_out, tail));
         HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp * nq,
-                              hipMemcpyDeviceToHost, st));
-        if (st != c->stream) {
+                              hipMemcpyDeviceToHost, tail));
+        if (tail != c->stream) {
             HIPCHK(hipEventRecord(c->ev_scan_done, st));
             HIPCHK(hipStreamWaitEvent(c->stream, c->ev_scan_done, 0));
         }
@@ -1871,6 +1881,8 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
     } else if (n == "mq_blocks") {
         if (value < 1 || value > 3) return fail(SZG_E_INVALID, "mq_blocks must be 1..3");
         ix->mq_blocks_max = (int)value;
+    } else if (n == "mq_tail_overlap") {
+        ix->mq_tail_overlap = value != 0;
     } else if (n == "mq_min") {
         if (value < 1 || value > 32) return fail(SZG_E_INVALID, "mq_min out of range");
         ix->mq_min = (int)value;
