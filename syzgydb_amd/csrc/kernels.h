@@ -108,11 +108,20 @@ struct MqArgs {
     int metric;               // kCosine: image = q/|q|, key = -cos.  kEuclidean: image = the scan's
                               // prepared query (maxInt*q for quantized rows), key = |n - image|^2
     float qnorm2[48];         // euclid: |image_q|^2 per query
+    float norm_bias;          // integer sweep: turns 4*(sum v'^2 + sum v') into sum n^2 of the real elements
     float *keys;              // out: [n_queries][key_stride] ranking keys
     size_t key_stride;        // floats, multiple of 4, >= n_rows
     const uint8_t *zero16;    // 16 zero bytes (address idle lanes read)
 };
 size_t mq_lds_bytes(int qbits, int r16, int nb);
+
+// Exact integer shared sweep for 8-bit rows (v_mfma_i32_16x16x64_i8).  MqArgs.queries is
+// the image [64-byte step][digit plane h,m,l][query block][lane = chunk*16 + query][16 bytes]
+// of the queries' balanced int8 digit planes (prep_query), followed by the float table
+// [qscale | qconst | qnorm2][48]; MqArgs.norm_bias as ScanArgs.norm_bias.
+size_t mq_i8_image_bytes(int r16, int nb);   // digit image only
+size_t mq_i8_lds_bytes(int r16, int nb);     // image + constants table
+hipError_t launch_mq_score_i8(const MqArgs &a, int nb, int grid, hipStream_t stream);
 hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStream_t stream);  // a.metric picks the key
 hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_rows,
                             const uint64_t *live_bits, const uint64_t *allow_bits,

@@ -259,6 +259,183 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 #undef MQ_CONSUME
 }
 
+// ---- exact integer shared sweep, 8-bit rows ---------------------------------------
+//
+// With v' = v - 128 (one xor per dword) the decoded element is n = 2v' + 1, and the
+// prepared query is the integer vector Q = 16384 h + 128 m + l of balanced int8 digits
+// (prep_query, the same planes the single-query integer path uses).  One
+// v_mfma_i32_16x16x64_i8 per digit plane multiplies 64 elements of 16 rows with 16
+// queries, exactly: B operand = the row bytes as they come from HBM (lane = chunk*16 +
+// row holds 16 consecutive elements), A operand = the plane's bytes from LDS (lane =
+// chunk*16 + query, same elements).  Both operands use the same lane -> K mapping, so the
+// products pair element with element whatever the hardware's K order is.  The row norm
+// comes from two v_dot4_i32_i8 per dword.  The finish is RowAcc<8>::finish's, so the key
+// and its error bound (key_eps, integer branch) are the single-query path's.
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+template <int NB, int METRIC>
+__global__ __launch_bounds__(512) void mq_score_i8_kernel(const MqArgs a)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int r16 = a.r16;
+    const int steps = (r16 + 3) / 4;  // 64-byte steps per row
+    const int n16 = steps * 3 * NB * 64;  // image, 16-byte words
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        const int n = n16 + (3 * 48 * 4) / 16;  // + constants table
+        for (int i = tid; i < n; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const v4i32 *qimg = reinterpret_cast<const v4i32 *>(smem);
+    const float *qtab = reinterpret_cast<const float *>(smem + (size_t)n16 * 16);
+
+    const int trow = lane & 15;
+    const int c = lane >> 4;
+    const uint64_t n_tiles = ((uint64_t)a.n_rows + 15) / 16;
+    const uint64_t tile_stride = (uint64_t)gridDim.x * nwaves;
+    const uint64_t tile_first = (uint64_t)blockIdx.x * nwaves + wave;
+    const uint64_t n_it = tile_first < n_tiles ? (n_tiles - tile_first + tile_stride - 1) / tile_stride : 0;
+    const uint64_t NP = n_it * (uint64_t)steps;
+
+    uint64_t itile = tile_first;
+    int is = 0;
+    uint64_t ctile = tile_first;
+    int cs = 0;
+
+    u32x4 ring[kRingMq];
+    v4i32 acc[3][NB];
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+        for (int b = 0; b < NB; b++) acc[p][b] = v4i32{0, 0, 0, 0};
+    int SQ = 0, SV = 0;
+    // A operands of the step about to be multiplied (fetched one step ahead)
+    v4i32 qn[3][NB];
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+        for (int b = 0; b < NB; b++) qn[p][b] = qimg[(p * NB + b) * 64 + lane];
+
+#define MQ8_ISSUE(u)                                                                     \
+    {                                                                                    \
+        const uint64_t row_ = itile * 16 + trow;                                         \
+        const int j_ = is * 4 + c;                                                       \
+        const bool ok_ = row_ < a.n_rows && j_ < r16;                                    \
+        ring[u] = load_nt(ok_ ? a.rows + row_ * a.pitch + (size_t)j_ * 16 : a.zero16);   \
+        if (++is == steps) {                                                             \
+            is = 0;                                                                      \
+            itile += tile_stride;                                                        \
+        }                                                                                \
+    }
+
+#define MQ8_CONSUME(u)                                                                   \
+    {                                                                                    \
+        const u32x4 v_ = ring[u];                                                        \
+        const bool in_ = cs * 4 + c < r16; /* else: the dummy piece, not part of the row */ \
+        v4i32 w_;                                                                        \
+        w_.x = in_ ? (int)(v_.x ^ 0x80808080u) : 0;                                      \
+        w_.y = in_ ? (int)(v_.y ^ 0x80808080u) : 0;                                      \
+        w_.z = in_ ? (int)(v_.z ^ 0x80808080u) : 0;                                      \
+        w_.w = in_ ? (int)(v_.w ^ 0x80808080u) : 0;                                      \
+        v4i32 qc_[3][NB];                                                                \
+        _Pragma("unroll") for (int p = 0; p < 3; p++)                                    \
+            _Pragma("unroll") for (int b = 0; b < NB; b++) qc_[p][b] = qn[p][b];         \
+        const int csn_ = cs + 1 == steps ? 0 : cs + 1;                                   \
+        _Pragma("unroll") for (int p = 0; p < 3; p++)                                    \
+            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
+                qn[p][b] = qimg[((csn_ * 3 + p) * NB + b) * 64 + lane];                  \
+        _Pragma("unroll") for (int p = 0; p < 3; p++)                                    \
+            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
+                acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qc_[p][b], w_, acc[p][b], 0, 0, 0); \
+        SQ = __builtin_amdgcn_sdot4(w_.x, w_.x, SQ, false);                              \
+        SQ = __builtin_amdgcn_sdot4(w_.y, w_.y, SQ, false);                              \
+        SQ = __builtin_amdgcn_sdot4(w_.z, w_.z, SQ, false);                              \
+        SQ = __builtin_amdgcn_sdot4(w_.w, w_.w, SQ, false);                              \
+        SV = __builtin_amdgcn_sdot4(w_.x, 0x01010101, SV, false);                        \
+        SV = __builtin_amdgcn_sdot4(w_.y, 0x01010101, SV, false);                        \
+        SV = __builtin_amdgcn_sdot4(w_.z, 0x01010101, SV, false);                        \
+        SV = __builtin_amdgcn_sdot4(w_.w, 0x01010101, SV, false);                        \
+        if (++cs == steps) {                                                             \
+            finish_tile8(ctile);                                                         \
+            cs = 0;                                                                      \
+            ctile += tile_stride;                                                        \
+        }                                                                                \
+    }
+
+    auto finish_tile8 = [&](uint64_t tile) {
+        int nrm = 4 * (SQ + SV);
+        nrm += __shfl_xor(nrm, 16);
+        nrm += __shfl_xor(nrm, 32);
+        const float norm = (float)nrm + a.norm_bias;
+        const float inv = __frsqrt_rn(norm);
+        const uint64_t row = tile * 16 + trow;
+        if (row < a.n_rows) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int q = b * 16 + c * 4 + r;
+                    const float dot = fmaf(16384.0f, (float)acc[0][b][r],
+                                           fmaf(128.0f, (float)acc[1][b][r], (float)acc[2][b][r]));
+                    const float d2 = fmaf(2.0f, dot, qtab[48 + q]);  // sum Q n
+                    float key;
+                    if (METRIC == kCosine)
+                        key = -(d2 * qtab[q]) * inv;
+                    else
+                        key = fmaf(-2.0f * qtab[q], d2, qtab[96 + q] + norm);
+                    if (!(key == key)) key = 3.0e38f;
+                    if (key > 3.0e38f) key = 3.0e38f;
+                    if (q < a.n_queries) a.keys[(size_t)q * a.key_stride + row] = key;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores (see mq_score_kernel)
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int b = 0; b < NB; b++) acc[p][b] = v4i32{0, 0, 0, 0};
+        SQ = 0;
+        SV = 0;
+    };
+
+    uint64_t issued = kRingMq, consumed = 0;
+#pragma unroll
+    for (int u = 0; u < kRingMq; u++) {
+        MQ8_ISSUE(u)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    while (consumed + 2 * kRingMq <= NP) {
+#pragma unroll
+        for (int u = 0; u < kRingMq; u++) {
+            MQ8_CONSUME(u)
+            MQ8_ISSUE(u)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        consumed += kRingMq;
+        issued += kRingMq;
+    }
+    while (consumed < NP) {
+#pragma unroll
+        for (int u = 0; u < kRingMq; u++) {
+            if (consumed < NP) {
+                MQ8_CONSUME(u)
+                consumed++;
+                if (issued < NP) {
+                    MQ8_ISSUE(u)
+                    issued++;
+                }
+            }
+        }
+    }
+#undef MQ8_ISSUE
+#undef MQ8_CONSUME
+}
+
 // ---- per-query selection over the score matrix ----------------------------------
 
 // grid (blocks per query, queries).  Each lane reads 4 keys at a time (16 bytes);
@@ -340,6 +517,38 @@ hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStre
     case 8: return launch_mq_score_q<8>(a, nb, grid, lds, stream);
     case 16: return launch_mq_score_q<16>(a, nb, grid, lds, stream);
     case 32: return launch_mq_score_q<32>(a, nb, grid, lds, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+size_t mq_i8_image_bytes(int r16, int nb) { return (size_t)((r16 + 3) / 4) * 3 * nb * 1024; }
+size_t mq_i8_lds_bytes(int r16, int nb) { return mq_i8_image_bytes(r16, nb) + 3 * 48 * sizeof(float); }
+
+namespace {
+template <int NB, int METRIC>
+hipError_t launch_mq_score_i8_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mq_score_i8_kernel<NB, METRIC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((mq_score_i8_kernel<NB, METRIC>), dim3(grid), dim3(512), lds, stream, a);
+    return hipGetLastError();
+}
+template <int NB>
+hipError_t launch_mq_score_i8_m(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
+{
+    if (a.metric == kCosine) return launch_mq_score_i8_t<NB, kCosine>(a, grid, lds, stream);
+    return launch_mq_score_i8_t<NB, kEuclidean>(a, grid, lds, stream);
+}
+}  // namespace
+
+hipError_t launch_mq_score_i8(const MqArgs &a, int nb, int grid, hipStream_t stream)
+{
+    const size_t lds = mq_i8_lds_bytes(a.r16, nb);
+    switch (nb) {
+    case 1: return launch_mq_score_i8_m<1>(a, grid, lds, stream);
+    case 2: return launch_mq_score_i8_m<2>(a, grid, lds, stream);
+    case 3: return launch_mq_score_i8_m<3>(a, grid, lds, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -223,6 +223,7 @@ struct szg_index {
     int tie_mode = 0;         // 0: exact full replay on ties/NaN, 1: keep the fast answer
     int serialize_scans = 1;  // scan launches of a shard never overlap each other
     int multi_query = 1;      // share one sweep between the queries of a batch (MFMA path)
+    int mq_i8 = 1;            // 8-bit rows: exact integer shared sweep (v_mfma_i32_16x16x64_i8)
     int mq_tail_overlap = 0;  // shared sweep: post-processing of a batch beside the next batch's sweep
     int mq_min = 8;           // smallest batch worth a shared sweep
     int mq_blocks_max = 3;    // query blocks of 16 per shared sweep (LDS image permitting)
@@ -660,11 +661,16 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
 
 // ---- multi-query sweep (32-bit rows, cosine): B queries share one pass ------------
 
+bool mq_uses_i8(const szg_index *ix) { return ix->bits == 8 && ix->mq_i8; }
+
 int mq_blocks(const szg_index *ix, int nq)
 {   // query blocks of 16 the batch needs, or 0 when the shared sweep does not apply
     if (!ix->multi_query || ix->bits == 64 || nq < ix->mq_min) return 0;
     int nb = std::min((nq + 15) / 16, ix->mq_blocks_max);
-    while (nb > 0 && szg::mq_lds_bytes(ix->bits, ix->map.r16, nb) > 150u * 1024u) nb--;  // image must fit LDS
+    auto lds = [&](int n) {
+        return mq_uses_i8(ix) ? szg::mq_i8_lds_bytes(ix->map.r16, n) : szg::mq_lds_bytes(ix->bits, ix->map.r16, n);
+    };
+    while (nb > 0 && lds(nb) > 150u * 1024u) nb--;  // image must fit LDS
     return nb;
 }
 
@@ -674,7 +680,8 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
 {
     HIPCHK(hipSetDevice(sh->device));
     const int r16 = ix->map.r16;
-    const size_t img = szg::mq_lds_bytes(ix->bits, r16, nb);
+    const bool i8 = mq_uses_i8(ix);
+    const size_t img = i8 ? szg::mq_i8_lds_bytes(r16, nb) : szg::mq_lds_bytes(ix->bits, r16, nb);
     int rc = ensure_host(&c->h_mq, &c->h_mq_cap, img);
     if (rc) return rc;
     rc = ensure_dev(&c->d_mq, &c->d_mq_cap, img);
@@ -682,12 +689,36 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     const size_t key_stride = ((size_t)sh->n_rows + 3) & ~(size_t)3;
     rc = ensure_dev(&c->d_keys, &c->keys_cap, key_stride * nq);
     if (rc) return rc;
+    memset(c->h_mq, 0, img);
+    if (i8) {
+        // [64-byte step][digit plane][query block][lane = chunk*16 + query][16 bytes] from the
+        // planes prep_query wrote ([plane][piece][16 bytes]), then [qscale | qconst | qnorm2][48]
+        const int steps = (r16 + 3) / 4;
+        uint8_t *im8 = c->h_mq;
+        for (int q = 0; q < nq; q++) {
+            const uint8_t *pl = c->h_qsw + (size_t)q * ix->qsw_bytes;
+            const int b = q / 16, qi = q % 16;
+            for (int s = 0; s < steps; s++)
+                for (int p = 0; p < 3; p++)
+                    for (int ch = 0; ch < 4; ch++) {
+                        const int j = s * 4 + ch;
+                        if (j >= r16) continue;
+                        memcpy(im8 + ((((size_t)s * 3 + p) * nb + b) * 64 + ch * 16 + qi) * 16,
+                               pl + ((size_t)p * r16 + j) * 16, 16);
+                    }
+        }
+        float *tab = reinterpret_cast<float *>(c->h_mq + szg::mq_i8_image_bytes(r16, nb));
+        for (int q = 0; q < nq && q < 48; q++) {
+            tab[q] = (float)c->meta[q].qscale;
+            tab[48 + q] = (float)c->meta[q].qconst;
+            tab[96 + q] = (float)c->meta[q].qnorm2;
+        }
+    } else {
     // LDS image [piece j][query block][group of 4 elements][query 16][4 floats].  Cosine:
     // the normalised queries (q / |q|, so the key is -cos; quantized rows decode to
     // n = maxInt * d and the common factor cancels).  Euclid: maxInt * q for quantized
     // rows (key = |n - maxInt q|^2 = maxInt^2 |d - q|^2, the single-query path's unit).
     float *im = reinterpret_cast<float *>(c->h_mq);
-    memset(im, 0, img);
     const int E = 128 / ix->bits, G4 = E / 4;
     for (int q = 0; q < nq; q++) {
         const double *src = c->h_q64 + (size_t)q * ix->dim;
@@ -699,6 +730,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
             const int j = e / E, i = e % E, g4 = i / 4, m = i % 4;
             im[((((size_t)j * nb + b) * G4 + g4) * 16 + qi) * 4 + m] = (float)(src[e] * scale);
         }
+    }
     }
     HIPCHK(hipMemcpyAsync(c->d_mq, c->h_mq, img, hipMemcpyHostToDevice, c->stream));
 
@@ -732,6 +764,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     a.keys = c->d_keys;
     a.key_stride = key_stride;
     a.zero16 = sh->zero16;
+    a.norm_bias = (float)ix->norm_bias;
     // The sweep wants every CU to itself (one 1024-thread block and up to 144 KiB of
     // LDS per CU), so the whole batch -- sweep, selection, merges, rerank, copy --
     // goes onto the shard's scan stream, one batch after the other; only uploads
@@ -744,7 +777,10 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
             HIPCHK(hipStreamWaitEvent(st, c->ev_up, 0));
         }
         if (ix->timing) HIPCHK(hipEventRecord(c->ev_scan0, st));
-        HIPCHK(szg::launch_mq_score(ix->bits, a, nb, sh->cu_count, st));
+        if (i8)
+            HIPCHK(szg::launch_mq_score_i8(a, nb, sh->cu_count, st));
+        else
+            HIPCHK(szg::launch_mq_score(ix->bits, a, nb, sh->cu_count, st));
         if (ix->timing) {
             HIPCHK(hipEventRecord(c->ev_scan1, st));
             c->timed_scan = true;
@@ -1106,7 +1142,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
             for (int j = 0; j < t.nq; j++) {
                 prep_query(ix, q + (size_t)j * ix->dim, t.ctx[s]->h_qsw + (size_t)j * ix->qsw_bytes,
                            &t.meta[j]);
-                t.meta[j].mq = nb > 0;
+                t.meta[j].mq = nb > 0 && !mq_uses_i8(ix);  // the integer sweep keeps the integer bound
                 t.ctx[s]->meta[j] = t.meta[j];
             }
             rc = enqueue_queries(ix, sh, t.ctx[s], q, t.nq, allow, allow_stride);
@@ -1881,6 +1917,8 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
     } else if (n == "mq_blocks") {
         if (value < 1 || value > 3) return fail(SZG_E_INVALID, "mq_blocks must be 1..3");
         ix->mq_blocks_max = (int)value;
+    } else if (n == "mq_i8") {
+        ix->mq_i8 = value != 0;
     } else if (n == "mq_tail_overlap") {
         ix->mq_tail_overlap = value != 0;
     } else if (n == "mq_min") {

@@ -137,3 +137,23 @@ def test_shared_sweep_euclidean_far_from_origin():
         check(ix, rows, dim, Q, 10, metric=0)
         st = ix.stats()
         assert st["mq_queries"] == 16 and st["escalations"] > 0
+
+
+@pytest.mark.parametrize("metric", [SZG_COSINE, SZG_EUCLIDEAN])
+@pytest.mark.parametrize("dim,n", [(768, 3000), (1536, 1500), (100, 4000), (37, 900), (64, 2000), (3, 500)])
+def test_shared_sweep_int8_mfma(metric, dim, n):
+    """8-bit rows take the exact integer sweep (v_mfma_i32_16x16x64_i8 on the queries' int8
+    digit planes); same bar, and the float32 MFMA sweep (mq_i8=0) must agree with it."""
+    rows = orc.synth_rows(331 + dim, 0, n, dim, 8)
+    Q = orc.synth_vectors(332 + dim, 0, 48, dim)
+    Q[7] *= 25.0
+    Q[8] *= 1e-3
+    allow = np.arange(n) % 3 != 0
+    with ScanIndex(dim, 8, metric) as ix:
+        ix.load(rows)
+        for i8 in (1, 0):
+            ix.set_option("mq_i8", i8)
+            ix.reset_stats()
+            check(ix, rows, dim, Q, 10, bits=8, metric=metric)
+            assert ix.stats()["mq_queries"] == 48
+            check(ix, rows, dim, Q[:17], 33, allow=allow, bits=8, metric=metric)
