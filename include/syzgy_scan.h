@@ -181,6 +181,7 @@ typedef struct szg_stats {
                                   (equal distances or NaN among the best k+1 candidates) */
     uint64_t mq_launches;      /* shared (multi-query) sweeps; each is also one scan launch */
     uint64_t mq_queries;       /* queries answered through shared sweeps */
+    uint64_t mq_fallbacks;     /* shared-sweep batches redone through the score matrix (candidate buffer overflow) */
 } szg_stats;
 
 /* Per-kernel HIP-event timing on the library's own streams (off by default). */

@@ -53,6 +53,7 @@ class SzgStats(ctypes.Structure):
         ("full_replays", ctypes.c_uint64),
         ("mq_launches", ctypes.c_uint64),
         ("mq_queries", ctypes.c_uint64),
+        ("mq_fallbacks", ctypes.c_uint64),
     ]
 
 

@@ -112,7 +112,23 @@ struct MqArgs {
     float *keys;              // out: [n_queries][key_stride] ranking keys
     size_t key_stride;        // floats, multiple of 4, >= n_rows
     const uint8_t *zero16;    // 16 zero bytes (address idle lanes read)
+    // fused selection (collect != 0): instead of writing the score matrix, every (query,
+    // row) whose key is <= thr[query] and whose mask bits allow it is appended to the
+    // query's candidate buffer; thr comes from a sweep of a prefix of the rows
+    int collect;
+    const float *thr;            // [n_queries]
+    uint64_t *cand_buf;          // [n_queries][cand_cap]  (ordered key << 32 | row)
+    uint32_t *cand_count;        // [n_queries]; may exceed cand_cap (then the batch is redone)
+    uint32_t cand_cap;
+    const uint64_t *live_bits;   // nullable
+    const uint64_t *allow_bits;  // nullable, per query
+    uint32_t allow_stride;
 };
+// thr[q] = key of the kp-th entry of query q's sorted list (3.0e38 if the list is shorter)
+hipError_t launch_mq_thr(const uint64_t *lists, int kp, int n_queries, float *thr, hipStream_t stream);
+// per query: the kp best of its candidate buffer, sorted, as one list [n_queries][kp]
+hipError_t launch_cand_select(const uint64_t *cand_buf, const uint32_t *cand_count, uint32_t cand_cap,
+                              int kp, int n_queries, uint64_t *lists, hipStream_t stream);
 size_t mq_lds_bytes(int qbits, int r16, int nb);
 
 // Exact integer shared sweep for 8-bit rows (v_mfma_i32_16x16x64_i8).  MqArgs.queries is
@@ -126,7 +142,9 @@ hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStre
 hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_rows,
                             const uint64_t *live_bits, const uint64_t *allow_bits,
                             uint32_t allow_stride, int kp, int n_queries, int blocks_per_query,
-                            uint64_t *block_lists, hipStream_t stream);
+                            uint64_t *block_lists, hipStream_t stream, float *thr_out = nullptr,
+                            uint32_t *count_zero = nullptr);  // thr_out: one block per query; also
+                                                              // writes thr[q] and zeroes count_zero[q]
 
 // Lists are [n_queries][n_lists][kp]; the output is [n_queries][n_out][kp].
 hipError_t launch_merge(const uint64_t *in, int n_lists, int kp, int n_queries, uint64_t *out,

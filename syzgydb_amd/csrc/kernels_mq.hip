@@ -73,8 +73,53 @@ __device__ __forceinline__ void decode_dword(uint32_t w, int e0, int dim, float 
     }
 }
 
+// Fused selection.  A (query, row) pair whose key is at or below the query's threshold goes
+// into the wave's own little hit buffer in LDS (wave-synchronous append: ballot + prefix
+// popcount, no atomics); when 64 are waiting -- normally only at the end of the kernel --
+// each lane takes one, checks the row's mask bits and claims a slot in the query's global
+// candidate buffer.  (One returning global atomic per hit, issued where the hit occurs,
+// stalls the wave for a full memory round trip each time: measured +40 % on the sweep.)
+constexpr int kHitCap = 64;
+struct HitBuf {
+    uint64_t *cand;  // [kHitCap]
+    uint8_t *query;  // [kHitCap]
+    int n;           // wave-uniform
+};
+
+__device__ __forceinline__ void hit_flush(const MqArgs &a, HitBuf &hb, int lane)
+{
+    if (lane < hb.n) {
+        const uint64_t c = hb.cand[lane];
+        const int q = hb.query[lane];
+        const uint32_t r = (uint32_t)c;
+        bool ok = true;
+        if (a.live_bits) ok = (a.live_bits[r >> 6] >> (r & 63)) & 1;
+        if (ok && a.allow_bits) ok = (a.allow_bits[(size_t)q * a.allow_stride + (r >> 6)] >> (r & 63)) & 1;
+        if (ok) {
+            const uint32_t idx = atomicAdd(a.cand_count + q, 1u);
+            if (idx < a.cand_cap) a.cand_buf[(size_t)q * a.cand_cap + idx] = c;
+        }
+    }
+    hb.n = 0;
+}
+
+__device__ __forceinline__ void hit_offer(const MqArgs &a, HitBuf &hb, int lane, bool hit, int q, uint64_t row,
+                                          float key)
+{
+    const uint64_t m = __ballot(hit);
+    if (!m) return;
+    const int cnt = __popcll(m);
+    if (hb.n + cnt > kHitCap) hit_flush(a, hb, lane);
+    if (hit) {
+        const int pos = hb.n + __popcll(m & ((1ull << lane) - 1ull));
+        hb.cand[pos] = ((uint64_t)ordered_key(key) << 32) | (uint32_t)row;
+        hb.query[pos] = (uint8_t)q;
+    }
+    hb.n += cnt;
+}
+
 // LDS image of the batch: [piece j][query block][group of 4 elements][query 16][4 floats]
-template <int NB, int QBITS, int METRIC>
+template <int NB, int QBITS, int METRIC, bool COLLECT>
 __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 {
     constexpr int E = 128 / QBITS;  // elements per 16-byte piece
@@ -92,9 +137,19 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         const int n = r16 * NB * G4 * 16;
         for (int i = tid; i < n; i += blockDim.x) dst[i] = src[i];
+        if (COLLECT && tid < 48)
+            reinterpret_cast<float *>(smem + (size_t)n * 16)[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
     }
     __syncthreads();
     const float4 *qlds = reinterpret_cast<const float4 *>(smem);
+    const float *thr_lds = reinterpret_cast<const float *>(smem + (size_t)r16 * NB * G4 * 16 * 16);
+    HitBuf hb;
+    {
+        uint8_t *base = smem + (size_t)r16 * NB * G4 * 16 * 16 + 48 * sizeof(float);
+        hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
+        hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
+        hb.n = 0;
+    }
 
     const int trow = lane & 15;
     const int c = lane >> 4;
@@ -192,7 +247,7 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
         const float inv = __frsqrt_rn(nrm);
         // D layout of the 16x16 product: column = lane & 15 (the tile's row),
         // row = (lane >> 4) * 4 + reg (the query inside its block of 16)
-        if (row < a.n_rows) {
+        if (COLLECT || row < a.n_rows) {
 #pragma unroll
             for (int b = 0; b < NB; b++) {
 #pragma unroll
@@ -207,7 +262,10 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
                     }
                     if (!(key == key)) key = 3.0e38f;
                     if (key > 3.0e38f) key = 3.0e38f;
-                    if (q < a.n_queries) a.keys[(size_t)q * a.key_stride + row] = key;
+                    if (COLLECT)
+                        hit_offer(a, hb, lane, row < a.n_rows && q < a.n_queries && key <= thr_lds[q], q, row, key);
+                    else if (q < a.n_queries)
+                        a.keys[(size_t)q * a.key_stride + row] = key;
                 }
             }
         }
@@ -257,6 +315,7 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
     }
 #undef MQ_ISSUE
 #undef MQ_CONSUME
+    if (COLLECT) hit_flush(a, hb, lane);
 }
 
 // ---- exact integer shared sweep, 8-bit rows ---------------------------------------
@@ -273,8 +332,8 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 // and its error bound (key_eps, integer branch) are the single-query path's.
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
-template <int NB, int METRIC>
-__global__ __launch_bounds__(512) void mq_score_i8_kernel(const MqArgs a)
+template <int NB, int METRIC, bool COLLECT>
+__global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x;
@@ -289,10 +348,20 @@ __global__ __launch_bounds__(512) void mq_score_i8_kernel(const MqArgs a)
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         const int n = n16 + (3 * 48 * 4) / 16;  // + constants table
         for (int i = tid; i < n; i += blockDim.x) dst[i] = src[i];
+        if (COLLECT && tid < 48)
+            reinterpret_cast<float *>(smem + (size_t)n * 16)[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
     }
     __syncthreads();
     const v4i32 *qimg = reinterpret_cast<const v4i32 *>(smem);
     const float *qtab = reinterpret_cast<const float *>(smem + (size_t)n16 * 16);
+    const float *thr_lds = qtab + 3 * 48;
+    HitBuf hb;
+    {
+        uint8_t *base = smem + (size_t)n16 * 16 + 4 * 48 * sizeof(float);
+        hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
+        hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
+        hb.n = 0;
+    }
 
     const int trow = lane & 15;
     const int c = lane >> 4;
@@ -374,7 +443,7 @@ __global__ __launch_bounds__(512) void mq_score_i8_kernel(const MqArgs a)
         const float norm = (float)nrm + a.norm_bias;
         const float inv = __frsqrt_rn(norm);
         const uint64_t row = tile * 16 + trow;
-        if (row < a.n_rows) {
+        if (COLLECT || row < a.n_rows) {
 #pragma unroll
             for (int b = 0; b < NB; b++) {
 #pragma unroll
@@ -390,7 +459,10 @@ __global__ __launch_bounds__(512) void mq_score_i8_kernel(const MqArgs a)
                         key = fmaf(-2.0f * qtab[q], d2, qtab[96 + q] + norm);
                     if (!(key == key)) key = 3.0e38f;
                     if (key > 3.0e38f) key = 3.0e38f;
-                    if (q < a.n_queries) a.keys[(size_t)q * a.key_stride + row] = key;
+                    if (COLLECT)
+                        hit_offer(a, hb, lane, row < a.n_rows && q < a.n_queries && key <= thr_lds[q], q, row, key);
+                    else if (q < a.n_queries)
+                        a.keys[(size_t)q * a.key_stride + row] = key;
                 }
             }
         }
@@ -434,6 +506,7 @@ __global__ __launch_bounds__(512) void mq_score_i8_kernel(const MqArgs a)
     }
 #undef MQ8_ISSUE
 #undef MQ8_CONSUME
+    if (COLLECT) hit_flush(a, hb, lane);
 }
 
 // ---- per-query selection over the score matrix ----------------------------------
@@ -444,7 +517,8 @@ __global__ __launch_bounds__(256) void mq_select_kernel(const float *keys, size_
                                                         uint32_t n_rows, const uint64_t *live_bits,
                                                         const uint64_t *allow_bits,
                                                         uint32_t allow_stride, int kp,
-                                                        uint64_t *block_lists)
+                                                        uint64_t *block_lists, float *thr_out,
+                                                        uint32_t *count_zero)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem);
@@ -473,29 +547,89 @@ __global__ __launch_bounds__(256) void mq_select_kernel(const float *keys, size_
     }
     wl.flush(lane);
     __syncthreads();
-    block_merge_lists(lists, nwaves, kp, block_lists + ((size_t)q * gridDim.x + blockIdx.x) * kp, tid,
-                      blockDim.x);
+    uint64_t *out = block_lists + ((size_t)q * gridDim.x + blockIdx.x) * kp;
+    block_merge_lists(lists, nwaves, kp, out, tid, blockDim.x);
+    if (thr_out) {  // one block per query: its kp-th key is the query's collect threshold
+        __syncthreads();
+        if (tid == 0) {
+            const uint64_t c = out[kp - 1];
+            thr_out[q] = c == kInvalidCand ? 3.0e38f : key_from_ordered((uint32_t)(c >> 32));
+            count_zero[q] = 0;
+        }
+    }
+}
+
+// thr[q] = key of the kp-th entry of query q's sorted candidate list
+__global__ void mq_thr_kernel(const uint64_t *lists, int kp, int n_queries, float *thr)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_queries) return;
+    const uint64_t c = lists[(size_t)q * kp + (kp - 1)];
+    thr[q] = c == kInvalidCand ? 3.0e38f : key_from_ordered((uint32_t)(c >> 32));
+}
+
+// one block per query: the kp best of the query's candidate buffer, sorted ascending
+__global__ __launch_bounds__(256) void cand_select_kernel(const uint64_t *cand_buf, const uint32_t *cand_count,
+                                                          uint32_t cand_cap, int kp, uint64_t *lists)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint64_t *wl_lds = reinterpret_cast<uint64_t *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int q = blockIdx.x;
+    WaveList wl;
+    wl.init(wl_lds + (size_t)wave * kp, kp, lane);
+    __syncthreads();
+    const uint32_t n = min(cand_count[q], cand_cap);
+    const uint64_t *src = cand_buf + (size_t)q * cand_cap;
+    for (uint32_t i = tid; i < ((n + blockDim.x - 1) / blockDim.x) * blockDim.x; i += blockDim.x) {
+        const bool ok = i < n;
+        const uint64_t c = ok ? src[i] : kInvalidCand;
+        wl.offer(ok, c, lane);
+    }
+    wl.flush(lane);
+    __syncthreads();
+    block_merge_lists(wl_lds, nwaves, kp, lists + (size_t)q * kp, tid, blockDim.x);
 }
 
 }  // namespace
 
-size_t mq_lds_bytes(int qbits, int r16, int nb) { return (size_t)r16 * nb * (128 / qbits) * 16 * 4; }
+hipError_t launch_mq_thr(const uint64_t *lists, int kp, int n_queries, float *thr, hipStream_t stream)
+{
+    hipLaunchKernelGGL(mq_thr_kernel, dim3(1), dim3(64), 0, stream, lists, kp, n_queries, thr);
+    return hipGetLastError();
+}
+
+hipError_t launch_cand_select(const uint64_t *cand_buf, const uint32_t *cand_count, uint32_t cand_cap,
+                              int kp, int n_queries, uint64_t *lists, hipStream_t stream)
+{
+    const size_t lds = (size_t)4 * kp * sizeof(uint64_t);
+    hipLaunchKernelGGL(cand_select_kernel, dim3(n_queries), dim3(256), lds, stream, cand_buf, cand_count,
+                       cand_cap, kp, lists);
+    return hipGetLastError();
+}
+
+size_t mq_lds_bytes(int qbits, int r16, int nb) { return (size_t)r16 * nb * (128 / qbits) * 16 * 4; }  // image only
 
 namespace {
-template <int NB, int QBITS, int METRIC>
+template <int NB, int QBITS, int METRIC, bool COLLECT>
 hipError_t launch_mq_score_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mq_score_kernel<NB, QBITS, METRIC>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void *>(&mq_score_kernel<NB, QBITS, METRIC, COLLECT>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mq_score_kernel<NB, QBITS, METRIC>), dim3(grid), dim3(1024), lds, stream, a);
+    hipLaunchKernelGGL((mq_score_kernel<NB, QBITS, METRIC, COLLECT>), dim3(grid), dim3(1024), lds, stream, a);
     return hipGetLastError();
 }
 template <int NB, int QBITS>
 hipError_t launch_mq_score_m(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
-    if (a.metric == kCosine) return launch_mq_score_t<NB, QBITS, kCosine>(a, grid, lds, stream);
-    return launch_mq_score_t<NB, QBITS, kEuclidean>(a, grid, lds, stream);
+    if (a.collect) {
+        if (a.metric == kCosine) return launch_mq_score_t<NB, QBITS, kCosine, true>(a, grid, lds, stream);
+        return launch_mq_score_t<NB, QBITS, kEuclidean, true>(a, grid, lds, stream);
+    }
+    if (a.metric == kCosine) return launch_mq_score_t<NB, QBITS, kCosine, false>(a, grid, lds, stream);
+    return launch_mq_score_t<NB, QBITS, kEuclidean, false>(a, grid, lds, stream);
 }
 template <int QBITS>
 hipError_t launch_mq_score_q(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
@@ -511,7 +645,8 @@ hipError_t launch_mq_score_q(const MqArgs &a, int nb, int grid, size_t lds, hipS
 
 hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStream_t stream)
 {
-    const size_t lds = mq_lds_bytes(qbits, a.r16, nb);
+    // + thresholds and the waves' hit buffers (fused selection)
+    const size_t lds = mq_lds_bytes(qbits, a.r16, nb) + 48 * sizeof(float) + (size_t)16 * kHitCap * 9;
     switch (qbits) {
     case 4: return launch_mq_score_q<4>(a, nb, grid, lds, stream);
     case 8: return launch_mq_score_q<8>(a, nb, grid, lds, stream);
@@ -522,23 +657,30 @@ hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStre
 }
 
 size_t mq_i8_image_bytes(int r16, int nb) { return (size_t)((r16 + 3) / 4) * 3 * nb * 1024; }
-size_t mq_i8_lds_bytes(int r16, int nb) { return mq_i8_image_bytes(r16, nb) + 3 * 48 * sizeof(float); }
+size_t mq_i8_lds_bytes(int r16, int nb)
+{   // + constants, thresholds, the 12 waves' hit buffers
+    return mq_i8_image_bytes(r16, nb) + 4 * 48 * sizeof(float) + (size_t)12 * 64 * 9;
+}
 
 namespace {
-template <int NB, int METRIC>
+template <int NB, int METRIC, bool COLLECT>
 hipError_t launch_mq_score_i8_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mq_score_i8_kernel<NB, METRIC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mq_score_i8_kernel<NB, METRIC, COLLECT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mq_score_i8_kernel<NB, METRIC>), dim3(grid), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((mq_score_i8_kernel<NB, METRIC, COLLECT>), dim3(grid), dim3(768), lds, stream, a);
     return hipGetLastError();
 }
 template <int NB>
 hipError_t launch_mq_score_i8_m(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
-    if (a.metric == kCosine) return launch_mq_score_i8_t<NB, kCosine>(a, grid, lds, stream);
-    return launch_mq_score_i8_t<NB, kEuclidean>(a, grid, lds, stream);
+    if (a.collect) {
+        if (a.metric == kCosine) return launch_mq_score_i8_t<NB, kCosine, true>(a, grid, lds, stream);
+        return launch_mq_score_i8_t<NB, kEuclidean, true>(a, grid, lds, stream);
+    }
+    if (a.metric == kCosine) return launch_mq_score_i8_t<NB, kCosine, false>(a, grid, lds, stream);
+    return launch_mq_score_i8_t<NB, kEuclidean, false>(a, grid, lds, stream);
 }
 }  // namespace
 
@@ -556,11 +698,13 @@ hipError_t launch_mq_score_i8(const MqArgs &a, int nb, int grid, hipStream_t str
 hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_rows,
                             const uint64_t *live_bits, const uint64_t *allow_bits,
                             uint32_t allow_stride, int kp, int n_queries, int blocks_per_query,
-                            uint64_t *block_lists, hipStream_t stream)
+                            uint64_t *block_lists, hipStream_t stream, float *thr_out, uint32_t *count_zero)
 {
+    if (thr_out && blocks_per_query != 1) return hipErrorInvalidValue;
     const size_t lds = (size_t)4 * kp * sizeof(uint64_t);
     hipLaunchKernelGGL(mq_select_kernel, dim3(blocks_per_query, n_queries), dim3(256), lds, stream, keys,
-                       key_stride, n_rows, live_bits, allow_bits, allow_stride, kp, block_lists);
+                       key_stride, n_rows, live_bits, allow_bits, allow_stride, kp, block_lists, thr_out,
+                       count_zero);
     return hipGetLastError();
 }
 

@@ -171,6 +171,15 @@ struct Ctx {
     size_t h_mq_cap = 0, d_mq_cap = 0;
     float *d_keys = nullptr;
     size_t keys_cap = 0;           // floats
+    // fused selection of the shared sweep: thresholds, candidate buffers, hit counts
+    float *d_thr = nullptr;
+    uint64_t *d_cand = nullptr;
+    size_t cand_cap_total = 0;     // entries
+    uint32_t *d_cand_count = nullptr, *h_cand_count = nullptr;
+    bool mq_fused_used = false;
+    uint32_t mq_cand_cap = 0;
+    int mq_nb = 0;
+    bool mq_has_allow = false;
     bool timed_scan = false;
     int timed_n = 0;               // scan launches between ev_scan0 and ev_scan1
     QMeta meta[kMaxBatch];         // constants of the staged queries
@@ -223,6 +232,7 @@ struct szg_index {
     int tie_mode = 0;         // 0: exact full replay on ties/NaN, 1: keep the fast answer
     int serialize_scans = 1;  // scan launches of a shard never overlap each other
     int multi_query = 1;      // share one sweep between the queries of a batch (MFMA path)
+    int mq_fused = 1;         // shared sweep: threshold-collect selection instead of a score matrix
     int mq_i8 = 1;            // 8-bit rows: exact integer shared sweep (v_mfma_i32_16x16x64_i8)
     int mq_tail_overlap = 0;  // shared sweep: post-processing of a batch beside the next batch's sweep
     int mq_min = 8;           // smallest batch worth a shared sweep
@@ -439,6 +449,10 @@ void ctx_free(Ctx *c)
     (void)hipFree(c->d_count);
     (void)hipHostFree(c->h_mq);
     (void)hipFree(c->d_mq);
+    (void)hipFree(c->d_thr);
+    (void)hipFree(c->d_cand);
+    (void)hipFree(c->d_cand_count);
+    (void)hipHostFree(c->h_cand_count);
     (void)hipFree(c->d_keys);
     delete c;
 }
@@ -676,7 +690,8 @@ int mq_blocks(const szg_index *ix, int nq)
 
 // top-k pass for the nq staged queries through ONE shared sweep:
 // score matrix -> per-query selection -> merges -> rerank -> D2H (async)
-int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bool has_allow)
+int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bool has_allow,
+                    bool force_matrix = false)
 {
     HIPCHK(hipSetDevice(sh->device));
     const int r16 = ix->map.r16;
@@ -685,9 +700,6 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     int rc = ensure_host(&c->h_mq, &c->h_mq_cap, img);
     if (rc) return rc;
     rc = ensure_dev(&c->d_mq, &c->d_mq_cap, img);
-    if (rc) return rc;
-    const size_t key_stride = ((size_t)sh->n_rows + 3) & ~(size_t)3;
-    rc = ensure_dev(&c->d_keys, &c->keys_cap, key_stride * nq);
     if (rc) return rc;
     memset(c->h_mq, 0, img);
     if (i8) {
@@ -750,6 +762,32 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     rc = ensure_host(&c->h_out, &c->h_out_cap, (size_t)nq * kp);
     if (rc) return rc;
 
+    // Fused selection: sweep a prefix of the rows into a small score matrix, take each
+    // query's kp-th best key there as its threshold, then sweep everything and collect the
+    // (query, row) pairs at or below their threshold -- about `hits` per query -- instead of
+    // writing and re-reading n_rows x batch keys.  Every row outside a query's buffer has a
+    // key above the threshold, which is >= the kp-th kept key: certification is unchanged.
+    const uint64_t hits = std::max<uint64_t>(1024, 16ull * kp);
+    uint64_t prefix = ((sh->n_rows * (uint64_t)kp + hits - 1) / hits + 15) & ~15ull;
+    prefix = std::max<uint64_t>(prefix, 16ull * kp);
+    const bool fused = ix->mq_fused && !force_matrix && prefix * 4 <= sh->n_rows;
+    const uint32_t cand_cap = (uint32_t)(4 * hits);
+    const size_t key_stride = fused ? (size_t)prefix : (((size_t)sh->n_rows + 3) & ~(size_t)3);
+    rc = ensure_dev(&c->d_keys, &c->keys_cap, key_stride * nq);
+    if (rc) return rc;
+    if (fused) {
+        if (!c->d_thr) HIPCHK(hipMalloc((void **)&c->d_thr, 64 * sizeof(float)));
+        if (!c->d_cand_count) HIPCHK(hipMalloc((void **)&c->d_cand_count, 64 * sizeof(uint32_t)));
+        if (!c->h_cand_count)
+            HIPCHK(hipHostMalloc((void **)&c->h_cand_count, 64 * sizeof(uint32_t), hipHostMallocDefault));
+        rc = ensure_dev(&c->d_cand, &c->cand_cap_total, (size_t)cand_cap * nq);
+        if (rc) return rc;
+    }
+    c->mq_fused_used = fused;
+    c->mq_cand_cap = cand_cap;
+    c->mq_nb = nb;
+    c->mq_has_allow = has_allow;
+
     szg::MqArgs a;
     memset(&a, 0, sizeof(a));
     a.rows = sh->rows;
@@ -776,11 +814,48 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
             HIPCHK(hipEventRecord(c->ev_up, c->stream));
             HIPCHK(hipStreamWaitEvent(st, c->ev_up, 0));
         }
-        if (ix->timing) HIPCHK(hipEventRecord(c->ev_scan0, st));
-        if (i8)
-            HIPCHK(szg::launch_mq_score_i8(a, nb, sh->cu_count, st));
-        else
-            HIPCHK(szg::launch_mq_score(ix->bits, a, nb, sh->cu_count, st));
+        auto launch_score = [&](const szg::MqArgs &x) -> hipError_t {
+            return i8 ? szg::launch_mq_score_i8(x, nb, sh->cu_count, st)
+                      : szg::launch_mq_score(ix->bits, x, nb, sh->cu_count, st);
+        };
+        // score matrix of rows [0, n_sel) -> per-query sorted list of kp (returns its buffer)
+        auto select_chain = [&](uint32_t n_sel, size_t kstride, hipStream_t s2, uint64_t **out) -> hipError_t {
+            hipError_t e = szg::launch_mq_select(c->d_keys, kstride, n_sel, sh->has_dead ? sh->live_bits : nullptr,
+                                                 has_allow ? c->d_allow : nullptr, (uint32_t)shard_words(sh),
+                                                 kp, nq, sb, c->d_lists_a, s2);
+            int n_lists = sb;
+            uint64_t *src = c->d_lists_a, *dst = c->d_lists_b;
+            const int fan = szg::merge_fan(kp);
+            while (e == hipSuccess && n_lists > 1) {
+                e = szg::launch_merge(src, n_lists, kp, nq, dst, s2);
+                n_lists = (n_lists + fan - 1) / fan;
+                std::swap(src, dst);
+            }
+            *out = src;
+            return e;
+        };
+        uint64_t *src = nullptr;
+        if (fused) {
+            szg::MqArgs pa = a;  // the prefix, into the (small) score matrix
+            pa.n_rows = (uint32_t)prefix;
+            HIPCHK(launch_score(pa));
+            // one block per query selects over the prefix's keys, publishes the query's
+            // threshold and zeroes its hit counter
+            HIPCHK(szg::launch_mq_select(c->d_keys, key_stride, (uint32_t)prefix,
+                                         sh->has_dead ? sh->live_bits : nullptr, has_allow ? c->d_allow : nullptr,
+                                         (uint32_t)shard_words(sh), kp, nq, 1, c->d_lists_a, st, c->d_thr,
+                                         c->d_cand_count));
+            a.collect = 1;
+            a.thr = c->d_thr;
+            a.cand_buf = c->d_cand;
+            a.cand_count = c->d_cand_count;
+            a.cand_cap = cand_cap;
+            a.live_bits = sh->has_dead ? sh->live_bits : nullptr;
+            a.allow_bits = has_allow ? c->d_allow : nullptr;
+            a.allow_stride = (uint32_t)shard_words(sh);
+        }
+        if (ix->timing) HIPCHK(hipEventRecord(c->ev_scan0, st));  // the full sweep (not the prefix pass)
+        HIPCHK(launch_score(a));
         if (ix->timing) {
             HIPCHK(hipEventRecord(c->ev_scan1, st));
             c->timed_scan = true;
@@ -795,17 +870,13 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
             HIPCHK(hipStreamWaitEvent(c->stream, c->ev_scan_done, 0));
             tail = c->stream;
         }
-        HIPCHK(szg::launch_mq_select(c->d_keys, key_stride, (uint32_t)sh->n_rows,
-                                     sh->has_dead ? sh->live_bits : nullptr,
-                                     has_allow ? c->d_allow : nullptr, (uint32_t)shard_words(sh), kp, nq,
-                                     sb, c->d_lists_a, tail));
-        int n_lists = sb;
-        uint64_t *src = c->d_lists_a, *dst = c->d_lists_b;
-        const int fan = szg::merge_fan(kp);
-        while (n_lists > 1) {
-            HIPCHK(szg::launch_merge(src, n_lists, kp, nq, dst, tail));
-            n_lists = (n_lists + fan - 1) / fan;
-            std::swap(src, dst);
+        if (fused) {
+            HIPCHK(szg::launch_cand_select(c->d_cand, c->d_cand_count, cand_cap, kp, nq, c->d_lists_a, tail));
+            src = c->d_lists_a;
+            HIPCHK(hipMemcpyAsync(c->h_cand_count, c->d_cand_count, 64 * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, tail));
+        } else {
+            HIPCHK(select_chain((uint32_t)sh->n_rows, key_stride, tail, &src));
         }
         HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64, src,
                                   nullptr, (uint32_t)kp, nq, c->d_out, tail));
@@ -1015,6 +1086,28 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
             if (e == hipSuccess) e = hipStreamSynchronize(t.ctx[s]->stream);
             if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "hipStreamSynchronize", e);
             if (rc == SZG_OK) rc = finish_timing(ix, t.ctx[s]);
+            // fused selection: a query whose candidate buffer overflowed (threshold from the
+            // prefix too loose: duplicates, sorted corpora) sends the batch down the matrix path
+            Ctx *c = t.ctx[s];
+            if (rc == SZG_OK && c->mq_fused_used) {
+                bool overflow = false;
+                for (int j = 0; j < t.nq; j++) overflow |= c->h_cand_count[j] > c->mq_cand_cap;
+                c->mq_fused_used = false;
+                if (overflow) {
+                    {
+                        std::lock_guard<std::mutex> lk(ix->stats_mu);
+                        ix->stats.mq_launches -= 1;  // counted again by the rerun
+                        ix->stats.mq_queries -= (uint64_t)t.nq;
+                        ix->stats.mq_fallbacks += 1;
+                    }
+                    rc = enqueue_topk_mq(ix, sh, c, t.kp, t.nq, c->mq_nb, c->mq_has_allow, true);
+                    if (rc == SZG_OK) {
+                        e = hipStreamSynchronize(c->stream);
+                        if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "hipStreamSynchronize", e);
+                    }
+                    if (rc == SZG_OK) rc = finish_timing(ix, c);
+                }
+            }
         }
         // gather every query's candidates first: the escalation and replay paths
         // below reuse the contexts' output buffers
@@ -1917,6 +2010,8 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
     } else if (n == "mq_blocks") {
         if (value < 1 || value > 3) return fail(SZG_E_INVALID, "mq_blocks must be 1..3");
         ix->mq_blocks_max = (int)value;
+    } else if (n == "mq_fused") {
+        ix->mq_fused = value != 0;
     } else if (n == "mq_i8") {
         ix->mq_i8 = value != 0;
     } else if (n == "mq_tail_overlap") {

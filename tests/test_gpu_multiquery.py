@@ -157,3 +157,35 @@ def test_shared_sweep_int8_mfma(metric, dim, n):
             check(ix, rows, dim, Q, 10, bits=8, metric=metric)
             assert ix.stats()["mq_queries"] == 48
             check(ix, rows, dim, Q[:17], 33, allow=allow, bits=8, metric=metric)
+
+
+@pytest.mark.parametrize("bits", [8, 32])
+def test_fused_selection_overflow_falls_back(bits):
+    """The shared sweep collects (query, row) pairs under a threshold taken from a prefix of the
+    rows.  When the prefix is unrepresentative -- rows sorted worst-first, or one vector repeated
+    thousands of times -- the candidate buffers overflow and the batch is redone through the
+    score matrix; answers stay the oracle's either way (and equal with mq_fused=0)."""
+    dim, n = 32, 60000
+    rng = np.random.default_rng(3)
+    q0 = rng.standard_normal(dim)
+    vec = rng.uniform(-1, 1, (n, dim))
+    order = np.argsort(vec @ q0)              # worst match first, best last
+    vec = vec[order]
+    vec[1000:31000] = vec[500]                # 30 000 copies of one vector
+    rows = orc.encode_rows(vec, bits)
+    Q = np.vstack([q0 + 0.01 * rng.standard_normal(dim) for _ in range(16)])
+    Q[3] = vec[500]                           # the repeated vector itself
+    with ScanIndex(dim, bits, SZG_COSINE) as ix:
+        ix.load(rows)
+        ix.set_option("tie_mode", 1)          # ties here are by construction; order among them is not the point
+        r1, d1, c1 = ix.search_topk(Q, 10)
+        assert ix.stats()["mq_fallbacks"] == 1
+        ix.set_option("mq_fused", 0)
+        r0, d0, c0 = ix.search_topk(Q, 10)
+        assert ix.stats()["mq_queries"] == 32
+        for qi in range(Q.shape[0]):
+            o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, 1, Q[qi], k=10)
+            for d in (d1, d0):
+                got = np.sort(d[qi, : c1[qi]])
+                want = np.sort(o_dist)
+                assert ((got == want) | (np.isnan(got) & np.isnan(want))).all(), qi
