@@ -25,11 +25,20 @@
 #include "kernels.h"
 #include "device_lists.h"
 
+// Built six times (parallel build, like kernels_scan.hip): -DSZG_MQ_PART=4/16/32 and 8
+// carry mq_score_kernel for one element width, -DSZG_MQ_PART=1 the int8 sweep, and the
+// default (0) the selection kernels and the dispatchers.
+#ifndef SZG_MQ_PART
+#define SZG_MQ_PART 0
+#endif
+#define SZG_CAT2(a, b) a##b
+#define SZG_CAT(a, b) SZG_CAT2(a, b)
+
 namespace szg {
 
 namespace {
 
-constexpr int kRingMq = 6;
+[[maybe_unused]] constexpr int kRingMq = 6;
 
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -46,7 +55,7 @@ __device__ __forceinline__ u32x4 load_nt(const uint8_t *p)
 // quantized rows as the odd integer n = 2v - maxInt (dequantize(v) = n / maxInt up
 // to rounding; the common 1/maxInt cancels in -cos).  Elements past `dim` (row
 // padding) read as 0.
-template <int QBITS>
+template <int QBITS, bool CHECK = true>
 __device__ __forceinline__ void decode_dword(uint32_t w, int e0, int dim, float *x)
 {
     constexpr int N = 32 / QBITS;  // elements per dword
@@ -66,7 +75,7 @@ __device__ __forceinline__ void decode_dword(uint32_t w, int e0, int dim, float 
             x[2 * k + 1] = fmaf((float)(byte & 0xFu), 2.0f, -15.0f);
         }
     }
-    if (QBITS != 32 && e0 + N > dim) {
+    if (CHECK && QBITS != 32 && e0 + N > dim) {
 #pragma unroll
         for (int i = 0; i < N; i++)
             if (e0 + i >= dim) x[i] = 0.0f;
@@ -118,8 +127,14 @@ __device__ __forceinline__ void hit_offer(const MqArgs &a, HitBuf &hb, int lane,
     hb.n += cnt;
 }
 
+#if SZG_MQ_PART >= 4
 // LDS image of the batch: [piece j][query block][group of 4 elements][query 16][4 floats]
-template <int NB, int QBITS, int METRIC, bool COLLECT>
+// FAST: rows are whole 64-byte steps of real elements (r16 % 4 == 0, dim a multiple of the
+// elements per piece) -- no per-piece range predicates, the row and LDS addresses advance
+// by constants.  MFMA and VALU instructions do not co-issue on this part (PMC:
+// SQ_VALU_MFMA_COEXEC_CYCLES = 0), so every VALU instruction shaved off the piece loop
+// is matrix-core time gained: 43 -> ~10 per piece.
+template <int NB, int QBITS, int METRIC, bool COLLECT, bool FAST = false>
 __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 {
     constexpr int E = 128 / QBITS;  // elements per 16-byte piece
@@ -175,6 +190,66 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
     float4 qn[NB];  // A operands of the group about to be multiplied (one ahead)
 #pragma unroll
     for (int b = 0; b < NB; b++) qn[b] = qlds[((min(c, r16 - 1) * NB + b) * G4) * 16 + trow];
+
+    // FAST cursors: the lane's next piece in HBM and its A operands' slot in LDS
+    auto row_ptr = [&](uint64_t tile) -> const uint8_t * {
+        const uint64_t r = min(tile * 16 + trow, (uint64_t)a.n_rows - 1);  // past the end: a valid row, discarded
+        return a.rows + r * a.pitch + (size_t)c * 16;
+    };
+    const uint8_t *iptr = row_ptr(tile_first);
+    const int qbase = c * NB * G4 * 16 + trow;  // float4 index of (this lane's chunk, step 0)
+    const int qstep = 4 * NB * G4 * 16;         // per 64-byte step
+
+#define MQF_ISSUE(u)                                                                     \
+    {                                                                                    \
+        ring[u] = load_nt(iptr);                                                         \
+        if (++is == steps) {                                                             \
+            is = 0;                                                                      \
+            itile += tile_stride;                                                        \
+            iptr = row_ptr(itile);                                                       \
+        } else {                                                                         \
+            iptr += 64;                                                                  \
+        }                                                                                \
+    }
+
+#define MQF_CONSUME(u)                                                                   \
+    {                                                                                    \
+        const u32x4 v_ = ring[u];                                                        \
+        const uint32_t w_[4] = {v_.x, v_.y, v_.z, v_.w};                                 \
+        float x_[E];                                                                     \
+        _Pragma("unroll") for (int d = 0; d < 4; d++)                                    \
+            decode_dword<QBITS, false>(w_[d], 0, 0, x_ + d * N);                         \
+        _Pragma("unroll") for (int i = 0; i < E; i++) nrm = fmaf(x_[i], x_[i], nrm);     \
+        const int qcur_ = qbase + cs * qstep;                                            \
+        const int qnext_ = qbase + (cs + 1 == steps ? 0 : cs + 1) * qstep;               \
+        _Pragma("unroll") for (int g = 0; g < G4; g++)                                   \
+        {                                                                                \
+            float4 qc_[NB];                                                              \
+            _Pragma("unroll") for (int b = 0; b < NB; b++) qc_[b] = qn[b];               \
+            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
+                qn[b] = g + 1 < G4 ? qlds[qcur_ + (b * G4 + g + 1) * 16]                 \
+                                   : qlds[qnext_ + (b * G4) * 16];                       \
+            /* element-major: consecutive MFMAs feed different accumulators */           \
+            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc_[b].x, x_[4 * g], acc[b], 0, 0, 0);     \
+            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc_[b].y, x_[4 * g + 1], acc[b], 0, 0, 0); \
+            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc_[b].z, x_[4 * g + 2], acc[b], 0, 0, 0); \
+            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc_[b].w, x_[4 * g + 3], acc[b], 0, 0, 0); \
+        }                                                                                \
+        if (QBITS == 32) {                                                               \
+            nz |= v_.x | v_.y;                                                           \
+            nz |= v_.z | v_.w;                                                           \
+        }                                                                                \
+        if (++cs == steps) {                                                             \
+            if (QBITS == 32) nz &= 0x7FFFFFFFu; else nz = 1u;                            \
+            finish_tile(ctile);                                                          \
+            cs = 0;                                                                      \
+            ctile += tile_stride;                                                        \
+        }                                                                                \
+    }
 
 #define MQ_ISSUE(u)                                                                      \
     {                                                                                    \
@@ -284,40 +359,52 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
     // Unconditional prologue (a load past the wave's share reads the dummy piece and is
     // never consumed) and pinned issue order: the compiler can then wait for slot u with
     // vmcnt(kRingMq - 1) instead of draining the queue.
-    uint64_t issued = kRingMq, consumed = 0;
-#pragma unroll
-    for (int u = 0; u < kRingMq; u++) {
-        MQ_ISSUE(u)
-        __builtin_amdgcn_sched_barrier(0);
+#define MQ_RUN_RING(ISSUE, CONSUME)                                                      \
+    {                                                                                    \
+        uint64_t issued = kRingMq, consumed = 0;                                         \
+        _Pragma("unroll") for (int u = 0; u < kRingMq; u++)                              \
+        {                                                                                \
+            ISSUE(u)                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                           \
+        }                                                                                \
+        while (consumed + 2 * kRingMq <= NP) {                                           \
+            _Pragma("unroll") for (int u = 0; u < kRingMq; u++)                          \
+            {                                                                            \
+                CONSUME(u)                                                               \
+                ISSUE(u)                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                       \
+            }                                                                            \
+            consumed += kRingMq;                                                         \
+            issued += kRingMq;                                                           \
+        }                                                                                \
+        while (consumed < NP) {                                                          \
+            _Pragma("unroll") for (int u = 0; u < kRingMq; u++)                          \
+            {                                                                            \
+                if (consumed < NP) {                                                     \
+                    CONSUME(u)                                                           \
+                    consumed++;                                                          \
+                    if (issued < NP) {                                                   \
+                        ISSUE(u)                                                         \
+                        issued++;                                                        \
+                    }                                                                    \
+                }                                                                        \
+            }                                                                            \
+        }                                                                                \
     }
-    while (consumed + 2 * kRingMq <= NP) {
-#pragma unroll
-        for (int u = 0; u < kRingMq; u++) {
-            MQ_CONSUME(u)
-            MQ_ISSUE(u)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        consumed += kRingMq;
-        issued += kRingMq;
-    }
-    while (consumed < NP) {
-#pragma unroll
-        for (int u = 0; u < kRingMq; u++) {
-            if (consumed < NP) {
-                MQ_CONSUME(u)
-                consumed++;
-                if (issued < NP) {
-                    MQ_ISSUE(u)
-                    issued++;
-                }
-            }
-        }
-    }
+    if (FAST)
+        MQ_RUN_RING(MQF_ISSUE, MQF_CONSUME)
+    else
+        MQ_RUN_RING(MQ_ISSUE, MQ_CONSUME)
+#undef MQF_ISSUE
+#undef MQF_CONSUME
 #undef MQ_ISSUE
 #undef MQ_CONSUME
     if (COLLECT) hit_flush(a, hb, lane);
 }
 
+#endif  // SZG_MQ_PART >= 4
+
+#if SZG_MQ_PART == 1
 // ---- exact integer shared sweep, 8-bit rows ---------------------------------------
 //
 // With v' = v - 128 (one xor per dword) the decoded element is n = 2v' + 1, and the
@@ -332,7 +419,7 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 // and its error bound (key_eps, integer branch) are the single-query path's.
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
-template <int NB, int METRIC, bool COLLECT>
+template <int NB, int METRIC, bool COLLECT, bool FAST = false>
 __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
 {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -389,6 +476,59 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
     for (int p = 0; p < 3; p++)
 #pragma unroll
         for (int b = 0; b < NB; b++) qn[p][b] = qimg[(p * NB + b) * 64 + lane];
+
+    // FAST (r16 % 4 == 0): no range predicates, addresses advance by constants
+    auto row_ptr = [&](uint64_t tile) -> const uint8_t * {
+        const uint64_t r = min(tile * 16 + trow, (uint64_t)a.n_rows - 1);
+        return a.rows + r * a.pitch + (size_t)c * 16;
+    };
+    const uint8_t *iptr = row_ptr(tile_first);
+    const int qstep8 = 3 * NB * 64;  // 16-byte words of the image per 64-byte step
+
+#define MQ8F_ISSUE(u)                                                                    \
+    {                                                                                    \
+        ring[u] = load_nt(iptr);                                                         \
+        if (++is == steps) {                                                             \
+            is = 0;                                                                      \
+            itile += tile_stride;                                                        \
+            iptr = row_ptr(itile);                                                       \
+        } else {                                                                         \
+            iptr += 64;                                                                  \
+        }                                                                                \
+    }
+
+#define MQ8F_CONSUME(u)                                                                  \
+    {                                                                                    \
+        const u32x4 v_ = ring[u];                                                        \
+        v4i32 w_;                                                                        \
+        w_.x = (int)(v_.x ^ 0x80808080u);                                                \
+        w_.y = (int)(v_.y ^ 0x80808080u);                                                \
+        w_.z = (int)(v_.z ^ 0x80808080u);                                                \
+        w_.w = (int)(v_.w ^ 0x80808080u);                                                \
+        v4i32 qc_[3][NB];                                                                \
+        _Pragma("unroll") for (int p = 0; p < 3; p++)                                    \
+            _Pragma("unroll") for (int b = 0; b < NB; b++) qc_[p][b] = qn[p][b];         \
+        const int qnext_ = lane + (cs + 1 == steps ? 0 : cs + 1) * qstep8;               \
+        _Pragma("unroll") for (int p = 0; p < 3; p++)                                    \
+            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
+                qn[p][b] = qimg[qnext_ + (p * NB + b) * 64];                             \
+        _Pragma("unroll") for (int p = 0; p < 3; p++)                                    \
+            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
+                acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qc_[p][b], w_, acc[p][b], 0, 0, 0); \
+        SQ = __builtin_amdgcn_sdot4(w_.x, w_.x, SQ, false);                              \
+        SQ = __builtin_amdgcn_sdot4(w_.y, w_.y, SQ, false);                              \
+        SQ = __builtin_amdgcn_sdot4(w_.z, w_.z, SQ, false);                              \
+        SQ = __builtin_amdgcn_sdot4(w_.w, w_.w, SQ, false);                              \
+        SV = __builtin_amdgcn_sdot4(w_.x, 0x01010101, SV, false);                        \
+        SV = __builtin_amdgcn_sdot4(w_.y, 0x01010101, SV, false);                        \
+        SV = __builtin_amdgcn_sdot4(w_.z, 0x01010101, SV, false);                        \
+        SV = __builtin_amdgcn_sdot4(w_.w, 0x01010101, SV, false);                        \
+        if (++cs == steps) {                                                             \
+            finish_tile8(ctile);                                                         \
+            cs = 0;                                                                      \
+            ctile += tile_stride;                                                        \
+        }                                                                                \
+    }
 
 #define MQ8_ISSUE(u)                                                                     \
     {                                                                                    \
@@ -475,40 +615,53 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
         SV = 0;
     };
 
-    uint64_t issued = kRingMq, consumed = 0;
-#pragma unroll
-    for (int u = 0; u < kRingMq; u++) {
-        MQ8_ISSUE(u)
-        __builtin_amdgcn_sched_barrier(0);
+#define MQ8_RUN_RING(ISSUE, CONSUME)                                                     \
+    {                                                                                    \
+        uint64_t issued = kRingMq, consumed = 0;                                         \
+        _Pragma("unroll") for (int u = 0; u < kRingMq; u++)                              \
+        {                                                                                \
+            ISSUE(u)                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                           \
+        }                                                                                \
+        while (consumed + 2 * kRingMq <= NP) {                                           \
+            _Pragma("unroll") for (int u = 0; u < kRingMq; u++)                          \
+            {                                                                            \
+                CONSUME(u)                                                               \
+                ISSUE(u)                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                       \
+            }                                                                            \
+            consumed += kRingMq;                                                         \
+            issued += kRingMq;                                                           \
+        }                                                                                \
+        while (consumed < NP) {                                                          \
+            _Pragma("unroll") for (int u = 0; u < kRingMq; u++)                          \
+            {                                                                            \
+                if (consumed < NP) {                                                     \
+                    CONSUME(u)                                                           \
+                    consumed++;                                                          \
+                    if (issued < NP) {                                                   \
+                        ISSUE(u)                                                         \
+                        issued++;                                                        \
+                    }                                                                    \
+                }                                                                        \
+            }                                                                            \
+        }                                                                                \
     }
-    while (consumed + 2 * kRingMq <= NP) {
-#pragma unroll
-        for (int u = 0; u < kRingMq; u++) {
-            MQ8_CONSUME(u)
-            MQ8_ISSUE(u)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        consumed += kRingMq;
-        issued += kRingMq;
-    }
-    while (consumed < NP) {
-#pragma unroll
-        for (int u = 0; u < kRingMq; u++) {
-            if (consumed < NP) {
-                MQ8_CONSUME(u)
-                consumed++;
-                if (issued < NP) {
-                    MQ8_ISSUE(u)
-                    issued++;
-                }
-            }
-        }
-    }
+    if (FAST)
+        MQ8_RUN_RING(MQ8F_ISSUE, MQ8F_CONSUME)
+    else
+        MQ8_RUN_RING(MQ8_ISSUE, MQ8_CONSUME)
+#undef MQ8F_ISSUE
+#undef MQ8F_CONSUME
+#undef MQ8_RUN_RING
 #undef MQ8_ISSUE
 #undef MQ8_CONSUME
     if (COLLECT) hit_flush(a, hb, lane);
 }
 
+#endif  // SZG_MQ_PART == 1
+
+#if SZG_MQ_PART == 0
 // ---- per-query selection over the score matrix ----------------------------------
 
 // grid (blocks per query, queries).  Each lane reads 4 keys at a time (16 bytes);
@@ -591,8 +744,11 @@ __global__ __launch_bounds__(256) void cand_select_kernel(const uint64_t *cand_b
     block_merge_lists(wl_lds, nwaves, kp, lists + (size_t)q * kp, tid, blockDim.x);
 }
 
+#endif  // SZG_MQ_PART == 0
+
 }  // namespace
 
+#if SZG_MQ_PART == 0
 hipError_t launch_mq_thr(const uint64_t *lists, int kp, int n_queries, float *thr, hipStream_t stream)
 {
     hipLaunchKernelGGL(mq_thr_kernel, dim3(1), dim3(64), 0, stream, lists, kp, n_queries, thr);
@@ -610,26 +766,36 @@ hipError_t launch_cand_select(const uint64_t *cand_buf, const uint32_t *cand_cou
 
 size_t mq_lds_bytes(int qbits, int r16, int nb) { return (size_t)r16 * nb * (128 / qbits) * 16 * 4; }  // image only
 
+#endif
+
+#if SZG_MQ_PART >= 4
 namespace {
-template <int NB, int QBITS, int METRIC, bool COLLECT>
+template <int NB, int QBITS, int METRIC, bool COLLECT, bool FAST>
 hipError_t launch_mq_score_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void *>(&mq_score_kernel<NB, QBITS, METRIC, COLLECT>),
+        reinterpret_cast<const void *>(&mq_score_kernel<NB, QBITS, METRIC, COLLECT, FAST>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mq_score_kernel<NB, QBITS, METRIC, COLLECT>), dim3(grid), dim3(1024), lds, stream, a);
+    hipLaunchKernelGGL((mq_score_kernel<NB, QBITS, METRIC, COLLECT, FAST>), dim3(grid), dim3(1024), lds, stream,
+                       a);
     return hipGetLastError();
 }
 template <int NB, int QBITS>
 hipError_t launch_mq_score_m(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
-    if (a.collect) {
-        if (a.metric == kCosine) return launch_mq_score_t<NB, QBITS, kCosine, true>(a, grid, lds, stream);
-        return launch_mq_score_t<NB, QBITS, kEuclidean, true>(a, grid, lds, stream);
+    if (a.collect) {  // the full sweep: predicate-free kernel when the row shape allows
+        const bool fast = a.r16 % 4 == 0 && a.dim % (128 / QBITS) == 0 && a.n_rows > 0;
+        if (fast) {
+            if (a.metric == kCosine)
+                return launch_mq_score_t<NB, QBITS, kCosine, true, true>(a, grid, lds, stream);
+            return launch_mq_score_t<NB, QBITS, kEuclidean, true, true>(a, grid, lds, stream);
+        }
+        if (a.metric == kCosine) return launch_mq_score_t<NB, QBITS, kCosine, true, false>(a, grid, lds, stream);
+        return launch_mq_score_t<NB, QBITS, kEuclidean, true, false>(a, grid, lds, stream);
     }
-    if (a.metric == kCosine) return launch_mq_score_t<NB, QBITS, kCosine, false>(a, grid, lds, stream);
-    return launch_mq_score_t<NB, QBITS, kEuclidean, false>(a, grid, lds, stream);
+    if (a.metric == kCosine) return launch_mq_score_t<NB, QBITS, kCosine, false, false>(a, grid, lds, stream);
+    return launch_mq_score_t<NB, QBITS, kEuclidean, false, false>(a, grid, lds, stream);
 }
 template <int QBITS>
 hipError_t launch_mq_score_q(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
@@ -643,15 +809,27 @@ hipError_t launch_mq_score_q(const MqArgs &a, int nb, int grid, size_t lds, hipS
 }
 }  // namespace
 
+hipError_t SZG_CAT(launch_mq_score_q, SZG_MQ_PART)(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
+{
+    return launch_mq_score_q<SZG_MQ_PART>(a, nb, grid, lds, stream);
+}
+#endif  // SZG_MQ_PART >= 4
+
+#if SZG_MQ_PART == 0
+hipError_t launch_mq_score_q4(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
+hipError_t launch_mq_score_q8(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
+hipError_t launch_mq_score_q16(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
+hipError_t launch_mq_score_q32(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
+
 hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStream_t stream)
 {
     // + thresholds and the waves' hit buffers (fused selection)
     const size_t lds = mq_lds_bytes(qbits, a.r16, nb) + 48 * sizeof(float) + (size_t)16 * kHitCap * 9;
     switch (qbits) {
-    case 4: return launch_mq_score_q<4>(a, nb, grid, lds, stream);
-    case 8: return launch_mq_score_q<8>(a, nb, grid, lds, stream);
-    case 16: return launch_mq_score_q<16>(a, nb, grid, lds, stream);
-    case 32: return launch_mq_score_q<32>(a, nb, grid, lds, stream);
+    case 4: return launch_mq_score_q4(a, nb, grid, lds, stream);
+    case 8: return launch_mq_score_q8(a, nb, grid, lds, stream);
+    case 16: return launch_mq_score_q16(a, nb, grid, lds, stream);
+    case 32: return launch_mq_score_q32(a, nb, grid, lds, stream);
     default: return hipErrorInvalidValue;
     }
 }
@@ -662,25 +840,34 @@ size_t mq_i8_lds_bytes(int r16, int nb)
     return mq_i8_image_bytes(r16, nb) + 4 * 48 * sizeof(float) + (size_t)12 * 64 * 9;
 }
 
+#endif  // SZG_MQ_PART == 0
+
+#if SZG_MQ_PART == 1
+size_t mq_i8_lds_bytes(int r16, int nb);
 namespace {
-template <int NB, int METRIC, bool COLLECT>
+template <int NB, int METRIC, bool COLLECT, bool FAST>
 hipError_t launch_mq_score_i8_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mq_score_i8_kernel<NB, METRIC, COLLECT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void *>(&mq_score_i8_kernel<NB, METRIC, COLLECT, FAST>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mq_score_i8_kernel<NB, METRIC, COLLECT>), dim3(grid), dim3(768), lds, stream, a);
+    hipLaunchKernelGGL((mq_score_i8_kernel<NB, METRIC, COLLECT, FAST>), dim3(grid), dim3(768), lds, stream, a);
     return hipGetLastError();
 }
 template <int NB>
 hipError_t launch_mq_score_i8_m(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
     if (a.collect) {
-        if (a.metric == kCosine) return launch_mq_score_i8_t<NB, kCosine, true>(a, grid, lds, stream);
-        return launch_mq_score_i8_t<NB, kEuclidean, true>(a, grid, lds, stream);
+        if (a.r16 % 4 == 0 && a.n_rows > 0) {  // whole 64-byte steps: the predicate-free kernel
+            if (a.metric == kCosine) return launch_mq_score_i8_t<NB, kCosine, true, true>(a, grid, lds, stream);
+            return launch_mq_score_i8_t<NB, kEuclidean, true, true>(a, grid, lds, stream);
+        }
+        if (a.metric == kCosine) return launch_mq_score_i8_t<NB, kCosine, true, false>(a, grid, lds, stream);
+        return launch_mq_score_i8_t<NB, kEuclidean, true, false>(a, grid, lds, stream);
     }
-    if (a.metric == kCosine) return launch_mq_score_i8_t<NB, kCosine, false>(a, grid, lds, stream);
-    return launch_mq_score_i8_t<NB, kEuclidean, false>(a, grid, lds, stream);
+    if (a.metric == kCosine) return launch_mq_score_i8_t<NB, kCosine, false, false>(a, grid, lds, stream);
+    return launch_mq_score_i8_t<NB, kEuclidean, false, false>(a, grid, lds, stream);
 }
 }  // namespace
 
@@ -695,6 +882,9 @@ hipError_t launch_mq_score_i8(const MqArgs &a, int nb, int grid, hipStream_t str
     }
 }
 
+#endif  // SZG_MQ_PART == 1
+
+#if SZG_MQ_PART == 0
 hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_rows,
                             const uint64_t *live_bits, const uint64_t *allow_bits,
                             uint32_t allow_stride, int kp, int n_queries, int blocks_per_query,
@@ -707,5 +897,7 @@ hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_row
                        count_zero);
     return hipGetLastError();
 }
+
+#endif
 
 }  // namespace szg
