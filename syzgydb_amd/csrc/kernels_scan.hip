@@ -238,12 +238,7 @@ struct RowAcc<8, METRIC> {
     __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const int r16, const int dim)
     {
         const uint4 *q4 = reinterpret_cast<const uint4 *>(q);
-#ifdef SZG_X_NOQ
-        const uint4 qh = raw, qm = raw, ql = raw;
-        (void)q4; (void)r16;
-#else
         const uint4 qh = q4[j], qm = q4[r16 + j], ql = q4[2 * r16 + j];
-#endif
         const uint32_t w[4] = {raw.x ^ 0x80808080u, raw.y ^ 0x80808080u, raw.z ^ 0x80808080u,
                                raw.w ^ 0x80808080u};
         const uint32_t h[4] = {qh.x, qh.y, qh.z, qh.w};
@@ -251,17 +246,11 @@ struct RowAcc<8, METRIC> {
         const uint32_t l[4] = {ql.x, ql.y, ql.z, ql.w};
 #pragma unroll
         for (int d = 0; d < 4; d++) {
-#ifdef SZG_X_NODOT
-            H += (int)(w[d] ^ h[d] ^ m[d] ^ l[d]);
-            continue;
-#endif
             H = __builtin_amdgcn_sdot4((int)h[d], (int)w[d], H, false);
             M = __builtin_amdgcn_sdot4((int)m[d], (int)w[d], M, false);
             L = __builtin_amdgcn_sdot4((int)l[d], (int)w[d], L, false);
-#ifndef SZG_X_NONORM
             SQ = __builtin_amdgcn_sdot4((int)w[d], (int)w[d], SQ, false);
             SV = __builtin_amdgcn_sdot4((int)w[d], 0x01010101, SV, false);
-#endif
         }
     }
     __device__ __forceinline__ float finish(const QConst &a, const Grp &g, bool lead)
@@ -289,13 +278,8 @@ struct RowAcc<4, METRIC> {
     __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const int r16, const int dim)
     {
         const uint4 *q4 = reinterpret_cast<const uint4 *>(q);
-#ifdef SZG_X_NOQ
-        const uint4 p0 = raw, p1 = raw, p2 = raw, p3 = raw, p4 = raw;
-        (void)q4; (void)r16;
-#else
         const uint4 p0 = q4[j], p1 = q4[r16 + j], p2 = q4[2 * r16 + j], p3 = q4[3 * r16 + j],
                     p4 = q4[4 * r16 + j];
-#endif
         const uint32_t w[4] = {raw.x ^ 0x88888888u, raw.y ^ 0x88888888u, raw.z ^ 0x88888888u,
                                raw.w ^ 0x88888888u};
         const uint32_t q0[4] = {p0.x, p0.y, p0.z, p0.w}, q1[4] = {p1.x, p1.y, p1.z, p1.w},
@@ -303,19 +287,13 @@ struct RowAcc<4, METRIC> {
                        q4w[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
         for (int d = 0; d < 4; d++) {
-#ifdef SZG_X_NODOT
-            D0 += (int)(w[d] ^ q0[d] ^ q1[d] ^ q2[d] ^ q3[d] ^ q4w[d]);
-            continue;
-#endif
             D0 = __builtin_amdgcn_sdot8((int)q0[d], (int)w[d], D0, false);
             D1 = __builtin_amdgcn_sdot8((int)q1[d], (int)w[d], D1, false);
             D2 = __builtin_amdgcn_sdot8((int)q2[d], (int)w[d], D2, false);
             D3 = __builtin_amdgcn_sdot8((int)q3[d], (int)w[d], D3, false);
             D4 = __builtin_amdgcn_sdot8((int)q4w[d], (int)w[d], D4, false);
-#ifndef SZG_X_NONORM
             SQ = __builtin_amdgcn_sdot8((int)w[d], (int)w[d], SQ, false);
             SV = __builtin_amdgcn_sdot8((int)w[d], 0x11111111, SV, false);
-#endif
         }
     }
     __device__ __forceinline__ float finish(const QConst &a, const Grp &g, bool lead)

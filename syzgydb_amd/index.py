@@ -4,6 +4,7 @@ One ScanIndex == one szg_index == the HBM mirror of one Collection's packed
 vectors.  All compute happens in libsyzgy_scan.so (HIP, gfx950).
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -50,6 +51,11 @@ class ScanIndex:
         check(self._L.szg_index_create(ctypes.byref(self._h), self.dim, self.quant_bits,
                                        self.metric, dev_arr, n_dev), "szg_index_create")
         self.row_bytes = int(self._L.szg_row_bytes(self.quant_bits, self.dim))
+        # SZG_OPTIONS="name=value,...": tunables applied to every new handle (test sweeps)
+        for item in os.environ.get("SZG_OPTIONS", "").split(","):
+            if "=" in item:
+                name, value = item.split("=", 1)
+                self.set_option(name.strip(), int(value))
 
     # -- lifetime -----------------------------------------------------------
     def close(self):
