@@ -135,9 +135,12 @@ size_t mq_lds_bytes(int qbits, int r16, int nb);
 // the image [64-byte step][digit plane h,m,l][query block][lane = chunk*16 + query][16 bytes]
 // of the queries' balanced int8 digit planes (prep_query), followed by the float table
 // [qscale | qconst | qnorm2][48]; MqArgs.norm_bias as ScanArgs.norm_bias.
-size_t mq_i8_image_bytes(int r16, int nb);   // digit image only
-size_t mq_i8_lds_bytes(int r16, int nb);     // image + constants table
-hipError_t launch_mq_score_i8(const MqArgs &a, int nb, int grid, hipStream_t stream);
+// row_bits = 4: two B operands per piece (high / low nibbles as unsigned bytes), the image
+// is [step][plane][even, odd elements][query block][lane][16 bytes] and the table's qconst
+// entries hold -15 * sum Q (n = 2x - 15).
+size_t mq_i8_image_bytes(int row_bits, int r16, int nb);   // digit image only
+size_t mq_i8_lds_bytes(int row_bits, int r16, int nb);     // image + constants table + hit buffers
+hipError_t launch_mq_score_i8(int row_bits, const MqArgs &a, int nb, int grid, hipStream_t stream);
 hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStream_t stream);  // a.metric picks the key
 hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_rows,
                             const uint64_t *live_bits, const uint64_t *allow_bits,

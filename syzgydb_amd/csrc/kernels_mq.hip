@@ -404,8 +404,8 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 
 #endif  // SZG_MQ_PART >= 4
 
-#if SZG_MQ_PART == 1
-// ---- exact integer shared sweep, 8-bit rows ---------------------------------------
+#if SZG_MQ_PART == 1 || SZG_MQ_PART == 2
+// ---- exact integer shared sweep, 8-bit rows (part 1) and 4-bit rows (part 2) ---------------------------------------
 //
 // With v' = v - 128 (one xor per dword) the decoded element is n = 2v' + 1, and the
 // prepared query is the integer vector Q = 16384 h + 128 m + l of balanced int8 digits
@@ -419,9 +419,15 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 // and its error bound (key_eps, integer branch) are the single-query path's.
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
-template <int NB, int METRIC, bool COLLECT, bool FAST = false>
+template <int NB, int METRIC, bool COLLECT, bool FAST = false, int RB = 8>
 __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
 {
+    // RB = 8: one B operand per 16-byte piece (the bytes, xor 0x80).  RB = 4: two -- the
+    // high nibbles (even elements) and the low nibbles (odd elements) as unsigned bytes
+    // 0..15, against the digit planes of the even / odd elements; n = 2x - 15 turns
+    // sum Q x into sum Q n on the host side of the constants table.
+    constexpr int T = RB == 4 ? 2 : 1;
+    constexpr bool PF = RB == 8;  // prefetch the A operands one step ahead (register budget)
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
     const int nwaves = blockDim.x >> 6;
     const int r16 = a.r16;
     const int steps = (r16 + 3) / 4;  // 64-byte steps per row
-    const int n16 = steps * 3 * NB * 64;  // image, 16-byte words
+    const int n16 = steps * 3 * T * NB * 64;  // image, 16-byte words
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -470,12 +476,17 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
 #pragma unroll
         for (int b = 0; b < NB; b++) acc[p][b] = v4i32{0, 0, 0, 0};
     int SQ = 0, SV = 0;
-    // A operands of the step about to be multiplied (fetched one step ahead)
-    v4i32 qn[3][NB];
+    const int qstep8 = 3 * T * NB * 64;  // 16-byte words of the image per 64-byte step
+    // A operands of the step about to be multiplied (fetched one step ahead when PF)
+    v4i32 qn[3][T][NB];
+    if (PF) {
 #pragma unroll
-    for (int p = 0; p < 3; p++)
+        for (int p = 0; p < 3; p++)
 #pragma unroll
-        for (int b = 0; b < NB; b++) qn[p][b] = qimg[(p * NB + b) * 64 + lane];
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int b = 0; b < NB; b++) qn[p][t][b] = qimg[((p * T + t) * NB + b) * 64 + lane];
+    }
 
     // FAST (r16 % 4 == 0): no range predicates, addresses advance by constants
     auto row_ptr = [&](uint64_t tile) -> const uint8_t * {
@@ -483,7 +494,6 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
         return a.rows + r * a.pitch + (size_t)c * 16;
     };
     const uint8_t *iptr = row_ptr(tile_first);
-    const int qstep8 = 3 * NB * 64;  // 16-byte words of the image per 64-byte step
 
 #define MQ8F_ISSUE(u)                                                                    \
     {                                                                                    \
@@ -494,39 +504,6 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
             iptr = row_ptr(itile);                                                       \
         } else {                                                                         \
             iptr += 64;                                                                  \
-        }                                                                                \
-    }
-
-#define MQ8F_CONSUME(u)                                                                  \
-    {                                                                                    \
-        const u32x4 v_ = ring[u];                                                        \
-        v4i32 w_;                                                                        \
-        w_.x = (int)(v_.x ^ 0x80808080u);                                                \
-        w_.y = (int)(v_.y ^ 0x80808080u);                                                \
-        w_.z = (int)(v_.z ^ 0x80808080u);                                                \
-        w_.w = (int)(v_.w ^ 0x80808080u);                                                \
-        v4i32 qc_[3][NB];                                                                \
-        _Pragma("unroll") for (int p = 0; p < 3; p++)                                    \
-            _Pragma("unroll") for (int b = 0; b < NB; b++) qc_[p][b] = qn[p][b];         \
-        const int qnext_ = lane + (cs + 1 == steps ? 0 : cs + 1) * qstep8;               \
-        _Pragma("unroll") for (int p = 0; p < 3; p++)                                    \
-            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
-                qn[p][b] = qimg[qnext_ + (p * NB + b) * 64];                             \
-        _Pragma("unroll") for (int p = 0; p < 3; p++)                                    \
-            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
-                acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qc_[p][b], w_, acc[p][b], 0, 0, 0); \
-        SQ = __builtin_amdgcn_sdot4(w_.x, w_.x, SQ, false);                              \
-        SQ = __builtin_amdgcn_sdot4(w_.y, w_.y, SQ, false);                              \
-        SQ = __builtin_amdgcn_sdot4(w_.z, w_.z, SQ, false);                              \
-        SQ = __builtin_amdgcn_sdot4(w_.w, w_.w, SQ, false);                              \
-        SV = __builtin_amdgcn_sdot4(w_.x, 0x01010101, SV, false);                        \
-        SV = __builtin_amdgcn_sdot4(w_.y, 0x01010101, SV, false);                        \
-        SV = __builtin_amdgcn_sdot4(w_.z, 0x01010101, SV, false);                        \
-        SV = __builtin_amdgcn_sdot4(w_.w, 0x01010101, SV, false);                        \
-        if (++cs == steps) {                                                             \
-            finish_tile8(ctile);                                                         \
-            cs = 0;                                                                      \
-            ctile += tile_stride;                                                        \
         }                                                                                \
     }
 
@@ -542,39 +519,61 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
         }                                                                                \
     }
 
-#define MQ8_CONSUME(u)                                                                   \
+    // PRED: the piece may be the dummy one (not part of the row): its operands become 0
+#define MQ8_CONSUME_X(u, PRED)                                                           \
     {                                                                                    \
         const u32x4 v_ = ring[u];                                                        \
-        const bool in_ = cs * 4 + c < r16; /* else: the dummy piece, not part of the row */ \
-        v4i32 w_;                                                                        \
-        w_.x = in_ ? (int)(v_.x ^ 0x80808080u) : 0;                                      \
-        w_.y = in_ ? (int)(v_.y ^ 0x80808080u) : 0;                                      \
-        w_.z = in_ ? (int)(v_.z ^ 0x80808080u) : 0;                                      \
-        w_.w = in_ ? (int)(v_.w ^ 0x80808080u) : 0;                                      \
-        v4i32 qc_[3][NB];                                                                \
+        const bool in_ = !(PRED) || cs * 4 + c < r16;                                    \
+        const uint32_t raw_[4] = {v_.x, v_.y, v_.z, v_.w};                               \
+        v4i32 bop_[T];                                                                   \
+        int wn_[4];                                                                      \
+        _Pragma("unroll") for (int d = 0; d < 4; d++)                                    \
+        {                                                                                \
+            if (RB == 8) {                                                               \
+                wn_[d] = in_ ? (int)(raw_[d] ^ 0x80808080u) : 0;                         \
+                bop_[0][d] = wn_[d];                                                     \
+            } else {                                                                     \
+                wn_[d] = in_ ? (int)(raw_[d] ^ 0x88888888u) : 0;                         \
+                bop_[0][d] = in_ ? (int)((raw_[d] >> 4) & 0x0F0F0F0Fu) : 0;              \
+                bop_[T - 1][d] = in_ ? (int)(raw_[d] & 0x0F0F0F0Fu) : 0;                 \
+            }                                                                            \
+        }                                                                                \
+        v4i32 qc_[3][T][NB];                                                             \
+        const int qcur_ = lane + cs * qstep8;                                            \
+        const int qnext_ = lane + (cs + 1 == steps ? 0 : cs + 1) * qstep8;               \
         _Pragma("unroll") for (int p = 0; p < 3; p++)                                    \
-            _Pragma("unroll") for (int b = 0; b < NB; b++) qc_[p][b] = qn[p][b];         \
-        const int csn_ = cs + 1 == steps ? 0 : cs + 1;                                   \
-        _Pragma("unroll") for (int p = 0; p < 3; p++)                                    \
-            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
-                qn[p][b] = qimg[((csn_ * 3 + p) * NB + b) * 64 + lane];                  \
-        _Pragma("unroll") for (int p = 0; p < 3; p++)                                    \
-            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
-                acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qc_[p][b], w_, acc[p][b], 0, 0, 0); \
-        SQ = __builtin_amdgcn_sdot4(w_.x, w_.x, SQ, false);                              \
-        SQ = __builtin_amdgcn_sdot4(w_.y, w_.y, SQ, false);                              \
-        SQ = __builtin_amdgcn_sdot4(w_.z, w_.z, SQ, false);                              \
-        SQ = __builtin_amdgcn_sdot4(w_.w, w_.w, SQ, false);                              \
-        SV = __builtin_amdgcn_sdot4(w_.x, 0x01010101, SV, false);                        \
-        SV = __builtin_amdgcn_sdot4(w_.y, 0x01010101, SV, false);                        \
-        SV = __builtin_amdgcn_sdot4(w_.z, 0x01010101, SV, false);                        \
-        SV = __builtin_amdgcn_sdot4(w_.w, 0x01010101, SV, false);                        \
+            _Pragma("unroll") for (int t = 0; t < T; t++)                                \
+                _Pragma("unroll") for (int b = 0; b < NB; b++)                           \
+                {                                                                        \
+                    if (PF) {                                                            \
+                        qc_[p][t][b] = qn[p][t][b];                                      \
+                        qn[p][t][b] = qimg[qnext_ + ((p * T + t) * NB + b) * 64];        \
+                    } else {                                                             \
+                        qc_[p][t][b] = qimg[qcur_ + ((p * T + t) * NB + b) * 64];        \
+                    }                                                                    \
+                }                                                                        \
+        _Pragma("unroll") for (int t = 0; t < T; t++)                                    \
+            _Pragma("unroll") for (int p = 0; p < 3; p++)                                \
+                _Pragma("unroll") for (int b = 0; b < NB; b++)                           \
+                    acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qc_[p][t][b], bop_[t], acc[p][b], 0, 0, 0); \
+        _Pragma("unroll") for (int d = 0; d < 4; d++)                                    \
+        {                                                                                \
+            if (RB == 8) {                                                               \
+                SQ = __builtin_amdgcn_sdot4(wn_[d], wn_[d], SQ, false);                  \
+                SV = __builtin_amdgcn_sdot4(wn_[d], 0x01010101, SV, false);              \
+            } else {                                                                     \
+                SQ = __builtin_amdgcn_sdot8(wn_[d], wn_[d], SQ, false);                  \
+                SV = __builtin_amdgcn_sdot8(wn_[d], 0x11111111, SV, false);              \
+            }                                                                            \
+        }                                                                                \
         if (++cs == steps) {                                                             \
             finish_tile8(ctile);                                                         \
             cs = 0;                                                                      \
             ctile += tile_stride;                                                        \
         }                                                                                \
     }
+#define MQ8_CONSUME(u) MQ8_CONSUME_X(u, true)
+#define MQ8F_CONSUME(u) MQ8_CONSUME_X(u, false)
 
     auto finish_tile8 = [&](uint64_t tile) {
         int nrm = 4 * (SQ + SV);
@@ -653,13 +652,14 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
         MQ8_RUN_RING(MQ8_ISSUE, MQ8_CONSUME)
 #undef MQ8F_ISSUE
 #undef MQ8F_CONSUME
+#undef MQ8_CONSUME_X
 #undef MQ8_RUN_RING
 #undef MQ8_ISSUE
 #undef MQ8_CONSUME
     if (COLLECT) hit_flush(a, hb, lane);
 }
 
-#endif  // SZG_MQ_PART == 1
+#endif  // SZG_MQ_PART == 1 || 2
 
 #if SZG_MQ_PART == 0
 // ---- per-query selection over the score matrix ----------------------------------
@@ -834,25 +834,37 @@ hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStre
     }
 }
 
-size_t mq_i8_image_bytes(int r16, int nb) { return (size_t)((r16 + 3) / 4) * 3 * nb * 1024; }
-size_t mq_i8_lds_bytes(int r16, int nb)
-{   // + constants, thresholds, the 12 waves' hit buffers
-    return mq_i8_image_bytes(r16, nb) + 4 * 48 * sizeof(float) + (size_t)12 * 64 * 9;
+size_t mq_i8_image_bytes(int row_bits, int r16, int nb)
+{
+    return (size_t)((r16 + 3) / 4) * 3 * (row_bits == 4 ? 2 : 1) * nb * 1024;
 }
-
+size_t mq_i8_lds_bytes(int row_bits, int r16, int nb)
+{   // + constants, thresholds, the 12 waves' hit buffers
+    return mq_i8_image_bytes(row_bits, r16, nb) + 4 * 48 * sizeof(float) + (size_t)12 * 64 * 9;
+}
+hipError_t launch_mq_score_i8_rows8(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
+hipError_t launch_mq_score_i8_rows4(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
+hipError_t launch_mq_score_i8(int row_bits, const MqArgs &a, int nb, int grid, hipStream_t stream)
+{
+    const size_t lds = mq_i8_lds_bytes(row_bits, a.r16, nb);
+    if (row_bits == 8) return launch_mq_score_i8_rows8(a, nb, grid, lds, stream);
+    if (row_bits == 4) return launch_mq_score_i8_rows4(a, nb, grid, lds, stream);
+    return hipErrorInvalidValue;
+}
 #endif  // SZG_MQ_PART == 0
 
-#if SZG_MQ_PART == 1
-size_t mq_i8_lds_bytes(int r16, int nb);
+#if SZG_MQ_PART == 1 || SZG_MQ_PART == 2
 namespace {
+constexpr int kRowBits = SZG_MQ_PART == 1 ? 8 : 4;
 template <int NB, int METRIC, bool COLLECT, bool FAST>
 hipError_t launch_mq_score_i8_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void *>(&mq_score_i8_kernel<NB, METRIC, COLLECT, FAST>),
+        reinterpret_cast<const void *>(&mq_score_i8_kernel<NB, METRIC, COLLECT, FAST, kRowBits>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mq_score_i8_kernel<NB, METRIC, COLLECT, FAST>), dim3(grid), dim3(768), lds, stream, a);
+    hipLaunchKernelGGL((mq_score_i8_kernel<NB, METRIC, COLLECT, FAST, kRowBits>), dim3(grid), dim3(768), lds,
+                       stream, a);
     return hipGetLastError();
 }
 template <int NB>
@@ -871,9 +883,12 @@ hipError_t launch_mq_score_i8_m(const MqArgs &a, int grid, size_t lds, hipStream
 }
 }  // namespace
 
-hipError_t launch_mq_score_i8(const MqArgs &a, int nb, int grid, hipStream_t stream)
+#if SZG_MQ_PART == 1
+hipError_t launch_mq_score_i8_rows8(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
+#else
+hipError_t launch_mq_score_i8_rows4(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
+#endif
 {
-    const size_t lds = mq_i8_lds_bytes(a.r16, nb);
     switch (nb) {
     case 1: return launch_mq_score_i8_m<1>(a, grid, lds, stream);
     case 2: return launch_mq_score_i8_m<2>(a, grid, lds, stream);
@@ -881,8 +896,7 @@ hipError_t launch_mq_score_i8(const MqArgs &a, int nb, int grid, hipStream_t str
     default: return hipErrorInvalidValue;
     }
 }
-
-#endif  // SZG_MQ_PART == 1
+#endif  // SZG_MQ_PART == 1 || 2
 
 #if SZG_MQ_PART == 0
 hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_rows,

@@ -132,6 +132,11 @@ struct QMeta {
     double qconst = 0;  // integer paths: sum Q_i
     double qnorm2 = 0;  // euclid: sum g_i^2 of the prepared query g
     bool mq = false;    // answered by the shared float32 MFMA sweep (its own error bound)
+    // 4-bit rows through the int8 shared sweep: the query as int8 digit planes of
+    // Q_i = round(v_i / mq_qscale), |Q| <= 1e6 (the single-query path's int4 planes stay
+    // in qscale / qconst for the escalation sweep)
+    bool mq_int4 = false;
+    double mq_qscale = 0, mq_qconst = 0;
 };
 
 struct Cand {
@@ -168,6 +173,7 @@ struct Ctx {
     uint32_t *d_count = nullptr;
     // multi-query sweep: LDS image of the batch, score matrix
     uint8_t *h_mq = nullptr, *d_mq = nullptr;
+    int32_t *h_mqQ = nullptr;      // 4-bit int8 sweep: the queries as integers (kMaxBatch x dim)
     size_t h_mq_cap = 0, d_mq_cap = 0;
     float *d_keys = nullptr;
     size_t keys_cap = 0;           // floats
@@ -279,6 +285,16 @@ szg::RowMap choose_map(int r16)
     return best;
 }
 
+// round to nearest (ties away from zero) without a libm call; NaN -> 0, clamped to +-lim.
+// Any rounding rule serves: Q only has to be within 1/2 of v/qscale (key_eps).
+inline long long round_clamp(double t, double lim)
+{
+    if (!(t == t)) return 0;
+    if (t > lim) t = lim;
+    if (t < -lim) t = -lim;
+    return (long long)(t + (t >= 0 ? 0.5 : -0.5));
+}
+
 // Query as the scan wants it (see RowAcc in kernels_scan.hip):
 //  * 16/32/64-bit rows: float (double for 64-bit), pre-normalised for cosine,
 //    pre-scaled by maxInt for 16-bit euclid, laid out [chunk][piece][4];
@@ -317,10 +333,7 @@ void prep_query(const szg_index *ix, const double *q, uint8_t *out_sw, QMeta *me
         double sumQ = 0.0;
         uint32_t *planes = reinterpret_cast<uint32_t *>(out_sw);
         for (int e = 0; e < dim; e++) {
-            double t = std::nearbyint(q[e] * scale / qs);
-            if (!(t == t)) t = 0;
-            t = std::max(-Qmax, std::min(Qmax, t));
-            long long Q = (long long)t;
+            long long Q = round_clamp(q[e] * scale / qs, Qmax);
             sumQ += (double)Q;
             const int j = e / E, i = e % E;
             if (bits == 8) {
@@ -381,6 +394,15 @@ double key_eps(const szg_index *ix, double key, const QMeta &m)
         if (ix->metric == SZG_COSINE) return 2.0 * n * u;
         const double s = 2.0 * m.qnorm + std::sqrt(k);
         return 1.5 * n * u * s * s + 1e-30;
+    }
+    if (m.mq_int4) {
+        // as the integer branch below with Qmax = 1e6 and the row operand x = nibble in 0..15
+        const double M = 15.0, V = 16.0, Qmax = 1000000.0;
+        const double fl = 16.0 * 0x1p-24 * m.mq_qscale * Qmax * V * (double)ix->dim;
+        if (ix->metric == SZG_COSINE)
+            return 0.5 * m.mq_qscale * std::sqrt((double)ix->dim) + fl / std::sqrt((double)ix->dim) + 0x1p-21;
+        return m.mq_qscale * M * (double)ix->dim + 2.0 * fl +
+               0x1p-21 * (k + m.qnorm2 + M * M * (double)ix->dim) + 1e-30;
     }
     if (ix->bits == 8 || ix->bits == 4) {
         // integer paths: the per-lane sums are exact.  What is left is (a) the query's
@@ -448,6 +470,7 @@ void ctx_free(Ctx *c)
     (void)hipFree(c->d_collect);
     (void)hipFree(c->d_count);
     (void)hipHostFree(c->h_mq);
+    free(c->h_mqQ);
     (void)hipFree(c->d_mq);
     (void)hipFree(c->d_thr);
     (void)hipFree(c->d_cand);
@@ -675,14 +698,42 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
 
 // ---- multi-query sweep (32-bit rows, cosine): B queries share one pass ------------
 
-bool mq_uses_i8(const szg_index *ix) { return ix->bits == 8 && ix->mq_i8; }
+bool mq_uses_i8(const szg_index *ix) { return (ix->bits == 8 || ix->bits == 4) && ix->mq_i8; }
+
+// the prepared real query of the integer sweeps: q/|q| (cosine) or maxInt*q (euclid)
+double mq_int_scale(const szg_index *ix, double m1)
+{
+    if (ix->metric == SZG_COSINE) return m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0;
+    return (double)((1u << ix->bits) - 1u);
+}
+
+// 4-bit rows, int8 sweep: quantization step, the integer query Q (dim values) and its digit sum
+void prep_mq_int4(const szg_index *ix, const double *q, QMeta *meta, int32_t *Qout)
+{
+    const double scale = mq_int_scale(ix, meta->m1);
+    double vmax = 0.0;
+    for (int e = 0; e < ix->dim; e++) vmax = std::max(vmax, std::fabs(q[e] * scale));
+    const double Qmax = 1000000.0;
+    const double qs = (vmax > 0 && std::isfinite(vmax)) ? vmax / Qmax : 1.0;
+    const double inv = scale / qs;
+    long long sumQ = 0;
+    for (int e = 0; e < ix->dim; e++) {
+        const long long Q = round_clamp(q[e] * inv, Qmax);
+        Qout[e] = (int32_t)Q;
+        sumQ += Q;
+    }
+    meta->mq_int4 = true;
+    meta->mq_qscale = qs;
+    meta->mq_qconst = (double)sumQ;
+}
 
 int mq_blocks(const szg_index *ix, int nq)
 {   // query blocks of 16 the batch needs, or 0 when the shared sweep does not apply
     if (!ix->multi_query || ix->bits == 64 || nq < ix->mq_min) return 0;
     int nb = std::min((nq + 15) / 16, ix->mq_blocks_max);
     auto lds = [&](int n) {
-        return mq_uses_i8(ix) ? szg::mq_i8_lds_bytes(ix->map.r16, n) : szg::mq_lds_bytes(ix->bits, ix->map.r16, n);
+        return mq_uses_i8(ix) ? szg::mq_i8_lds_bytes(ix->bits, ix->map.r16, n)
+                              : szg::mq_lds_bytes(ix->bits, ix->map.r16, n);
     };
     while (nb > 0 && lds(nb) > 150u * 1024u) nb--;  // image must fit LDS
     return nb;
@@ -696,13 +747,13 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     HIPCHK(hipSetDevice(sh->device));
     const int r16 = ix->map.r16;
     const bool i8 = mq_uses_i8(ix);
-    const size_t img = i8 ? szg::mq_i8_lds_bytes(r16, nb) : szg::mq_lds_bytes(ix->bits, r16, nb);
+    const size_t img = i8 ? szg::mq_i8_lds_bytes(ix->bits, r16, nb) : szg::mq_lds_bytes(ix->bits, r16, nb);
     int rc = ensure_host(&c->h_mq, &c->h_mq_cap, img);
     if (rc) return rc;
     rc = ensure_dev(&c->d_mq, &c->d_mq_cap, img);
     if (rc) return rc;
     memset(c->h_mq, 0, img);
-    if (i8) {
+    if (i8 && ix->bits == 8) {
         // [64-byte step][digit plane][query block][lane = chunk*16 + query][16 bytes] from the
         // planes prep_query wrote ([plane][piece][16 bytes]), then [qscale | qconst | qnorm2][48]
         const int steps = (r16 + 3) / 4;
@@ -719,10 +770,39 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
                                pl + ((size_t)p * r16 + j) * 16, 16);
                     }
         }
-        float *tab = reinterpret_cast<float *>(c->h_mq + szg::mq_i8_image_bytes(r16, nb));
+        float *tab = reinterpret_cast<float *>(c->h_mq + szg::mq_i8_image_bytes(8, r16, nb));
         for (int q = 0; q < nq && q < 48; q++) {
             tab[q] = (float)c->meta[q].qscale;
             tab[48 + q] = (float)c->meta[q].qconst;
+            tab[96 + q] = (float)c->meta[q].qnorm2;
+        }
+    } else if (i8) {
+        // 4-bit rows: [step][plane][even | odd elements][query block][lane][16 bytes] of the int8
+        // digits of Q = round(v / mq_qscale); byte bi of a lane's word belongs to element
+        // 32*piece + 2*bi (+1 for the odd half).  n = 2x - 15: sum Q n = 2 sum Q x - 15 sum Q.
+        uint8_t *im8 = c->h_mq;
+        for (int q = 0; q < nq; q++) {
+            const int32_t *Qv = c->h_mqQ + (size_t)q * ix->dim;
+            const int b = q / 16, qi = q % 16;
+            for (int e = 0; e < ix->dim; e++) {
+                int Q = Qv[e];
+                const int j = e >> 5, i = e & 31, bi = i >> 1, half = i & 1;
+                const int s = j >> 2, ch = j & 3;
+                uint8_t *dst = im8 + ((((size_t)s * 3 * 2 + half) * nb + b) * 64 + ch * 16 + qi) * 16 + bi;
+                const size_t plane = (size_t)2 * nb * 64 * 16;  // bytes between digit planes of a step
+                const int l = ((Q + 64) & 127) - 64;
+                Q = (Q - l) >> 7;
+                const int mdig = ((Q + 64) & 127) - 64;
+                Q = (Q - mdig) >> 7;
+                dst[0] = (uint8_t)(int8_t)Q;          // plane 0 = h (x16384)
+                dst[plane] = (uint8_t)(int8_t)mdig;   // plane 1 = m (x128)
+                dst[2 * plane] = (uint8_t)(int8_t)l;  // plane 2 = l
+            }
+        }
+        float *tab = reinterpret_cast<float *>(c->h_mq + szg::mq_i8_image_bytes(4, r16, nb));
+        for (int q = 0; q < nq && q < 48; q++) {
+            tab[q] = (float)c->meta[q].mq_qscale;
+            tab[48 + q] = (float)(-15.0 * c->meta[q].mq_qconst);
             tab[96 + q] = (float)c->meta[q].qnorm2;
         }
     } else {
@@ -815,7 +895,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
             HIPCHK(hipStreamWaitEvent(st, c->ev_up, 0));
         }
         auto launch_score = [&](const szg::MqArgs &x) -> hipError_t {
-            return i8 ? szg::launch_mq_score_i8(x, nb, sh->cu_count, st)
+            return i8 ? szg::launch_mq_score_i8(ix->bits, x, nb, sh->cu_count, st)
                       : szg::launch_mq_score(ix->bits, x, nb, sh->cu_count, st);
         };
         // score matrix of rows [0, n_sel) -> per-query sorted list of kp (returns its buffer)
@@ -1155,9 +1235,16 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                     ix->stats.escalations++;
                 }
                 double thr = INFINITY;
-                if ((int)res.size() == k && std::isfinite(kmax) && !zero_query)
-                    thr = (double)kmax +
-                          2.1 * key_eps(ix, (double)kmax + key_eps(ix, kmax, t.meta[j]), t.meta[j]);
+                if ((int)res.size() == k && std::isfinite(kmax) && !zero_query) {
+                    // kmax carries the error of the sweep that produced it; the collect sweep
+                    // (always the single-query kernel) adds its own on the rows it tests
+                    QMeta single = t.meta[j];
+                    single.mq = false;
+                    single.mq_int4 = false;
+                    const double e1 = key_eps(ix, (double)kmax + key_eps(ix, kmax, t.meta[j]), t.meta[j]);
+                    const double e2 = key_eps(ix, (double)kmax + e1, single);
+                    thr = (double)kmax + 1.05 * (e1 + e2);
+                }
                 const float thr_f = thr >= 3.0e38 ? 3.0e38f : std::nextafter((float)thr, INFINITY);
                 cands.clear();
                 for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
@@ -1235,7 +1322,13 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
             for (int j = 0; j < t.nq; j++) {
                 prep_query(ix, q + (size_t)j * ix->dim, t.ctx[s]->h_qsw + (size_t)j * ix->qsw_bytes,
                            &t.meta[j]);
-                t.meta[j].mq = nb > 0 && !mq_uses_i8(ix);  // the integer sweep keeps the integer bound
+                t.meta[j].mq = nb > 0 && !mq_uses_i8(ix);  // the integer sweeps keep the integer bound
+                if (nb > 0 && mq_uses_i8(ix) && ix->bits == 4) {
+                    Ctx *cx = t.ctx[s];
+                    if (!cx->h_mqQ) cx->h_mqQ = (int32_t *)malloc(sizeof(int32_t) * (size_t)kMaxBatch * ix->dim);
+                    if (!cx->h_mqQ) return fail(SZG_E_NOMEM, "host scratch");
+                    prep_mq_int4(ix, q + (size_t)j * ix->dim, &t.meta[j], cx->h_mqQ + (size_t)j * ix->dim);
+                }
                 t.ctx[s]->meta[j] = t.meta[j];
             }
             rc = enqueue_queries(ix, sh, t.ctx[s], q, t.nq, allow, allow_stride);

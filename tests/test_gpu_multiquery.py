@@ -139,24 +139,26 @@ def test_shared_sweep_euclidean_far_from_origin():
         assert st["mq_queries"] == 16 and st["escalations"] > 0
 
 
+@pytest.mark.parametrize("bits", [8, 4])
 @pytest.mark.parametrize("metric", [SZG_COSINE, SZG_EUCLIDEAN])
-@pytest.mark.parametrize("dim,n", [(768, 3000), (1536, 1500), (100, 4000), (37, 900), (64, 2000), (3, 500)])
-def test_shared_sweep_int8_mfma(metric, dim, n):
-    """8-bit rows take the exact integer sweep (v_mfma_i32_16x16x64_i8 on the queries' int8
-    digit planes); same bar, and the float32 MFMA sweep (mq_i8=0) must agree with it."""
-    rows = orc.synth_rows(331 + dim, 0, n, dim, 8)
+@pytest.mark.parametrize("dim,n", [(768, 3000), (1536, 1500), (100, 4000), (37, 900), (64, 2000), (128, 2500), (3, 500)])
+def test_shared_sweep_int8_mfma(bits, metric, dim, n):
+    """8- and 4-bit rows take the exact integer sweep (v_mfma_i32_16x16x64_i8 on the queries'
+    int8 digit planes; 4-bit rows as two nibble operands per piece); same bar, and the float32
+    MFMA sweep (mq_i8=0) must agree with it."""
+    rows = orc.synth_rows(331 + dim, 0, n, dim, bits)
     Q = orc.synth_vectors(332 + dim, 0, 48, dim)
     Q[7] *= 25.0
     Q[8] *= 1e-3
     allow = np.arange(n) % 3 != 0
-    with ScanIndex(dim, 8, metric) as ix:
+    with ScanIndex(dim, bits, metric) as ix:
         ix.load(rows)
         for i8 in (1, 0):
             ix.set_option("mq_i8", i8)
             ix.reset_stats()
-            check(ix, rows, dim, Q, 10, bits=8, metric=metric)
+            check(ix, rows, dim, Q, 10, bits=bits, metric=metric)
             assert ix.stats()["mq_queries"] == 48
-            check(ix, rows, dim, Q[:17], 33, allow=allow, bits=8, metric=metric)
+            check(ix, rows, dim, Q[:17], 33, allow=allow, bits=bits, metric=metric)
 
 
 @pytest.mark.parametrize("bits", [8, 32])
