@@ -1138,6 +1138,7 @@ struct Ticket {
     std::vector<Ctx *> ctx;      // one per shard
     std::vector<QMeta> meta;
     int kp = 0;
+    bool failed = false;         // enqueueing failed part-way: drain and release only
 };
 
 int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
@@ -1159,6 +1160,17 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
     // result assembly for one finished batch
     auto finish = [&](Ticket &t) -> int {
         int rc = SZG_OK;
+        if (t.failed) {
+            for (size_t s = 0; s < n_sh; s++) {
+                if (!t.ctx[s]) continue;
+                (void)hipSetDevice(ix->shards[s]->device);
+                (void)hipStreamSynchronize(t.ctx[s]->stream);
+                t.ctx[s]->mq_fused_used = false;
+                ctx_release(ix->shards[s], t.ctx[s]);
+            }
+            t.ctx.assign(n_sh, nullptr);
+            return SZG_OK;  // the enqueue error is already the call's return code
+        }
         for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
             Shard *sh = ix->shards[s];
             if (sh->n_rows == 0) continue;
@@ -1326,16 +1338,20 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 if (nb > 0 && mq_uses_i8(ix) && ix->bits == 4) {
                     Ctx *cx = t.ctx[s];
                     if (!cx->h_mqQ) cx->h_mqQ = (int32_t *)malloc(sizeof(int32_t) * (size_t)kMaxBatch * ix->dim);
-                    if (!cx->h_mqQ) return fail(SZG_E_NOMEM, "host scratch");
+                    if (!cx->h_mqQ) {
+                        rc = fail(SZG_E_NOMEM, "host scratch");  // the ticket is still finished below
+                        break;
+                    }
                     prep_mq_int4(ix, q + (size_t)j * ix->dim, &t.meta[j], cx->h_mqQ + (size_t)j * ix->dim);
                 }
                 t.ctx[s]->meta[j] = t.meta[j];
             }
-            rc = enqueue_queries(ix, sh, t.ctx[s], q, t.nq, allow, allow_stride);
+            if (rc == SZG_OK) rc = enqueue_queries(ix, sh, t.ctx[s], q, t.nq, allow, allow_stride);
             if (rc == SZG_OK)
                 rc = nb ? enqueue_topk_mq(ix, sh, t.ctx[s], kp, t.nq, nb, allow != nullptr)
                         : enqueue_topk(ix, sh, t.ctx[s], kp, t.nq, allow != nullptr);
         }
+        t.failed = rc != SZG_OK;  // nothing to gather: finish() only drains and releases
         inflight.push_back(std::move(t));
         q0 += inflight.back().nq;
     }
