@@ -109,6 +109,9 @@ __device__ __forceinline__ void hit_flush(const MqArgs &a, HitBuf &hb, int lane)
             if (idx < a.cand_cap) a.cand_buf[(size_t)q * a.cand_cap + idx] = c;
         }
     }
+    // gfx9: loads, stores and atomics share one vmcnt and retire out of order among
+    // themselves; leaving these pending would turn every later ring wait into vmcnt(0)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     hb.n = 0;
 }
 
@@ -348,8 +351,9 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
         // respect to each other, so with a key store possibly pending the compiler can only
         // wait for a ring slot with vmcnt(0) -- which also waits for the load just issued
         // and serialises the ring.  Draining here, once per tile, lets every wait inside
-        // the tile be a counted one.
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+        // the tile be a counted one.  (The fused-selection form stores nothing here; its rare
+        // hit flush drains itself.)
+        if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
 #pragma unroll
         for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
         nrm = 0.f;
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
                 }
             }
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores (see mq_score_kernel)
+        if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores (see mq_score_kernel)
 #pragma unroll
         for (int p = 0; p < 3; p++)
 #pragma unroll
