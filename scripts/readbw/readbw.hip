@@ -49,6 +49,61 @@ __global__ __launch_bounds__(256) void read_chunk_kernel(const u32x4 *p, size_t 
     if (r == 0x12345678u) out[0] = r;
 }
 
+// segment pattern: a wave instruction reads SEG bytes of each of 64*16/SEG consecutive rows
+// (lanes of a row group contiguous); a tile of rows is finished in ROWB/SEG instructions.
+// SEG = 64, ROWB = 192: the single-query walk of 192-byte rows (config #5);
+// SEG = 64, ROWB = 768: the MFMA operand layout of the shared sweep on 768-byte rows.
+template <bool NT, int SEG, int ROWB>
+__global__ __launch_bounds__(256) void read_seg_kernel(const uint8_t *p, size_t n_rows, uint32_t *out)
+{
+    constexpr int LPR = SEG / 16;        // lanes per row
+    constexpr int RPW = 64 / LPR;        // rows per wave instruction
+    constexpr int P = ROWB / SEG;        // instructions per tile
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t lane = threadIdx.x & 63;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t g = lane / LPR, l = lane % LPR;
+    u32x4 acc = {0, 0, 0, 0};
+    for (size_t tile = wave; (tile + 1) * RPW <= n_rows; tile += n_waves) {
+        const uint8_t *rp = p + (tile * RPW + g) * ROWB + l * 16;
+        u32x4 v[P];
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const u32x4 *q = reinterpret_cast<const u32x4 *>(rp + (size_t)i * SEG);
+            v[i] = NT ? __builtin_nontemporal_load(q) : *q;
+        }
+#pragma unroll
+        for (int i = 0; i < P; i++) acc ^= v[i];
+    }
+    const uint32_t r = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (r == 0x12345678u) out[0] = r;
+}
+
+template <bool NT, int SEG, int ROWB>
+int run_seg(const u32x4 *buf, size_t bytes, uint32_t *out, int bpc, int cus)
+{
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0));
+    CHK(hipEventCreate(&e1));
+    const int grid = bpc * cus;
+    const size_t n_rows = bytes / ROWB;
+    auto launch = [&]() {
+        hipLaunchKernelGGL((read_seg_kernel<NT, SEG, ROWB>), dim3(grid), dim3(256), 0, 0,
+                           reinterpret_cast<const uint8_t *>(buf), n_rows, out);
+    };
+    for (int i = 0; i < 3; i++) launch();
+    CHK(hipEventRecord(e0));
+    const int reps = 20;
+    for (int i = 0; i < reps; i++) launch();
+    CHK(hipEventRecord(e1));
+    CHK(hipEventSynchronize(e1));
+    float ms;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-6s segments of %3d B, rows of %4d B, blocks/CU=%d  %.1f us/pass  %.2f TB/s\n", NT ? "nt" : "plain",
+           SEG, ROWB, bpc, ms / reps * 1e3, (double)n_rows * ROWB / (ms / reps * 1e-3) / 1e12);
+    return 0;
+}
+
 template <bool NT, int D, bool CHUNK>
 int run(const u32x4 *buf, size_t n_vec, uint32_t *out, int bpc, int cus, const char *name)
 {
@@ -95,6 +150,14 @@ int main(int argc, char **argv)
         if (run<true, 3, true>(buf, n_vec, out, bpc, cus, "nt")) return 1;
         if (run<true, 4, true>(buf, n_vec, out, bpc, cus, "nt")) return 1;
         if (run<true, 8, true>(buf, n_vec, out, bpc, cus, "nt")) return 1;
+    }
+    for (int bpc : {2, 3, 4}) {
+        if (run_seg<false, 64, 192>(buf, bytes, out, bpc, cus)) return 1;
+        if (run_seg<true, 64, 192>(buf, bytes, out, bpc, cus)) return 1;
+        if (run_seg<false, 64, 768>(buf, bytes, out, bpc, cus)) return 1;
+        if (run_seg<true, 64, 768>(buf, bytes, out, bpc, cus)) return 1;
+        if (run_seg<true, 128, 768>(buf, bytes, out, bpc, cus)) return 1;
+        if (run_seg<true, 256, 768>(buf, bytes, out, bpc, cus)) return 1;
     }
     CHK(hipFree(buf));
     CHK(hipFree(out));
