@@ -1,0 +1,110 @@
+"""Differential fuzzing of the C-ABI search entry points against the CPU oracle.
+
+Random shapes (dim, quantization, metric, rows, k, batch size), filter masks, tombstones,
+two-shard handles, duplicate-heavy and scaled corpora, random tunables.  Every answer must be
+the oracle's: same rows in the same order, bit-equal float64 distances (NaN == NaN).
+
+    python scripts/fuzz_gpu.py [seconds] [seed]
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import oracle as orc
+from syzgydb_amd import ScanIndex
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+OPTS = [("queries_per_launch", [1, 3, 16]), ("multi_query", [0, 1]), ("mq_fused", [0, 1]), ("mq_i8", [0, 1]),
+        ("serialize_scans", [0, 1]), ("shape_kernels", [0, 1]), ("blocks_per_cu", [0, 1, 3]),
+        ("mq_min", [2, 8]), ("mq_blocks", [1, 2, 3]), ("slack", [0, 16, 40])]
+
+
+def same(got_r, got_d, want_r, want_d):
+    if len(got_r) != len(want_r):
+        return False
+    if [int(x) for x in got_r] != [int(x) for x in want_r]:
+        return False
+    g, w = np.asarray(got_d), np.asarray(want_d)
+    return bool(((g == w) | (np.isnan(g) & np.isnan(w))).all())
+
+
+t_end = time.time() + budget
+it = fails = 0
+while time.time() < t_end:
+    it += 1
+    bits = int(rng.choice([4, 8, 16, 32, 64]))
+    metric = int(rng.integers(0, 2))
+    dim = int(rng.choice([1, 2, 3, 5, 16, 17, 31, 32, 33, 64, 100, 128, 129, 384, 500, 768, 1024]))
+    n = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 200, 1000, 3000, 9000]))
+    if dim * n > 4_000_000:
+        n = max(1, 4_000_000 // dim)
+    nq = int(rng.choice([1, 2, 7, 8, 9, 16, 17, 33, 50]))
+    k = int(rng.choice([1, 2, 10, 11, 50, 100, 300]))
+    kind = int(rng.integers(0, 5))
+    vec = rng.uniform(-1, 1, (n, dim))
+    if kind == 1:          # duplicates
+        vec[rng.integers(0, n, n // 2)] = vec[0]
+    elif kind == 2:        # coarse grid: many equal distances
+        vec = np.round(vec * 2) / 2
+    elif kind == 3 and bits >= 32:   # large magnitudes / far from the origin
+        vec = vec * 1e3 + 5e3
+    elif kind == 4:        # some zero rows
+        vec[rng.integers(0, n, max(1, n // 10))] = 0.0
+    rows = orc.encode_rows(vec, bits)
+    Q = rng.uniform(-1, 1, (nq, dim))
+    if kind == 3 and bits >= 32:
+        Q = Q * 1e3 + 5e3
+    if rng.random() < 0.2:
+        Q[0] = orc.decode_vector(rows[int(rng.integers(0, n))], dim, bits)   # a stored row as the query
+    if rng.random() < 0.1:
+        Q[-1] = 0.0
+    allow = None
+    if rng.random() < 0.4:
+        allow = rng.random((nq, n)) < rng.choice([0.05, 0.5, 0.95])
+    devices = [0, 0] if rng.random() < 0.25 else [0]
+    opts = {name: int(rng.choice(vals)) for name, vals in OPTS if rng.random() < 0.3}
+    dead = []
+    desc = dict(it=it, bits=bits, metric=metric, dim=dim, n=n, nq=nq, k=k, kind=kind, masked=allow is not None,
+                devices=devices, opts=opts)
+    try:
+        with ScanIndex(dim, bits, metric, devices=devices) as ix:
+            ix.load(rows)
+            for name, val in opts.items():
+                ix.set_option(name, val)
+            if rng.random() < 0.3 and n > 2:
+                dead = [int(x) for x in rng.choice(n, size=max(1, n // 7), replace=False)]
+                for r in dead:
+                    ix.tombstone(r)
+            live = np.ones(n, dtype=bool)
+            live[dead] = False
+            r, d, c = ix.search_topk(Q, k, allow=allow)
+            for qi in range(nq):
+                m = live if allow is None else (live & allow[qi])
+                o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, Q[qi], k=k, allow=m.astype(np.uint8))
+                if not same(r[qi, : c[qi]], d[qi, : c[qi]], o_rows, o_dist):
+                    fails += 1
+                    print("MISMATCH topk", desc, "query", qi, flush=True)
+                    print("  got ", [int(x) for x in r[qi, : c[qi]]][:12], d[qi, : c[qi]][:6], flush=True)
+                    print("  want", [int(x) for x in o_rows][:12], o_dist[:6], flush=True)
+                    break
+            # one radius search at a result distance
+            qi = int(rng.integers(0, nq))
+            m = live if allow is None else (live & allow[qi])
+            o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, Q[qi], k=min(k, 20), allow=m.astype(np.uint8))
+            finite = [x for x in o_dist if x == x and x > 0]
+            if finite:
+                radius = float(finite[-1])
+                rr, dd = ix.search_radius(Q[qi], radius, allow=None if allow is None else allow[qi])
+                w_rows, w_dist, _ = orc.search_exact(rows, dim, bits, metric, Q[qi], radius=radius,
+                                                     allow=m.astype(np.uint8))
+                if not same(rr, dd, w_rows, w_dist):
+                    fails += 1
+                    print("MISMATCH radius", desc, "query", qi, radius, len(rr), len(w_rows), flush=True)
+    except Exception as e:  # noqa: BLE001
+        fails += 1
+        print("EXCEPTION", desc, repr(e), flush=True)
+    if it % 25 == 0:
+        print("iterations %d, failures %d" % (it, fails), flush=True)
+print("FUZZ done: %d iterations, %d failures (seed %d)" % (it, fails, seed), flush=True)
+sys.exit(1 if fails else 0)
