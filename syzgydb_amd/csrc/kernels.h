@@ -31,6 +31,29 @@ __host__ __device__ inline float key_from_ordered(uint32_t u)
 
 // How the 64 lanes of a wave are laid over rows of r16 16-byte pieces:
 // groups of L lanes take one row each, every lane P pieces of it.
+// Where a row's 16-byte pieces live in the resident mirror.
+//   linear: row-major, `pitch` bytes per row.
+//   tiled : tiles of 16 rows; inside a tile the 64-byte step s of all 16 rows is one
+//           contiguous KiB ([step][row & 15][piece & 3]).  A wave instruction that reads one
+//           64-byte step of 16 rows -- the walk of short rows and the MFMA operand layout of
+//           the shared sweeps -- then reads 1 KiB contiguous instead of sixteen 64-byte
+//           segments (a bare read of which tops out at 6.2 TB/s, scripts/readbw).  Needs
+//           pitch % 64 == 0; rows are allocated in multiples of 16.
+struct RowLayout {
+    uint32_t pitch;
+    uint32_t tiled;
+    uint32_t steps;  // pitch / 64 when tiled
+};
+__host__ __device__ inline uint64_t piece_offset(const RowLayout &l, uint64_t row, uint32_t j)
+{
+    if (!l.tiled) return row * l.pitch + (uint64_t)j * 16;
+    return (row >> 4) * ((uint64_t)l.steps * 1024) + (uint64_t)(j >> 2) * 1024 + (row & 15) * 64 + (j & 3) * 16;
+}
+__host__ __device__ inline uint64_t layout_bytes(const RowLayout &l, uint64_t rows)
+{
+    return l.tiled ? ((rows + 15) >> 4) * ((uint64_t)l.steps * 1024) : rows * (uint64_t)l.pitch;
+}
+
 struct RowMap {
     int r16;  // 16-byte pieces per (pitched) row
     int L;    // lanes per row
@@ -65,6 +88,7 @@ struct ScanArgs {
     const uint8_t *rows;        // resident mirror: n_rows x pitch bytes, little-endian elements
     uint32_t n_rows;
     uint32_t pitch;             // bytes, multiple of 16
+    uint32_t tiled, steps;      // RowLayout of `rows`
     int dim;
     RowMap map;
     const uint64_t *live_bits;  // nullable: bit r == 0 -> tombstoned
@@ -101,6 +125,7 @@ struct MqArgs {
     const uint8_t *rows;      // resident mirror
     uint32_t n_rows;
     uint32_t pitch;
+    uint32_t tiled, steps;    // RowLayout of `rows`
     int r16;                  // 16-byte pieces per row
     int dim;
     const void *queries;      // device: LDS image [piece][query block][group of 4][16 queries][4 floats]
@@ -161,18 +186,21 @@ struct RerankOut {
 
 // Exact float64 distances, reference operation order, for n candidates of each of
 // n_queries queries: query_f64 [n_queries][dim], cands/out [n_queries][n_cands_max].
-hipError_t launch_rerank(int qbits, int metric, const uint8_t *rows, uint32_t pitch, int dim,
+hipError_t launch_rerank(int qbits, int metric, const uint8_t *rows, RowLayout layout, int dim,
                          const double *query_f64, const uint64_t *cands, const uint32_t *n_cands_dev,
                          uint32_t n_cands_max, int n_queries, RerankOut *out, hipStream_t stream);
 
-// Page-in transform: reference row encoding (big-endian 16/32/64-bit) -> resident layout.
-hipError_t launch_repack(int qbits, const uint8_t *src, uint32_t row_bytes, uint8_t *dst,
-                         uint32_t pitch, uint64_t n_rows, int to_reference, hipStream_t stream);
+// Page-in transform: n_rows rows in the reference encoding at `ref` (big-endian 16/32/64-bit,
+// row_bytes apart) <-> rows [first_row, first_row + n_rows) of the resident mirror `rows`.
+hipError_t launch_repack(int qbits, uint8_t *ref, uint32_t row_bytes, uint8_t *rows, RowLayout layout,
+                         uint64_t first_row, uint64_t n_rows, int to_reference, hipStream_t stream);
 
-// Rows directly in the resident layout: synthetic (src == nullptr, see
-// szg_index_synth) or quantized + packed from float64 vectors on the device.
-hipError_t launch_synth(int qbits, uint8_t *dst, uint32_t pitch, int dim, uint64_t n_rows,
-                        uint64_t seed, uint64_t first_row, const double *src, hipStream_t stream);
+// Rows [dst_first_row, +n_rows) of the mirror directly in the resident layout: synthetic
+// (src == nullptr, see szg_index_synth; seed_first_row indexes the PRNG stream) or
+// quantized + packed from float64 vectors on the device.
+hipError_t launch_synth(int qbits, uint8_t *rows, RowLayout layout, uint64_t dst_first_row, int dim,
+                        uint64_t n_rows, uint64_t seed, uint64_t seed_first_row, const double *src,
+                        hipStream_t stream);
 
 // device float64 primitive probe (tests)
 hipError_t launch_f64_probe(int op, const double *a, const double *b, double *out, uint64_t n,

@@ -86,7 +86,18 @@ __device__ double go_acos(double x)
 // ---- exact element decode (resident layout -> reference float64 value) ------
 
 template <int QBITS>
-__device__ __forceinline__ double decode_elem(const uint8_t *rp, int i)
+__device__ __forceinline__ double decode_elem_piece(const uint8_t *rp, int i);
+
+template <int QBITS>
+__device__ __forceinline__ double decode_elem(const uint8_t *rows, const RowLayout &lay, uint64_t row, int i)
+{
+    constexpr int E = 128 / QBITS;  // elements per 16-byte piece
+    const uint8_t *pp = rows + piece_offset(lay, row, (uint32_t)(i / E));
+    return decode_elem_piece<QBITS>(pp, i % E);
+}
+
+template <int QBITS>
+__device__ __forceinline__ double decode_elem_piece(const uint8_t *rp, int i)
 {
     if (QBITS == 64) {
         return reinterpret_cast<const double *>(rp)[i];
@@ -134,7 +145,7 @@ __device__ __forceinline__ double ordered_sum(double s, const double *p, int n)
 // then add them up in index order, one accumulator each, as the loops of
 // collection.go:812-832 do.
 template <int QBITS, int METRIC>
-__global__ __launch_bounds__(64) void rerank_kernel(const uint8_t *rows, uint32_t pitch, int dim,
+__global__ __launch_bounds__(64) void rerank_kernel(const uint8_t *rows, RowLayout lay, int dim,
                                                     const double *query, const uint64_t *cands,
                                                     const uint32_t *n_dev, uint32_t n_max,
                                                     RerankOut *out)
@@ -164,14 +175,13 @@ __global__ __launch_bounds__(64) void rerank_kernel(const uint8_t *rows, uint32_
             continue;
         }
         const uint32_t row = (uint32_t)c;
-        const uint8_t *rp = rows + (uint64_t)row * pitch;
         double s = 0.0;
         for (int base = 0; base < dim; base += CH) {
             const int m = min(CH, dim - base);
             __syncthreads();
             for (int i = lane; i < m; i += 64) {
                 const double x = query[base + i];
-                const double y = decode_elem<QBITS>(rp, base + i);
+                const double y = decode_elem<QBITS>(rows, lay, row, base + i);
                 if (METRIC == kEuclidean) {
                     const double diff = __dsub_rn(x, y);
                     p0[i] = __dmul_rn(diff, diff);
@@ -244,11 +254,11 @@ __device__ __forceinline__ uint64_t quantize(double value)
 // values; otherwise row-major float64 vectors (bulk AddDocument: quantize + pack on
 // the device exactly as encodeDocument does, collection.go:713-743)
 template <int QBITS>
-__global__ void synth_kernel(uint8_t *dst, uint32_t pitch, int dim, uint64_t n_rows,
+__global__ void synth_kernel(uint8_t *dst, RowLayout lay, uint64_t dst_first_row, int dim, uint64_t n_rows,
                              uint64_t seed, uint64_t first_row, const double *src)
 {
     constexpr int E = 128 / QBITS;
-    const uint32_t r16 = pitch / 16;
+    const uint32_t r16 = lay.pitch / 16;
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t row = t / r16;
     const uint32_t j = (uint32_t)(t - row * r16);
@@ -275,7 +285,7 @@ __global__ void synth_kernel(uint8_t *dst, uint32_t pitch, int dim, uint64_t n_r
             w[b >> 2] |= (uint32_t)(q & 0xF) << (8 * (b & 3) + ((i & 1) ? 0 : 4));
         }
     }
-    *reinterpret_cast<uint4 *>(dst + row * pitch + (uint64_t)j * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4 *>(dst + piece_offset(lay, dst_first_row + row, j)) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // ---- page-in transform --------------------------------------------------------
@@ -283,28 +293,35 @@ __global__ void synth_kernel(uint8_t *dst, uint32_t pitch, int dim, uint64_t n_r
 // endian); 4- and 8-bit rows are copied.  One thread per destination byte; the
 // aligned 32-bit fast path below covers every bench-sized case.
 
-__global__ void repack_bytes_kernel(const uint8_t *src, uint32_t src_pitch, uint8_t *dst,
-                                    uint32_t dst_pitch, uint32_t row_bytes, uint32_t es,
-                                    uint64_t n_rows)
-{
+__global__ void repack_bytes_kernel(uint8_t *ref, uint32_t row_bytes, uint8_t *rows, RowLayout lay,
+                                    uint64_t first_row, uint32_t es, uint64_t n_rows, int to_reference)
+{   // one thread per byte of the DESTINATION row (pitch bytes resident, row_bytes reference)
+    const uint32_t dst_pitch = to_reference ? row_bytes : lay.pitch;
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t row = t / dst_pitch;
     const uint32_t b = (uint32_t)(t - row * dst_pitch);
     if (row >= n_rows) return;
-    uint8_t v = 0;
-    if (b < row_bytes) {
-        const uint32_t e = b / es, k = b - e * es;
-        v = src[row * src_pitch + (uint64_t)e * es + (es - 1 - k)];
+    const uint32_t e = b / es, k = b - e * es;
+    const uint32_t sb = e * es + (es - 1 - k);  // the mirrored byte on the other side
+    if (to_reference) {
+        ref[row * row_bytes + b] = rows[piece_offset(lay, first_row + row, sb >> 4) + (sb & 15)];
+    } else {
+        uint8_t v = 0;
+        if (b < row_bytes) v = ref[row * row_bytes + sb];
+        rows[piece_offset(lay, first_row + row, b >> 4) + (b & 15)] = v;
     }
-    dst[row * dst_pitch + b] = v;
 }
 
-// row_bytes % 16 == 0 and both pitches == row_bytes: pure streaming, 16 B per thread
-__global__ void repack_vec_kernel(const uint4 *src, uint4 *dst, uint64_t n_vec, uint32_t es)
+// row_bytes % 16 == 0 and pitch == row_bytes: 16 bytes per thread
+__global__ void repack_vec_kernel(uint4 *ref, uint8_t *rows, RowLayout lay, uint64_t first_row, uint32_t r16,
+                                  uint64_t n_vec, uint32_t es, int to_reference)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_vec) return;
-    uint4 v = src[t];
+    const uint64_t row = t / r16;
+    const uint32_t j = (uint32_t)(t - row * r16);
+    uint4 *res = reinterpret_cast<uint4 *>(rows + piece_offset(lay, first_row + row, j));
+    uint4 v = to_reference ? *res : ref[t];
     if (es == 2) {
         auto sw = [](uint32_t x) { return ((x & 0x00FF00FFu) << 8) | ((x >> 8) & 0x00FF00FFu); };
         v = make_uint4(sw(v.x), sw(v.y), sw(v.z), sw(v.w));
@@ -315,7 +332,10 @@ __global__ void repack_vec_kernel(const uint4 *src, uint4 *dst, uint64_t n_vec, 
         v = make_uint4(__builtin_bswap32(v.y), __builtin_bswap32(v.x), __builtin_bswap32(v.w),
                        __builtin_bswap32(v.z));
     }
-    dst[t] = v;
+    if (to_reference)
+        ref[t] = v;
+    else
+        *res = v;
 }
 
 __global__ void fill_bits_kernel(uint64_t *bits, uint64_t n_rows, uint64_t n_words)
@@ -346,7 +366,7 @@ __global__ void f64_probe_kernel(int op, const double *a, const double *b, doubl
 }
 
 template <int QBITS>
-hipError_t launch_rerank_q(int metric, const uint8_t *rows, uint32_t pitch, int dim,
+hipError_t launch_rerank_q(int metric, const uint8_t *rows, RowLayout lay, int dim,
                            const double *q, const uint64_t *cands, const uint32_t *n_dev,
                            uint32_t n_max, int n_queries, RerankOut *out, hipStream_t stream)
 {
@@ -355,16 +375,16 @@ hipError_t launch_rerank_q(int metric, const uint8_t *rows, uint32_t pitch, int 
     const size_t lds = (size_t)1024 * 3 * sizeof(double);
     if (metric == kCosine)
         hipLaunchKernelGGL((rerank_kernel<QBITS, kCosine>), grid, dim3(64), lds, stream, rows,
-                           pitch, dim, q, cands, n_dev, n_max, out);
+                           lay, dim, q, cands, n_dev, n_max, out);
     else
         hipLaunchKernelGGL((rerank_kernel<QBITS, kEuclidean>), grid, dim3(64), lds, stream,
-                           rows, pitch, dim, q, cands, n_dev, n_max, out);
+                           rows, lay, dim, q, cands, n_dev, n_max, out);
     return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t launch_rerank(int qbits, int metric, const uint8_t *rows, uint32_t pitch, int dim,
+hipError_t launch_rerank(int qbits, int metric, const uint8_t *rows, RowLayout pitch, int dim,
                          const double *q, const uint64_t *cands, const uint32_t *n_dev,
                          uint32_t n_max, int n_queries, RerankOut *out, hipStream_t stream)
 {
@@ -378,41 +398,39 @@ hipError_t launch_rerank(int qbits, int metric, const uint8_t *rows, uint32_t pi
     }
 }
 
-hipError_t launch_repack(int qbits, const uint8_t *src, uint32_t row_bytes, uint8_t *dst,
-                         uint32_t pitch, uint64_t n_rows, int to_reference, hipStream_t stream)
+hipError_t launch_repack(int qbits, uint8_t *ref, uint32_t row_bytes, uint8_t *rows, RowLayout lay,
+                         uint64_t first_row, uint64_t n_rows, int to_reference, hipStream_t stream)
 {
     if (n_rows == 0) return hipSuccess;
     const uint32_t es = qbits <= 8 ? 1u : (uint32_t)qbits / 8u;
-    if (row_bytes == pitch && (row_bytes % 16) == 0) {
-        const uint64_t n_vec = n_rows * (row_bytes / 16);
+    if (row_bytes == lay.pitch && (row_bytes % 16) == 0) {
+        const uint32_t r16 = row_bytes / 16;
+        const uint64_t n_vec = n_rows * r16;
         const uint64_t grid = (n_vec + 255) / 256;
         hipLaunchKernelGGL(repack_vec_kernel, dim3((unsigned)grid), dim3(256), 0, stream,
-                           reinterpret_cast<const uint4 *>(src), reinterpret_cast<uint4 *>(dst),
-                           n_vec, es);
+                           reinterpret_cast<uint4 *>(ref), rows, lay, first_row, r16, n_vec, es, to_reference);
         return hipGetLastError();
     }
-    const uint32_t src_pitch = to_reference ? pitch : row_bytes;
-    const uint32_t dst_pitch = to_reference ? row_bytes : pitch;
-    const uint64_t total = n_rows * dst_pitch;
+    const uint64_t total = n_rows * (to_reference ? row_bytes : lay.pitch);
     const uint64_t grid = (total + 255) / 256;
-    hipLaunchKernelGGL(repack_bytes_kernel, dim3((unsigned)grid), dim3(256), 0, stream, src,
-                       src_pitch, dst, dst_pitch, row_bytes, es, n_rows);
+    hipLaunchKernelGGL(repack_bytes_kernel, dim3((unsigned)grid), dim3(256), 0, stream, ref, row_bytes, rows,
+                       lay, first_row, es, n_rows, to_reference);
     return hipGetLastError();
 }
 
-hipError_t launch_synth(int qbits, uint8_t *dst, uint32_t pitch, int dim, uint64_t n_rows,
-                        uint64_t seed, uint64_t first_row, const double *src, hipStream_t stream)
+hipError_t launch_synth(int qbits, uint8_t *rows, RowLayout lay, uint64_t dst_first_row, int dim,
+                        uint64_t n_rows, uint64_t seed, uint64_t first_row, const double *src,
+                        hipStream_t stream)
 {
     if (n_rows == 0) return hipSuccess;
-    const uint64_t total = n_rows * (pitch / 16);
-    const uint64_t grid = (total + 255) / 256;
-    const dim3 g((unsigned)grid), b(256);
+    const uint64_t total = n_rows * (lay.pitch / 16);
+    const dim3 g((unsigned)((total + 255) / 256)), b(256);
     switch (qbits) {
-    case 4: hipLaunchKernelGGL(synth_kernel<4>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row, src); break;
-    case 8: hipLaunchKernelGGL(synth_kernel<8>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row, src); break;
-    case 16: hipLaunchKernelGGL(synth_kernel<16>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row, src); break;
-    case 32: hipLaunchKernelGGL(synth_kernel<32>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row, src); break;
-    case 64: hipLaunchKernelGGL(synth_kernel<64>, g, b, 0, stream, dst, pitch, dim, n_rows, seed, first_row, src); break;
+    case 4: hipLaunchKernelGGL(synth_kernel<4>, g, b, 0, stream, rows, lay, dst_first_row, dim, n_rows, seed, first_row, src); break;
+    case 8: hipLaunchKernelGGL(synth_kernel<8>, g, b, 0, stream, rows, lay, dst_first_row, dim, n_rows, seed, first_row, src); break;
+    case 16: hipLaunchKernelGGL(synth_kernel<16>, g, b, 0, stream, rows, lay, dst_first_row, dim, n_rows, seed, first_row, src); break;
+    case 32: hipLaunchKernelGGL(synth_kernel<32>, g, b, 0, stream, rows, lay, dst_first_row, dim, n_rows, seed, first_row, src); break;
+    case 64: hipLaunchKernelGGL(synth_kernel<64>, g, b, 0, stream, rows, lay, dst_first_row, dim, n_rows, seed, first_row, src); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -221,6 +221,7 @@ struct Shard {
 struct szg_index {
     int dim = 0, bits = 0, metric = 0;
     uint32_t row_bytes = 0, pitch = 0;
+    szg::RowLayout layout{};  // of every shard's mirror (linear, or 16-row x 64-byte-step tiles)
     szg::RowMap map{};
     size_t qsw_bytes = 0;
     double norm_bias = 0;     // integer paths: sum n^2 = 4(SQ+SV) + norm_bias (padding removed)
@@ -598,6 +599,8 @@ void fill_scan_args(const szg_index *ix, const Shard *sh, const Ctx *c, bool has
     a->rows = sh->rows;
     a->n_rows = (uint32_t)sh->n_rows;
     a->pitch = ix->pitch;
+    a->tiled = ix->layout.tiled;
+    a->steps = ix->layout.steps;
     a->dim = ix->dim;
     a->map = ix->map;
     a->live_bits = sh->has_dead ? sh->live_bits : nullptr;
@@ -688,7 +691,7 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
         n_lists = (n_lists + fan - 1) / fan;
         std::swap(src, dst);
     }
-    HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64, src,
+    HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, src,
                               nullptr, (uint32_t)kp, nq, c->d_out, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp * nq,
                           hipMemcpyDeviceToHost, c->stream));
@@ -873,6 +876,8 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     a.rows = sh->rows;
     a.n_rows = (uint32_t)sh->n_rows;
     a.pitch = ix->pitch;
+    a.tiled = ix->layout.tiled;
+    a.steps = ix->layout.steps;
     a.r16 = r16;
     a.dim = ix->dim;
     a.queries = c->d_mq;
@@ -958,7 +963,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
         } else {
             HIPCHK(select_chain((uint32_t)sh->n_rows, key_stride, tail, &src));
         }
-        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64, src,
+        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, src,
                                   nullptr, (uint32_t)kp, nq, c->d_out, tail));
         HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp * nq,
                               hipMemcpyDeviceToHost, tail));
@@ -1052,7 +1057,7 @@ int run_collect(szg_index *ix, Shard *sh, Ctx *c, int slot, float thr_key, bool 
         if (rc) return rc;
         rc = ensure_host(&c->h_out, &c->h_out_cap, (size_t)count);
         if (rc) return rc;
-        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim,
+        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim,
                                   c->d_q64 + (size_t)slot * ix->dim, c->d_collect, nullptr, count, 1,
                                   c->d_out, c->stream));
         HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * count,
@@ -1112,7 +1117,7 @@ int run_full_replay(szg_index *ix, std::vector<Ctx *> &ctx, int slot, const uint
         if (rc) return rc;
         rc = ensure_host(&c->h_out, &c->h_out_cap, n);
         if (rc) return rc;
-        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim,
+        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim,
                                   c->d_q64 + (size_t)slot * ix->dim, nullptr, nullptr, (uint32_t)n, 1,
                                   c->d_out, c->stream));
         HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * n, hipMemcpyDeviceToHost,
@@ -1377,8 +1382,8 @@ int upload_rows(szg_index *ix, Shard *sh, uint64_t dst_row, const uint8_t *rows,
         hipError_t e = hipMemcpy(stage, rows + off * ix->row_bytes, m * ix->row_bytes,
                                  hipMemcpyHostToDevice);
         if (e == hipSuccess)
-            e = szg::launch_repack(ix->bits, stage, ix->row_bytes,
-                                   sh->rows + (dst_row + off) * ix->pitch, ix->pitch, m, 0, nullptr);
+            e = szg::launch_repack(ix->bits, stage, ix->row_bytes, sh->rows, ix->layout, dst_row + off, m, 0,
+                                   nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "upload_rows", e);
     }
@@ -1394,10 +1399,10 @@ int shard_reserve(szg_index *ix, Shard *sh, uint64_t rows_needed)
         uint64_t cap = std::max<uint64_t>(rows_needed, sh->cap_rows + sh->cap_rows / 2);
         cap = (cap + 63) & ~63ull;
         uint8_t *nr = nullptr;
-        hipError_t e = hipMalloc((void **)&nr, cap * ix->pitch + 64);
+        hipError_t e = hipMalloc((void **)&nr, szg::layout_bytes(ix->layout, cap) + 64);
         if (e != hipSuccess) return fail(SZG_E_NOMEM, "hipMalloc(corpus)", e);
         if (sh->rows && sh->n_rows)
-            HIPCHK(hipMemcpy(nr, sh->rows, sh->n_rows * ix->pitch, hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(nr, sh->rows, szg::layout_bytes(ix->layout, sh->n_rows), hipMemcpyDeviceToDevice));
         if (sh->rows) HIPCHK(hipFree(sh->rows));
         sh->rows = nr;
         sh->cap_rows = cap;
@@ -1538,6 +1543,7 @@ int szg_index_create(szg_index **out, int dim, int quant_bits, int metric, const
     ix->metric = metric;
     ix->row_bytes = (uint32_t)rb;
     ix->pitch = (uint32_t)((rb + 15) & ~15ll);
+    ix->layout = szg::RowLayout{ix->pitch, 0u, 0u};
     ix->map = choose_map((int)(ix->pitch / 16));
     ix->qsw_bytes = szg::query_lds_bytes(quant_bits, ix->map.r16);
     if (quant_bits == 8 || quant_bits == 4) {
@@ -1660,7 +1666,7 @@ int szg_index_synth(szg_index *ix, uint64_t n_rows, uint64_t seed, uint64_t firs
     for (size_t s = 0; s < ix->shards.size(); s++) {
         Shard *sh = ix->shards[s];
         HIPCHK(hipSetDevice(sh->device));
-        HIPCHK(szg::launch_synth(ix->bits, sh->rows, ix->pitch, ix->dim, counts[s], seed,
+        HIPCHK(szg::launch_synth(ix->bits, sh->rows, ix->layout, 0, ix->dim, counts[s], seed,
                                  first_row + sh->first, nullptr, nullptr));
         HIPCHK(hipDeviceSynchronize());
         sh->n_rows = counts[s];
@@ -1717,8 +1723,8 @@ int szg_index_append_f64(szg_index *ix, const double *vectors, uint64_t n_rows)
         hipError_t e = hipMemcpy(stage, vectors + off * (uint64_t)ix->dim, m * (uint64_t)ix->dim * 8,
                                  hipMemcpyHostToDevice);
         if (e == hipSuccess)
-            e = szg::launch_synth(ix->bits, sh->rows + (sh->n_rows + off) * ix->pitch, ix->pitch, ix->dim,
-                                  m, 0, 0, stage, nullptr);
+            e = szg::launch_synth(ix->bits, sh->rows, ix->layout, sh->n_rows + off, ix->dim, m, 0, 0, stage,
+                                  nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "append_f64", e);
     }
@@ -1744,8 +1750,7 @@ int szg_index_overwrite_f64(szg_index *ix, uint64_t row, const double *vector)
     HIPCHK(hipMalloc((void **)&stage, (size_t)ix->dim * 8));
     hipError_t e = hipMemcpy(stage, vector, (size_t)ix->dim * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess)
-        e = szg::launch_synth(ix->bits, sh->rows + local * ix->pitch, ix->pitch, ix->dim, 1, 0, 0, stage,
-                              nullptr);
+        e = szg::launch_synth(ix->bits, sh->rows, ix->layout, local, ix->dim, 1, 0, 0, stage, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(stage);
     if (e != hipSuccess) return fail(SZG_E_DEVICE, "overwrite_f64", e);
@@ -1787,7 +1792,7 @@ int szg_distances(szg_index *ix, const double *query, const uint64_t *rows, uint
             if (r2) return r2;
             HIPCHK(hipMemcpyAsync(c->d_collect, cands.data(), cands.size() * sizeof(uint64_t),
                                   hipMemcpyHostToDevice, c->stream));
-            HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64,
+            HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64,
                                       c->d_collect, nullptr, (uint32_t)cands.size(), 1, c->d_out, c->stream));
             HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * cands.size(),
                                   hipMemcpyDeviceToHost, c->stream));
@@ -1904,8 +1909,8 @@ int szg_index_read_rows(szg_index *ix, uint64_t first_row, uint64_t n_rows, uint
         const uint64_t m = hi - lo;
         uint8_t *stage = nullptr;
         HIPCHK(hipMalloc((void **)&stage, m * ix->row_bytes));
-        hipError_t e = szg::launch_repack(ix->bits, sh->rows + (lo - sh->first) * ix->pitch,
-                                          ix->row_bytes, stage, ix->pitch, m, 1, nullptr);
+        hipError_t e = szg::launch_repack(ix->bits, stage, ix->row_bytes, sh->rows, ix->layout, lo - sh->first, m,
+                                          1, nullptr);
         if (e == hipSuccess)
             e = hipMemcpy(out + (lo - first_row) * ix->row_bytes, stage, m * ix->row_bytes,
                           hipMemcpyDeviceToHost);
