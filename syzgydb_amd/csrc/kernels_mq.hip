@@ -150,6 +150,8 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
     const int nwaves = blockDim.x >> 6;
     const int r16 = a.r16;           // 16-byte pieces per row
     const int steps = (r16 + 3) / 4; // 64-byte steps per row
+    const RowLayout mlay{a.pitch, a.tiled, a.steps};
+    const uint32_t istep = a.tiled ? 1024u : 64u;  // bytes from one 64-byte step of a row to the next
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
     // FAST cursors: the lane's next piece in HBM and its A operands' slot in LDS
     auto row_ptr = [&](uint64_t tile) -> const uint8_t * {
         const uint64_t r = min(tile * 16 + trow, (uint64_t)a.n_rows - 1);  // past the end: a valid row, discarded
-        return a.rows + r * a.pitch + (size_t)c * 16;
+        return a.rows + piece_offset(mlay, r, (uint32_t)c);
     };
     const uint8_t *iptr = row_ptr(tile_first);
     const int qbase = c * NB * G4 * 16 + trow;  // float4 index of (this lane's chunk, step 0)
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
             itile += tile_stride;                                                        \
             iptr = row_ptr(itile);                                                       \
         } else {                                                                         \
-            iptr += 64;                                                                  \
+            iptr += istep;                                                               \
         }                                                                                \
     }
 
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
         const uint64_t row_ = itile * 16 + trow;                                         \
         const int j_ = is * 4 + c;                                                       \
         const bool ok_ = row_ < a.n_rows && j_ < r16;                                    \
-        ring[u] = load_nt(ok_ ? a.rows + row_ * a.pitch + (size_t)j_ * 16 : a.zero16);   \
+        ring[u] = load_nt(ok_ ? a.rows + piece_offset(mlay, row_, (uint32_t)j_) : a.zero16); \
         if (++is == steps) {                                                             \
             is = 0;                                                                      \
             itile += tile_stride;                                                        \
@@ -439,6 +441,8 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
     const int nwaves = blockDim.x >> 6;
     const int r16 = a.r16;
     const int steps = (r16 + 3) / 4;  // 64-byte steps per row
+    const RowLayout mlay{a.pitch, a.tiled, a.steps};
+    const uint32_t istep = a.tiled ? 1024u : 64u;  // bytes from one 64-byte step of a row to the next
     const int n16 = steps * 3 * T * NB * 64;  // image, 16-byte words
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
     // FAST (r16 % 4 == 0): no range predicates, addresses advance by constants
     auto row_ptr = [&](uint64_t tile) -> const uint8_t * {
         const uint64_t r = min(tile * 16 + trow, (uint64_t)a.n_rows - 1);
-        return a.rows + r * a.pitch + (size_t)c * 16;
+        return a.rows + piece_offset(mlay, r, (uint32_t)c);
     };
     const uint8_t *iptr = row_ptr(tile_first);
 
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
             itile += tile_stride;                                                        \
             iptr = row_ptr(itile);                                                       \
         } else {                                                                         \
-            iptr += 64;                                                                  \
+            iptr += istep;                                                               \
         }                                                                                \
     }
 
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
         const uint64_t row_ = itile * 16 + trow;                                         \
         const int j_ = is * 4 + c;                                                       \
         const bool ok_ = row_ < a.n_rows && j_ < r16;                                    \
-        ring[u] = load_nt(ok_ ? a.rows + row_ * a.pitch + (size_t)j_ * 16 : a.zero16);   \
+        ring[u] = load_nt(ok_ ? a.rows + piece_offset(mlay, row_, (uint32_t)j_) : a.zero16); \
         if (++is == steps) {                                                             \
             is = 0;                                                                      \
             itile += tile_stride;                                                        \

@@ -489,9 +489,13 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
     if (it_dense * (uint64_t)P < 2 * D) it_dense = 0;  // too short for the ring: general phase
     uint64_t crow0 = row_first;
     if (it_dense) {
-        const uint8_t *iptr = a.rows + (row_first + grp) * (uint64_t)a.pitch + (size_t)lig * 16;
-        const uint64_t piece_step = (uint64_t)L * 16;
-        const uint64_t row_jump = stride * (uint64_t)a.pitch - (uint64_t)(P - 1) * piece_step;
+        // linear rows: the group's lanes walk their row L*16 bytes at a time.  Tiled rows (L = 4,
+        // 16 rows per wave step): the wave reads one 1 KiB step of its tile per piece.
+        const RowLayout lay{a.pitch, a.tiled, a.steps};
+        const uint8_t *iptr = a.rows + piece_offset(lay, row_first + grp, (uint32_t)lig);
+        const uint64_t piece_step = a.tiled ? 1024u : (uint64_t)L * 16;
+        const uint64_t row_jump = (a.tiled ? (stride >> 4) * ((uint64_t)a.steps * 1024) : stride * (uint64_t)a.pitch) -
+                                  (uint64_t)(P - 1) * piece_step;
         int ip = 0, cp = 0, jc = lig;
 #define SZG_DN_ISSUE(u)                                                                 \
     {                                                                                   \
@@ -531,7 +535,8 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
     int ip = 0;
     bool ivalid = row_valid(irow0);
     bool inext = MASKED ? row_valid(irow0 + stride) : false;
-    const uint8_t *irp = a.rows + (uint64_t)(uint32_t)(irow0 + grp) * a.pitch;
+    const RowLayout glay{a.pitch, a.tiled, a.steps};
+    uint64_t irow = (uint32_t)(irow0 + grp);
     // consume cursor
     int cp = 0;
     bool cvalid = false;
@@ -540,12 +545,12 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
     {                                                                                   \
         const int j_ = ip * L + lig;                                                    \
         const bool ok_ = ivalid && j_ < r16;                                            \
-        ring[u] = load_piece<NT>(ok_ ? irp + (size_t)j_ * 16 : a.rows);                     \
+        ring[u] = load_piece<NT>(ok_ ? a.rows + piece_offset(glay, irow, (uint32_t)j_) : a.rows); \
         okmask = (okmask & ~(1u << (u))) | ((uint32_t)ok_ << (u));                      \
         if (++ip == P) {                                                                \
             ip = 0;                                                                     \
             irow0 += stride;                                                            \
-            irp = a.rows + (uint64_t)(uint32_t)(irow0 + grp) * a.pitch;                 \
+            irow = (uint32_t)(irow0 + grp);                                             \
             if (MASKED) {                                                               \
                 ivalid = inext;                                                         \
                 inext = row_valid(irow0 + stride);                                      \
@@ -704,14 +709,17 @@ __global__ __launch_bounds__(1024) void merge_kernel(const uint64_t *in, int n_l
 template <int QBITS> struct Shapes {
     [[maybe_unused]] static constexpr int LA = 0, PA = 0, LB = 0, PB = 0;
 };
-template <> struct Shapes<4> {
-    [[maybe_unused]] static constexpr int LA = 4, PA = 3, LB = 8, PB = 3;
+template <> struct Shapes<4> {  // tiled 4-bit rows: L = 4, P = r16 / 4 (384 and 768 dims)
+    [[maybe_unused]] static constexpr int LA = 4, PA = 3, LB = 4, PB = 6;
 };
 
 template <int QBITS, int METRIC, bool COLLECT, int LL, int PP>
 void launch_shaped(const ScanArgs &a, dim3 g, dim3 b, size_t lds, hipStream_t stream)
 {
-    hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, COLLECT, false, (LL >= 8), LL, PP>), g, b, lds, stream, a);
+    if (LL >= 8 || a.tiled)
+        hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, COLLECT, false, true, LL, PP>), g, b, lds, stream, a);
+    else
+        hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, COLLECT, false, false, LL, PP>), g, b, lds, stream, a);
 }
 
 template <int QBITS, int METRIC, bool COLLECT, bool MASKED>
@@ -731,7 +739,7 @@ hipError_t launch_scan_qmcm(const ScanArgs &a, int grid, int block, size_t lds, 
             }
         }
     }
-    if (a.map.L >= 8)  // whole lines per group per load: stream past the caches
+    if (a.map.L >= 8 || a.tiled)  // whole lines per load instruction: stream past the caches
         hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, COLLECT, MASKED, true>), g, b, lds, stream, a);
     else
         hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, COLLECT, MASKED, false>), g, b, lds, stream, a);

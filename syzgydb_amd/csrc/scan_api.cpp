@@ -251,8 +251,9 @@ struct szg_index {
 
 namespace {
 
-szg::RowMap choose_map(int r16)
-{   // Groups of L lanes per row, P pieces per lane.
+szg::RowMap choose_map(int r16, bool tiled = false)
+{
+    if (tiled) return szg::RowMap{r16, 4, r16 / 4, 16, 1, 1};  // one 64-byte step of 16 rows per load   // Groups of L lanes per row, P pieces per lane.
     // 1) Exact power-of-two groups (L*P == r16): every lane always holds a piece (the
     //    kernel's dense phase), reductions are DPP.  The SMALLEST such L >= 8 wins: a
     //    group still reads whole 128-byte lines per load, and the fewer lanes share a
@@ -1543,8 +1544,11 @@ int szg_index_create(szg_index **out, int dim, int quant_bits, int metric, const
     ix->metric = metric;
     ix->row_bytes = (uint32_t)rb;
     ix->pitch = (uint32_t)((rb + 15) & ~15ll);
-    ix->layout = szg::RowLayout{ix->pitch, 0u, 0u};
-    ix->map = choose_map((int)(ix->pitch / 16));
+    // 4-bit rows of whole 64-byte steps live in 16-row tiles (kernels.h, RowLayout): their
+    // single-query walk and the shared sweeps then read 1 KiB runs instead of 64-byte segments
+    const bool tiled = quant_bits == 4 && ix->pitch % 64 == 0 && getenv("SZG_NO_TILES") == nullptr;
+    ix->layout = szg::RowLayout{ix->pitch, tiled ? 1u : 0u, tiled ? ix->pitch / 64u : 0u};
+    ix->map = choose_map((int)(ix->pitch / 16), tiled);
     ix->qsw_bytes = szg::query_lds_bytes(quant_bits, ix->map.r16);
     if (quant_bits == 8 || quant_bits == 4) {
         const double M = (double)((1u << quant_bits) - 1u);
@@ -2115,6 +2119,7 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
         }
     } else if (n == "lanes_per_row") {
         // tuning hook: force the lane-group width L (power of two, L*P >= r16)
+        if (ix->layout.tiled) return fail(SZG_E_UNSUPPORTED, "lanes_per_row: tiled rows walk 4 lanes per row");
         const int L = (int)value, r16 = ix->map.r16;
         if (L < 1 || L > 64 || (L & (L - 1))) return fail(SZG_E_INVALID, "lanes_per_row must be a power of two <= 64");
         const int P = (r16 + L - 1) / L;
