@@ -553,7 +553,7 @@ LaunchGeom scan_geometry(const szg_index *ix, const Shard *sh, int kp, bool plai
         // (4 waves per CU is another 0.5 % faster on 3 KB rows at 1M rows but 10 % slower
         // on a 125 K-row shard, where the sweep's ramp-up and tail weigh more.)
         (void)plain_topk;
-        if (kp > 64 || (ix->bits >= 32 && ix->row_bytes >= 1024))
+        if (kp > 64 || (ix->bits >= 32 && ix->row_bytes >= 1024) || (ix->bits == 8 && ix->layout.tiled))
             waves_per_cu = 8;
         else
             waves_per_cu = 12;
@@ -1544,9 +1544,12 @@ int szg_index_create(szg_index **out, int dim, int quant_bits, int metric, const
     ix->metric = metric;
     ix->row_bytes = (uint32_t)rb;
     ix->pitch = (uint32_t)((rb + 15) & ~15ll);
-    // 4-bit rows of whole 64-byte steps live in 16-row tiles (kernels.h, RowLayout): their
+    // 4- and 8-bit rows of whole 64-byte steps live in 16-row tiles (kernels.h, RowLayout): their
     // single-query walk and the shared sweeps then read 1 KiB runs instead of 64-byte segments
-    const bool tiled = quant_bits == 4 && ix->pitch % 64 == 0 && getenv("SZG_NO_TILES") == nullptr;
+    // (+8-12 % on 4-bit rows, +2.5 % on 8-bit rows; float rows measured -1..0 % and stay linear:
+    // scripts/dev_tiles.sh, dev_tiles_all.sh).  SZG_TILES_ALL / SZG_NO_TILES override for A/B runs.
+    const bool tiled = (quant_bits <= 8 || getenv("SZG_TILES_ALL") != nullptr) && ix->pitch % 64 == 0 &&
+                       getenv("SZG_NO_TILES") == nullptr;
     ix->layout = szg::RowLayout{ix->pitch, tiled ? 1u : 0u, tiled ? ix->pitch / 64u : 0u};
     ix->map = choose_map((int)(ix->pitch / 16), tiled);
     ix->qsw_bytes = szg::query_lds_bytes(quant_bits, ix->map.r16);
