@@ -69,7 +69,20 @@ while time.time() < t_end:
                 devices=devices, opts=opts)
     try:
         with ScanIndex(dim, bits, metric, devices=devices) as ix:
-            ix.load(rows)
+            split = int(rng.integers(1, n)) if (n > 1 and rng.random() < 0.3) else n
+            ix.load(rows[:split])
+            if split < n:   # the rest arrives through the mutation entry points
+                if rng.random() < 0.5:
+                    ix.append(rows[split:])
+                else:
+                    ix.append_vectors(vec[split:])
+            if n > 3 and rng.random() < 0.3:   # overwrite a few rows in place
+                for r0 in rng.choice(n, size=min(5, n), replace=False):
+                    nv = rng.uniform(-1, 1, dim)
+                    vec[r0] = nv
+                    rows[r0] = orc.encode_rows(nv.reshape(1, -1), bits)[0]
+                    ix.overwrite(int(r0), rows[r0])
+            assert (ix.read_rows(0, n) == rows).all(), "read_rows != what was written"
             for name, val in opts.items():
                 ix.set_option(name, val)
             if rng.random() < 0.3 and n > 2:

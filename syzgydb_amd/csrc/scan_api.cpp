@@ -1682,19 +1682,32 @@ int szg_index_synth(szg_index *ix, uint64_t n_rows, uint64_t seed, uint64_t firs
     return SZG_OK;
 }
 
+// The shard new rows go to.  Ranges stay contiguous in row order, so only the last shard
+// that holds rows can grow -- or the next, still empty one can start, which it does only at
+// a 64-row boundary (every shard's first row must be a multiple of 64: filter and tombstone
+// bitmaps are split between shards by whole words) and once its predecessor holds 4M rows.
+Shard *append_target(szg_index *ix)
+{
+    size_t idx = 0;
+    for (size_t s = 0; s < ix->shards.size(); s++)
+        if (ix->shards[s]->n_rows) idx = s;
+    Shard *t = ix->shards[idx];
+    if (idx + 1 < ix->shards.size() && t->n_rows >= (4ull << 20) && (t->first + t->n_rows) % 64 == 0) {
+        Shard *nx = ix->shards[idx + 1];
+        nx->first = t->first + t->n_rows;
+        return nx;
+    }
+    if (t->n_rows == 0) t->first = 0;
+    return t;
+}
+
 int szg_index_append(szg_index *ix, const uint8_t *rows, uint64_t n_rows)
 {
     if (!ix || (!rows && n_rows)) return fail(SZG_E_INVALID, "null argument");
     if (n_rows == 0) return SZG_OK;
-    Shard *sh = ix->shards.back();  // new rows extend the last shard's range
+    Shard *sh = append_target(ix);
     HIPCHK(hipSetDevice(sh->device));
     HIPCHK(hipDeviceSynchronize());
-    if (sh->n_rows == 0) {  // keep ranges contiguous when earlier shards hold rows
-        uint64_t first = 0;
-        for (Shard *o : ix->shards)
-            if (o != sh) first += o->n_rows;
-        sh->first = first;
-    }
     int rc = shard_reserve(ix, sh, sh->n_rows + n_rows);
     if (rc) return rc;
     rc = upload_rows(ix, sh, sh->n_rows, rows, n_rows);
@@ -1711,15 +1724,9 @@ int szg_index_append_f64(szg_index *ix, const double *vectors, uint64_t n_rows)
 {
     if (!ix || (!vectors && n_rows)) return fail(SZG_E_INVALID, "null argument");
     if (n_rows == 0) return SZG_OK;
-    Shard *sh = ix->shards.back();
+    Shard *sh = append_target(ix);
     HIPCHK(hipSetDevice(sh->device));
     HIPCHK(hipDeviceSynchronize());
-    if (sh->n_rows == 0) {
-        uint64_t first = 0;
-        for (Shard *o : ix->shards)
-            if (o != sh) first += o->n_rows;
-        sh->first = first;
-    }
     int rc = shard_reserve(ix, sh, sh->n_rows + n_rows);
     if (rc) return rc;
     const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / ((uint64_t)ix->dim * 8));

@@ -252,3 +252,27 @@ def test_pair_distances_and_average_distance(bits, metric):
     assert avg == total / count
     assert c.computeAverageDistance(0) == 0.0
     c.Close()
+
+
+def test_append_on_two_shards_keeps_filter_bits_aligned():
+    """Rows appended to a two-shard handle after a small load: every shard must still start at a
+    multiple of 64 rows, or the per-shard slices of the filter / tombstone bitmaps shift
+    (found by scripts/fuzz_gpu.py)."""
+    dim, bits, metric, n = 24, 32, 0, 300
+    rows = orc.synth_rows(901, 0, n, dim, bits)
+    Q = orc.synth_vectors(902, 0, 5, dim)
+    rng = np.random.default_rng(4)
+    allow = rng.random((5, n)) < 0.5
+    for split in (1, 5, 64, 70, 299):
+        with ScanIndex(dim, bits, metric, devices=[0, 0]) as ix:
+            ix.load(rows[:split])
+            ix.append(rows[split:])
+            ix.tombstone(3)
+            assert (ix.read_rows(0, n) == rows).all()
+            r, d, c = ix.search_topk(Q, 10, allow=allow)
+            for qi in range(5):
+                m = allow[qi].copy()
+                m[3] = False
+                o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, Q[qi], k=10, allow=m.astype(np.uint8))
+                assert [int(x) for x in r[qi, : c[qi]]] == [int(x) for x in o_rows], (split, qi)
+                assert (d[qi, : c[qi]] == o_dist).all()
