@@ -114,6 +114,29 @@ while time.time() < t_end:
                 if not same(rr, dd, w_rows, w_dist):
                     fails += 1
                     print("MISMATCH radius", desc, "query", qi, radius, len(rr), len(w_rows), flush=True)
+            # the candidate re-rank primitives: float64 distances for row lists and row pairs
+            pick = rng.integers(0, n, min(n, 40)).astype(np.uint64)
+            got = ix.distances(Q[0], pick)
+            want = orc.all_distances(rows[pick.astype(np.int64)], dim, bits, metric, Q[0])
+            if not bool(((got == want) | (np.isnan(got) & np.isnan(want))).all()):
+                fails += 1
+                print("MISMATCH distances", desc, flush=True)
+            pa = rng.integers(0, n, 20).astype(np.uint64)
+            pb = rng.integers(0, n, 20).astype(np.uint64)
+            got = ix.pair_distances(pa, pb)
+            fn = orc.angular if metric == 1 else orc.euclidean
+            want = np.array([fn(orc.decode_vector(rows[int(x)], dim, bits), orc.decode_vector(rows[int(y)], dim, bits))
+                             for x, y in zip(pa, pb)])
+            if not bool(((got == want) | (np.isnan(got) & np.isnan(want))).all()):
+                fails += 1
+                print("MISMATCH pair_distances", desc, flush=True)
+            # a radius search into a buffer that is too small: the best `cap` hits and the true total
+            if finite and len(w_rows) > 3:
+                cap = int(rng.integers(1, len(w_rows)))
+                tr, td, total = ix.search_radius(Q[qi], radius, allow=None if allow is None else allow[qi], capacity=cap)
+                if total != len(w_rows) or not same(tr, td, w_rows[:cap], w_dist[:cap]):
+                    fails += 1
+                    print("MISMATCH truncated radius", desc, cap, total, len(w_rows), flush=True)
     except Exception as e:  # noqa: BLE001
         fails += 1
         print("EXCEPTION", desc, repr(e), flush=True)
