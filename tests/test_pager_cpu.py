@@ -108,3 +108,44 @@ def test_oracle_span_builder_is_read_by_the_pager(tmp_path, oracle):
     s1, r1 = oracle.bench_topk(rows, dim, bits, 0, oracle.synth_vectors(22, 0, 2, dim), 5, 1)
     s2, r2 = oracle.bench_topk_faithful(rows, dim, bits, 0, oracle.synth_vectors(22, 0, 2, dim), 5, meta_len=7)
     assert (r1 == r2).all()
+
+
+def test_pager_randomized_against_a_python_model(tmp_path, oracle):
+    """Random collection files -- rewrites of the same id (highest sequence wins), removed
+    records (FREE spans), checksum failures, padded spans, ids that sort differently as
+    strings -- against a small Python model of the reference's scan rules
+    (spanfile.go:282-357) and visit order (sort.Strings, :540-560)."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        dim = int(rng.choice([1, 3, 8, 33]))
+        bits = int(rng.choice([4, 8, 16, 32, 64]))
+        n_spans = int(rng.integers(0, 60))
+        model = {}      # id -> (sequence, metadata, vector bytes)
+        bad = 0
+        spans = []
+        for s in range(n_spans):
+            seq = int(rng.integers(2, 5000))
+            rid = int(rng.choice([1, 2, 3, 10, 11, 21, 100, 101, 9, 1000, int(rng.integers(0, 10**9))]))
+            vec = codec.encode_rows(rng.uniform(-1, 1, (1, dim)), bits)[0].tobytes()
+            meta = bytes(rng.integers(0, 256, int(rng.integers(0, 20))).astype(np.uint8))
+            kind = rng.random()
+            if kind < 0.12:
+                spans.append(sw.span(seq, str(rid), [(0, meta), (1, vec)], corrupt=True))
+                bad += 1
+            elif kind < 0.24:
+                spans.append(sw.span(seq, str(rid), [(0, meta), (1, vec)], magic=sw.FREE))
+            else:
+                spans.append(sw.span(seq, str(rid), [(0, meta), (1, vec)], pad=int(rng.choice([0, 0, 3, 14]))))
+                if rid not in model or seq > model[rid][0]:
+                    model[rid] = (seq, meta, vec)
+        path = tmp_path / ("rand%d.dat" % case)
+        sw.collection_file(path, int(rng.integers(0, 2)), dim, bits, [], extra_spans=spans,
+                           tail_zeros=int(rng.choice([0, 15, 4096])))
+        order = sorted(model, key=lambda i: str(i))
+        with SpanfilePager(path, n_threads=int(rng.integers(1, 5))) as pg:
+            assert [int(x) for x in pg.ids()] == order, case
+            assert pg.skipped == bad
+            vec = pg.vectors()
+            for row, rid in enumerate(order):
+                assert vec[row].tobytes() == model[rid][2]
+                assert pg.metadata(row) == model[rid][1]
