@@ -16,3 +16,12 @@ def test_fuzz_short(seed):
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "0 failures" in p.stdout
+
+
+@pytest.mark.gpu
+def test_collection_fuzz_short():
+    """Stateful fuzz of the Collection mirror (add / re-add / remove / update / search / list)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_collection.py"), "10", "5"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "0 failures" in p.stdout
