@@ -62,6 +62,7 @@ class SearchArgs:
     Offset: int = 0
     Limit: int = 0
     Precision: str = ""
+    FilterKey: Optional[str] = None  # not in the reference: names the filter for the bitmask cache
 
 
 class Collection:
@@ -81,6 +82,10 @@ class Collection:
         self._id_of = []     # row -> id (None once tombstoned)
         self._meta = []      # row -> metadata bytes
         self._closed = False
+        # filter -> allow-bitmask cache: a filter's verdicts only change when the
+        # collection does, so they are kept per (filter key, collection version)
+        self._version = 0
+        self._mask_cache = {}
 
     @classmethod
     def from_spanfile(cls, path, devices=None):
@@ -108,6 +113,7 @@ class Collection:
                              "expected %d, got %d" % (self.DimensionCount, v.size))
         row_bytes = codec.encode_rows(v.reshape(1, -1), self.Quantization)
         id = int(id)
+        self._version += 1
         if id in self._row_of:  # WriteRecord of an existing id replaces the record
             row = self._row_of[id]
             self._index.overwrite(row, row_bytes)
@@ -124,6 +130,7 @@ class Collection:
         if V.shape[1] != self.DimensionCount:
             raise ValueError("vector size does not match the expected number of dimensions")
         ids = [int(i) for i in ids]
+        self._version += 1
         if any(i in self._row_of for i in ids) or len(set(ids)) != len(ids):
             for j, i in enumerate(ids):
                 self.AddDocument(i, V[j], metadatas[j] if metadatas else b"")
@@ -146,12 +153,14 @@ class Collection:
         row = self._row_of.get(int(id))
         if row is None:
             raise KeyError("record not found")
+        self._version += 1
         self._meta[row] = bytes(new_metadata)
 
     def removeDocument(self, id: int):
         row = self._row_of.pop(int(id), None)
         if row is None:
             raise KeyError("record not found")
+        self._version += 1
         self._index.tombstone(row)
         self._id_of[row] = None
         self._meta[row] = b""
@@ -196,14 +205,25 @@ class Collection:
             self._closed = True
 
     # -- Search ---------------------------------------------------------------
-    def _allow_mask(self, flt):
+    def _allow_mask(self, flt, key=None):
+        """One bit per row from the caller's filter (collection.go:592-594).  `key` (e.g. the
+        REST layer's filter text) makes the verdicts reusable until the collection changes;
+        without it the filter object itself is the key."""
         if flt is None:
             return None
+        ck = (key if key is not None else id(flt), self._version)
+        hit = self._mask_cache.get(ck)
+        if hit is not None and (key is not None or hit[1] is flt):
+            return hit[0]
         mask = np.zeros(len(self._id_of), dtype=bool)
-        for row, id in enumerate(self._id_of):
-            if id is not None:
-                mask[row] = bool(flt(id, self._meta[row]))
-        return pack_allow_bits(mask)
+        for row, id_ in enumerate(self._id_of):
+            if id_ is not None:
+                mask[row] = bool(flt(id_, self._meta[row]))
+        bits = pack_allow_bits(mask)
+        if len(self._mask_cache) > 16:
+            self._mask_cache.clear()
+        self._mask_cache[ck] = (bits, flt)
+        return bits
 
     def Search(self, args: SearchArgs) -> SearchResults:
         """collection.go:569-711."""
@@ -228,7 +248,7 @@ class Collection:
             if q.size != self.DimensionCount:
                 # undefined in the reference (collection.go:814, :823); rejected here
                 raise ValueError("query length %d != dimension %d" % (q.size, self.DimensionCount))
-            allow = self._allow_mask(args.Filter) if n_records else None
+            allow = self._allow_mask(args.Filter, getattr(args, "FilterKey", None)) if n_records else None
             if n_records == 0:
                 rows, dist = [], []
             elif args.Radius > 0:  # K is ignored (collection.go:598-605)

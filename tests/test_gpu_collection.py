@@ -276,3 +276,32 @@ def test_append_on_two_shards_keeps_filter_bits_aligned():
                 o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, Q[qi], k=10, allow=m.astype(np.uint8))
                 assert [int(x) for x in r[qi, : c[qi]]] == [int(x) for x in o_rows], (split, qi)
                 assert (d[qi, : c[qi]] == o_dist).all()
+
+
+def test_filter_bitmask_cache():
+    """A filter's verdicts are kept per (filter, collection version): the second search with the
+    same filter does not call it again; any mutation invalidates."""
+    dim = 8
+    c = Collection(CollectionOptions(Name="f", DistanceMethod=Euclidean, DimensionCount=dim, Quantization=32))
+    rng = np.random.default_rng(1)
+    for i in range(50):
+        c.AddDocument(i, rng.uniform(-1, 1, dim), b"m%d" % i)
+    calls = [0]
+
+    def even(id, meta):
+        calls[0] += 1
+        return id % 2 == 0
+
+    q = rng.uniform(-1, 1, dim)
+    a = c.Search(SearchArgs(Vector=q, K=5, Filter=even, Precision="exact"))
+    assert calls[0] == 50 and all(r.ID % 2 == 0 for r in a.Results)
+    b = c.Search(SearchArgs(Vector=q, K=5, Filter=even, Precision="exact"))
+    assert calls[0] == 50 and [r.ID for r in b.Results] == [r.ID for r in a.Results]
+    c.AddDocument(100, q, b"exact match")          # version changes: verdicts are recomputed
+    d = c.Search(SearchArgs(Vector=q, K=5, Filter=even, Precision="exact"))
+    assert calls[0] == 101 and d.Results[0].ID == 100
+    # a named filter survives a new closure object
+    e = c.Search(SearchArgs(Vector=q, K=5, Filter=lambda i, m: i % 2 == 0, FilterKey="even", Precision="exact"))
+    f = c.Search(SearchArgs(Vector=q, K=5, Filter=lambda i, m: 1 / 0, FilterKey="even", Precision="exact"))
+    assert [r.ID for r in f.Results] == [r.ID for r in e.Results] == [r.ID for r in d.Results]
+    c.Close()
