@@ -195,7 +195,7 @@ int szg_reset_stats(szg_index *ix);
  * "block_threads", "query_batch" (queries staged, merged, re-ranked and copied back
  * together, default 16), "queries_per_launch" (sweeps one scan launch walks back to
  * back, query-major, default 16: no launch gap or chip-wide tail between the sweeps of
- * a batch; 1 = one launch per sweep), "multi_query" (default 1: batches of >= "mq_min" queries on
+ * a batch; 1 = one launch per sweep), "multi_query" (default 1: batches of >= "mq_min" (default 2) queries on
  * 4/8/16/32-bit collections, either metric, share ONE sweep of the corpus, the dot
  * products going to the matrix cores; 0 = every query gets its own sweep), "mq_i8" (default 1: 8- and 4-bit collections run the shared sweep in exact
  * integer arithmetic on the int8 matrix cores, v_mfma_i32_16x16x64_i8; 0 = the float32 MFMA

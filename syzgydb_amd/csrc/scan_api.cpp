@@ -242,7 +242,7 @@ struct szg_index {
     int mq_fused = 1;         // shared sweep: threshold-collect selection instead of a score matrix
     int mq_i8 = 1;            // 8-bit rows: exact integer shared sweep (v_mfma_i32_16x16x64_i8)
     int mq_tail_overlap = 0;  // shared sweep: post-processing of a batch beside the next batch's sweep
-    int mq_min = 8;           // smallest batch worth a shared sweep
+    int mq_min = 2;           // smallest batch worth a shared sweep (measured: 2 queries already break even)
     int mq_blocks_max = 3;    // query blocks of 16 per shared sweep (LDS image permitting)
     bool timing = false;
     std::mutex stats_mu;

@@ -32,7 +32,7 @@ def test_shared_sweep_matches_oracle(dim, n, nq):
         ix.load(rows)
         check(ix, rows, dim, Q, 10)
         st = ix.stats()
-        shared = nq - (nq % 48 if nq % 48 < 8 else 0)   # a tail below mq_min gets its own sweeps
+        shared = nq - (nq % 48 if nq % 48 < 2 else 0)   # a tail below mq_min (2) gets its own sweep
         assert st["mq_queries"] == shared and st["mq_launches"] == (shared + 47) // 48
         ix.set_option("multi_query", 0)
         ix.reset_stats()
@@ -120,7 +120,7 @@ def test_shared_sweep_euclidean(bits, dim, n):
     with ScanIndex(dim, bits, SZG_EUCLIDEAN) as ix:
         ix.load(rows)
         check(ix, rows, dim, Q, 10, bits=bits, metric=0)
-        assert ix.stats()["mq_queries"] == 48   # the tail of 2 (< mq_min) gets its own sweeps
+        assert ix.stats()["mq_queries"] == 50
         check(ix, rows, dim, Q[:24], 100, allow=allow, bits=bits, metric=0)
 
 

@@ -39,13 +39,15 @@ def test_topk_matches_oracle(bits, metric, dim, n):
     with ScanIndex(dim, bits, metric) as ix:
         ix.load(rows)
         assert ix.rows == n
-        for k in (1, 10):
-            r, d, c = ix.search_topk(queries, k)
-            for qi in range(queries.shape[0]):
-                o_rows, o_dist, searched = orc.search_exact(rows, dim, bits, metric, queries[qi], k=k)
-                assert searched == n
-                assert c[qi] == len(o_rows)
-                assert_same(r[qi, : c[qi]], d[qi, : c[qi]], o_rows, o_dist)
+        for mq in (0, 1):   # one sweep per query; the shared sweep (batches of >= 2 take it by default)
+            ix.set_option("multi_query", mq)
+            for k in (1, 10):
+                r, d, c = ix.search_topk(queries, k)
+                for qi in range(queries.shape[0]):
+                    o_rows, o_dist, searched = orc.search_exact(rows, dim, bits, metric, queries[qi], k=k)
+                    assert searched == n
+                    assert c[qi] == len(o_rows)
+                    assert_same(r[qi, : c[qi]], d[qi, : c[qi]], o_rows, o_dist)
 
 
 @pytest.mark.parametrize("bits", [4, 8, 32])
