@@ -305,3 +305,42 @@ def test_filter_bitmask_cache():
     f = c.Search(SearchArgs(Vector=q, K=5, Filter=lambda i, m: 1 / 0, FilterKey="even", Precision="exact"))
     assert [r.ID for r in f.Results] == [r.ID for r in e.Results] == [r.ID for r in d.Results]
     c.Close()
+
+
+@pytest.mark.parametrize("bits,metric,devices", [(32, 1, [0]), (8, 0, [0]), (4, 1, [0, 0]), (32, 0, [0, 0])])
+def test_concurrent_mixed_batches_from_threads(bits, metric, devices):
+    """Eight threads on one handle, each mixing single queries, small and large batches (one sweep
+    per query, shared sweeps, radius searches, filter masks): every answer is the oracle's."""
+    import threading
+    dim, n = 64, 30000
+    rows = orc.synth_rows(31 + bits, 0, n, dim, bits)
+    Q = orc.synth_vectors(32, 0, 120, dim)
+    want = [orc.search_exact(rows, dim, bits, metric, Q[i], k=7) for i in range(Q.shape[0])]
+    allow = (np.arange(n) % 3 != 0)
+    want_f = [orc.search_exact(rows, dim, bits, metric, Q[i], k=7, allow=allow.astype(np.uint8)) for i in range(8)]
+    with ScanIndex(dim, bits, metric, devices=devices) as ix:
+        ix.load(rows)
+        errs = []
+
+        def worker(t):
+            try:
+                rng = np.random.default_rng(t)
+                for it in range(12):
+                    nq = int(rng.choice([1, 1, 2, 5, 16, 40]))
+                    lo = int(rng.integers(0, Q.shape[0] - nq))
+                    r, d, c = ix.search_topk(Q[lo:lo + nq], 7)
+                    for j in range(nq):
+                        assert [int(x) for x in r[j, : c[j]]] == [int(x) for x in want[lo + j][0]], (t, it, j)
+                        assert (d[j, : c[j]] == want[lo + j][1]).all()
+                    if it % 4 == 0:
+                        i = int(rng.integers(0, 8))
+                        r, d, c = ix.search_topk(Q[i], 7, allow=allow)
+                        assert [int(x) for x in r[0, : c[0]]] == [int(x) for x in want_f[i][0]]
+                        rr, dd = ix.search_radius(Q[i], float(want[i][1][3]))
+                        assert [int(x) for x in rr] == [int(x) for x in want[i][0][:len(rr)]] and len(rr) >= 4
+            except Exception as e:  # pragma: no cover
+                errs.append(repr(e))
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs[:3]
