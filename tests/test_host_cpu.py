@@ -140,3 +140,46 @@ def test_shard_ranges_cover_everything():
                 assert lo == prev and hi >= lo
                 prev = hi
             assert prev == n
+
+
+def test_merge_topk_randomized(oracle):
+    """Random shard counts, sizes, k and corpora (incl. grids with many equal distances):
+    whenever szg_merge_topk does not flag the query as history-dependent, the merged list is the
+    single-collection answer; when it does, it is still a correct top-k by distance."""
+    from syzgydb_amd.sharded import merge_topk, shard_range
+    rng = np.random.default_rng(77)
+    for case in range(60):
+        dim = int(rng.choice([2, 5, 16]))
+        bits = int(rng.choice([4, 8, 32]))
+        metric = int(rng.integers(0, 2))
+        n = int(rng.choice([3, 64, 65, 200, 1500]))
+        G = int(rng.integers(1, 9))
+        k = int(rng.choice([1, 3, 10, 40]))
+        vec = rng.uniform(-1, 1, (n, dim))
+        if case % 3 == 0:
+            vec = np.round(vec * 2) / 2          # many ties
+        rows = oracle.encode_rows(vec, bits)
+        Q = rng.uniform(-1, 1, (3, dim))
+        kk = k + 1
+        R = np.full((G, 3, kk), np.iinfo(np.uint64).max, np.uint64)
+        D = np.zeros((G, 3, kk))
+        C = np.zeros((G, 3), np.int32)
+        for g in range(G):
+            lo, hi = shard_range(n, g, G)
+            for qi in range(3):
+                if hi > lo:
+                    r, d, _ = oracle.search_exact(rows[lo:hi], dim, bits, metric, Q[qi], k=kk)
+                    R[g, qi, : len(r)] = r + lo
+                    D[g, qi, : len(r)] = d
+                    C[g, qi] = len(r)
+        out_r, out_d, out_c, hist = merge_topk(k, R, D, C)
+        for qi in range(3):
+            r, d, _ = oracle.search_exact(rows, dim, bits, metric, Q[qi], k=k)
+            got_d = out_d[qi, : out_c[qi]]
+            assert out_c[qi] == len(r), (case, qi)
+            if not hist[qi]:
+                assert [int(x) for x in out_r[qi, : out_c[qi]]] == [int(x) for x in r], (case, qi)
+                assert same_f64(got_d, d)
+            else:   # equal distances / NaN among the best k+1: the multiset of distances is pinned
+                a, b = np.sort(got_d), np.sort(d)
+                assert ((a == b) | (np.isnan(a) & np.isnan(b))).all(), (case, qi)
