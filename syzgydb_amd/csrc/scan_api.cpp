@@ -218,6 +218,19 @@ struct Shard {
 
 }  // namespace
 
+// One caller of szg_search_topk(n_queries == 1) waiting to be answered as part of a batch.
+struct PendingSearch {
+    const double *query;
+    int k;
+    uint64_t *out_rows;
+    double *out_dist;
+    int32_t *out_count;
+    int rc = 0;
+    bool done = false;
+    bool lead = false;  // told to take over as the batch leader
+    std::condition_variable cv;
+};
+
 struct szg_index {
     int dim = 0, bits = 0, metric = 0;
     uint32_t row_bytes = 0, pitch = 0;
@@ -239,6 +252,7 @@ struct szg_index {
     int tie_mode = 0;         // 0: exact full replay on ties/NaN, 1: keep the fast answer
     int serialize_scans = 1;  // scan launches of a shard never overlap each other
     int multi_query = 1;      // share one sweep between the queries of a batch (MFMA path)
+    int coalesce = 1;         // concurrent single-query calls share sweeps (see Combiner)
     int mq_fused = 1;         // shared sweep: threshold-collect selection instead of a score matrix
     int mq_i8 = 1;            // 8-bit rows: exact integer shared sweep (v_mfma_i32_16x16x64_i8)
     int mq_tail_overlap = 0;  // shared sweep: post-processing of a batch beside the next batch's sweep
@@ -246,6 +260,10 @@ struct szg_index {
     int mq_blocks_max = 3;    // query blocks of 16 per shared sweep (LDS image permitting)
     bool timing = false;
     std::mutex stats_mu;
+    // coalescing of concurrent single-query searches (szg_search_topk, n_queries == 1)
+    std::mutex comb_mu;
+    std::deque<struct PendingSearch *> comb_waiting;
+    bool comb_leader = false;
     szg_stats stats{};
 };
 
@@ -1956,7 +1974,76 @@ int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
         if (out_count) for (int i = 0; i < n_queries; i++) out_count[i] = 0;
         return SZG_OK;
     }
-    return search_topk_impl(ix, queries, n_queries, k, allow_bits, out_rows, out_dist, out_count);
+    if (!(ix->coalesce && n_queries == 1 && !allow_bits && ix->multi_query))
+        return search_topk_impl(ix, queries, n_queries, k, allow_bits, out_rows, out_dist, out_count);
+
+    // Search holds only RLock in the reference (collection.go:570), so many goroutines call in
+    // at once, each with ONE query.  Whoever finds no batch in flight becomes the leader: it
+    // answers everything that is waiting with the same k as one batch (one shared sweep instead
+    // of one sweep per caller), then hands the lead to a waiter if its own answer has arrived.
+    // A lone caller is its own batch of one and pays nothing for this.
+    PendingSearch me;
+    me.query = queries;
+    me.k = k;
+    me.out_rows = out_rows;
+    me.out_dist = out_dist;
+    me.out_count = out_count;
+    std::unique_lock<std::mutex> lk(ix->comb_mu);
+    ix->comb_waiting.push_back(&me);
+    if (ix->comb_leader) {
+        me.cv.wait(lk, [&] { return me.done || me.lead; });
+        if (me.done) return me.rc;
+    }
+    ix->comb_leader = true;
+    std::vector<PendingSearch *> batch;
+    std::vector<double> q;
+    std::vector<uint64_t> rows;
+    std::vector<double> dist;
+    std::vector<int32_t> count;
+    while (!me.done) {
+        batch.clear();
+        const int kk = ix->comb_waiting.front()->k;  // never empty here: `me` is in it until done
+        for (auto it = ix->comb_waiting.begin(); it != ix->comb_waiting.end() && batch.size() < 48;) {
+            if ((*it)->k == kk) {
+                batch.push_back(*it);
+                it = ix->comb_waiting.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        lk.unlock();
+        const int nq = (int)batch.size();
+        int rc;
+        if (nq == 1) {
+            PendingSearch *p = batch[0];
+            rc = search_topk_impl(ix, p->query, 1, kk, nullptr, p->out_rows, p->out_dist, p->out_count);
+        } else {
+            q.resize((size_t)nq * ix->dim);
+            rows.resize((size_t)nq * kk);
+            dist.resize((size_t)nq * kk);
+            count.resize(nq);
+            for (int i = 0; i < nq; i++) memcpy(&q[(size_t)i * ix->dim], batch[i]->query, sizeof(double) * ix->dim);
+            rc = search_topk_impl(ix, q.data(), nq, kk, nullptr, rows.data(), dist.data(), count.data());
+            for (int i = 0; i < nq && rc == SZG_OK; i++) {
+                memcpy(batch[i]->out_rows, &rows[(size_t)i * kk], sizeof(uint64_t) * kk);
+                memcpy(batch[i]->out_dist, &dist[(size_t)i * kk], sizeof(double) * kk);
+                if (batch[i]->out_count) *batch[i]->out_count = count[i];
+            }
+        }
+        lk.lock();
+        for (PendingSearch *p : batch) {
+            p->rc = rc;
+            p->done = true;
+            if (p != &me) p->cv.notify_one();
+        }
+    }
+    if (!ix->comb_waiting.empty()) {
+        ix->comb_waiting.front()->lead = true;  // it stays queued and forms the next batch itself
+        ix->comb_waiting.front()->cv.notify_one();
+    } else {
+        ix->comb_leader = false;
+    }
+    return me.rc;
 }
 
 int szg_search_radius(szg_index *ix, const double *query, double radius,
@@ -2139,6 +2226,8 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
     } else if (n == "mq_blocks") {
         if (value < 1 || value > 3) return fail(SZG_E_INVALID, "mq_blocks must be 1..3");
         ix->mq_blocks_max = (int)value;
+    } else if (n == "coalesce") {
+        ix->coalesce = value != 0;
     } else if (n == "mq_fused") {
         ix->mq_fused = value != 0;
     } else if (n == "mq_i8") {

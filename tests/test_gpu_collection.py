@@ -344,3 +344,39 @@ def test_concurrent_mixed_batches_from_threads(bits, metric, devices):
         [t.start() for t in th]
         [t.join() for t in th]
         assert not errs, errs[:3]
+
+
+def test_concurrent_single_queries_are_coalesced():
+    """Many threads, one query each (the reference's concurrent Searches under RLock): callers that
+    arrive while a batch is in flight are answered together by one shared sweep; answers unchanged."""
+    import threading
+    dim, n, bits, k = 48, 200000, 32, 6
+    rows = orc.synth_rows(41, 0, n, dim, bits)
+    Q = orc.synth_vectors(42, 0, 96, dim)
+    want = [orc.search_exact(rows, dim, bits, 1, Q[i], k=k) for i in range(Q.shape[0])]
+    with ScanIndex(dim, bits, 1) as ix:
+        ix.load(rows)
+        errs = []
+
+        def worker(t):
+            try:
+                for i in range(t, Q.shape[0], 16):
+                    kk = k if i % 5 else k - 1        # a second k in the mix: batches are per k
+                    r, d, c = ix.search_topk(Q[i], kk)
+                    assert [int(x) for x in r[0, : c[0]]] == [int(x) for x in want[i][0][:kk]], i
+                    assert (d[0, : c[0]] == want[i][1][:kk]).all()
+            except Exception as e:  # pragma: no cover
+                errs.append(repr(e))
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs[:3]
+        st = ix.stats()
+        assert st["queries"] == 96
+        assert st["mq_queries"] > 0          # some callers shared a sweep
+        ix.set_option("coalesce", 0)
+        ix.reset_stats()
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs and ix.stats()["mq_queries"] == 0
