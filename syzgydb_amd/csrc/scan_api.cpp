@@ -221,6 +221,7 @@ struct Shard {
 // One caller of szg_search_topk(n_queries == 1) waiting to be answered as part of a batch.
 struct PendingSearch {
     const double *query;
+    const uint64_t *allow;  // the caller's filter mask, or nullptr
     int k;
     uint64_t *out_rows;
     double *out_dist;
@@ -585,9 +586,9 @@ LaunchGeom scan_geometry(const szg_index *ix, const Shard *sh, int kp, bool plai
 size_t shard_words(const Shard *sh) { return (size_t)((sh->n_rows + 63) / 64); }
 
 // Enqueue H2D of nq prepared queries (+ their masks) on the ctx stream.
-// allow: nq masks of allow_stride words each (index-level), or nullptr.
-int enqueue_queries(szg_index *ix, Shard *sh, Ctx *c, const double *q, int nq,
-                    const uint64_t *allow, size_t allow_stride)
+// masks: nullptr (no query of the batch is filtered), or nq pointers to index-level masks
+// ((total_rows + 63) / 64 words each); a null entry allows every row.
+int enqueue_queries(szg_index *ix, Shard *sh, Ctx *c, const double *q, int nq, const uint64_t *const *masks)
 {
     HIPCHK(hipSetDevice(sh->device));
     memcpy(c->h_q64, q, sizeof(double) * ix->dim * nq);
@@ -595,15 +596,18 @@ int enqueue_queries(szg_index *ix, Shard *sh, Ctx *c, const double *q, int nq,
     HIPCHK(hipMemcpyAsync(c->d_qsw, c->h_qsw, ix->qsw_bytes * nq, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_q64, c->h_q64, sizeof(double) * ix->dim * nq, hipMemcpyHostToDevice,
                           c->stream));
-    if (allow) {
+    if (masks) {
         const size_t words = shard_words(sh);
         int rc = ensure_dev(&c->d_allow, &c->allow_cap, words * nq);
         if (rc) return rc;
         rc = ensure_host(&c->h_allow, &c->h_allow_cap, words * nq);
         if (rc) return rc;
-        for (int i = 0; i < nq; i++)
-            memcpy(c->h_allow + (size_t)i * words, allow + (size_t)i * allow_stride + sh->first / 64,
-                   words * sizeof(uint64_t));
+        for (int i = 0; i < nq; i++) {
+            if (masks[i])
+                memcpy(c->h_allow + (size_t)i * words, masks[i] + sh->first / 64, words * sizeof(uint64_t));
+            else
+                memset(c->h_allow + (size_t)i * words, 0xFF, words * sizeof(uint64_t));
+        }
         HIPCHK(hipMemcpyAsync(c->d_allow, c->h_allow, words * nq * sizeof(uint64_t),
                               hipMemcpyHostToDevice, c->stream));
     }
@@ -1163,16 +1167,23 @@ struct Ticket {
     std::vector<QMeta> meta;
     int kp = 0;
     bool failed = false;         // enqueueing failed part-way: drain and release only
+    bool any_mask = false;       // some query of the batch carries a filter mask
 };
 
+// allow_bits: n_queries masks back to back, or nullptr; allow_ptrs (used instead when given):
+// one mask pointer per query, null entries unfiltered.
 int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                      const uint64_t *allow_bits, uint64_t *out_rows, double *out_dist,
-                     int32_t *out_count)
+                     int32_t *out_count, const uint64_t *const *allow_ptrs = nullptr)
 {
     const size_t n_sh = ix->shards.size();
     uint64_t total_rows = 0;
     for (Shard *s : ix->shards) total_rows += s->n_rows;
     const size_t allow_stride = (total_rows + 63) / 64;
+    auto mask_of = [&](int qi) -> const uint64_t * {
+        if (allow_ptrs) return allow_ptrs[qi];
+        return allow_bits ? allow_bits + (size_t)qi * allow_stride : nullptr;
+    };
     const int kp = k + std::max(ix->slack_min, k / 2);
     for (Shard *s : ix->shards) {
         if (s->n_rows == 0) continue;
@@ -1242,7 +1253,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
         }
         for (int j = 0; j < t.nq && rc == SZG_OK; j++) {
             const int qi = t.first + j;
-            const uint64_t *allow = allow_bits ? allow_bits + (size_t)qi * allow_stride : nullptr;
+            const uint64_t *allow = mask_of(qi);
             std::vector<Cand> &cands = all[j];
             std::vector<HeapItem> res;
             replay_topk(cands, k, &res);
@@ -1286,7 +1297,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
                     Shard *sh = ix->shards[s];
                     if (sh->n_rows == 0) continue;
-                    rc = run_collect(ix, sh, t.ctx[s], j, thr_f, allow != nullptr, &cands);
+                    rc = run_collect(ix, sh, t.ctx[s], j, thr_f, t.any_mask, &cands);
                 }
                 if (rc == SZG_OK) replay_topk(cands, k, &res);
             }
@@ -1351,7 +1362,12 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
             continue;
         }
         const double *q = queries + (size_t)q0 * ix->dim;
-        const uint64_t *allow = allow_bits ? allow_bits + (size_t)q0 * allow_stride : nullptr;
+        std::vector<const uint64_t *> masks(t.nq);
+        for (int j = 0; j < t.nq; j++) {
+            masks[j] = mask_of(q0 + j);
+            t.any_mask |= masks[j] != nullptr;
+        }
+        const uint64_t *const *mptr = t.any_mask ? masks.data() : nullptr;
         for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
             Shard *sh = ix->shards[s];
             if (sh->n_rows == 0) continue;
@@ -1370,10 +1386,10 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 }
                 t.ctx[s]->meta[j] = t.meta[j];
             }
-            if (rc == SZG_OK) rc = enqueue_queries(ix, sh, t.ctx[s], q, t.nq, allow, allow_stride);
+            if (rc == SZG_OK) rc = enqueue_queries(ix, sh, t.ctx[s], q, t.nq, mptr);
             if (rc == SZG_OK)
-                rc = nb ? enqueue_topk_mq(ix, sh, t.ctx[s], kp, t.nq, nb, allow != nullptr)
-                        : enqueue_topk(ix, sh, t.ctx[s], kp, t.nq, allow != nullptr);
+                rc = nb ? enqueue_topk_mq(ix, sh, t.ctx[s], kp, t.nq, nb, t.any_mask)
+                        : enqueue_topk(ix, sh, t.ctx[s], kp, t.nq, t.any_mask);
         }
         t.failed = rc != SZG_OK;  // nothing to gather: finish() only drains and releases
         inflight.push_back(std::move(t));
@@ -1974,7 +1990,7 @@ int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
         if (out_count) for (int i = 0; i < n_queries; i++) out_count[i] = 0;
         return SZG_OK;
     }
-    if (!(ix->coalesce && n_queries == 1 && !allow_bits && ix->multi_query))
+    if (!(ix->coalesce && n_queries == 1 && ix->multi_query))
         return search_topk_impl(ix, queries, n_queries, k, allow_bits, out_rows, out_dist, out_count);
 
     // Search holds only RLock in the reference (collection.go:570), so many goroutines call in
@@ -1984,6 +2000,7 @@ int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
     // A lone caller is its own batch of one and pays nothing for this.
     PendingSearch me;
     me.query = queries;
+    me.allow = allow_bits;
     me.k = k;
     me.out_rows = out_rows;
     me.out_dist = out_dist;
@@ -2000,6 +2017,7 @@ int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
     std::vector<uint64_t> rows;
     std::vector<double> dist;
     std::vector<int32_t> count;
+    std::vector<const uint64_t *> masks;
     while (!me.done) {
         batch.clear();
         const int kk = ix->comb_waiting.front()->k;  // never empty here: `me` is in it until done
@@ -2016,14 +2034,21 @@ int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
         int rc;
         if (nq == 1) {
             PendingSearch *p = batch[0];
-            rc = search_topk_impl(ix, p->query, 1, kk, nullptr, p->out_rows, p->out_dist, p->out_count);
+            rc = search_topk_impl(ix, p->query, 1, kk, p->allow, p->out_rows, p->out_dist, p->out_count);
         } else {
             q.resize((size_t)nq * ix->dim);
             rows.resize((size_t)nq * kk);
             dist.resize((size_t)nq * kk);
             count.resize(nq);
-            for (int i = 0; i < nq; i++) memcpy(&q[(size_t)i * ix->dim], batch[i]->query, sizeof(double) * ix->dim);
-            rc = search_topk_impl(ix, q.data(), nq, kk, nullptr, rows.data(), dist.data(), count.data());
+            masks.resize(nq);
+            bool any = false;
+            for (int i = 0; i < nq; i++) {
+                memcpy(&q[(size_t)i * ix->dim], batch[i]->query, sizeof(double) * ix->dim);
+                masks[i] = batch[i]->allow;  // each caller's own filter, if it has one
+                any |= masks[i] != nullptr;
+            }
+            rc = search_topk_impl(ix, q.data(), nq, kk, nullptr, rows.data(), dist.data(), count.data(),
+                                  any ? masks.data() : nullptr);
             for (int i = 0; i < nq && rc == SZG_OK; i++) {
                 memcpy(batch[i]->out_rows, &rows[(size_t)i * kk], sizeof(uint64_t) * kk);
                 memcpy(batch[i]->out_dist, &dist[(size_t)i * kk], sizeof(double) * kk);
@@ -2085,7 +2110,7 @@ int szg_search_radius(szg_index *ix, const double *query, double radius,
         Ctx *c = ctx_acquire(sh);
         memcpy(c->h_qsw, tmp.data(), ix->qsw_bytes);
         c->meta[0] = meta;
-        rc = enqueue_queries(ix, sh, c, query, 1, allow_bits, (total_rows + 63) / 64);
+        rc = enqueue_queries(ix, sh, c, query, 1, allow_bits ? &allow_bits : nullptr);
         if (rc == SZG_OK) rc = run_collect(ix, sh, c, 0, thr_f, allow_bits != nullptr, &cands);
         ctx_release(sh, c);
     }

@@ -354,6 +354,10 @@ def test_concurrent_single_queries_are_coalesced():
     rows = orc.synth_rows(41, 0, n, dim, bits)
     Q = orc.synth_vectors(42, 0, 96, dim)
     want = [orc.search_exact(rows, dim, bits, 1, Q[i], k=k) for i in range(Q.shape[0])]
+    rng = np.random.default_rng(3)
+    allow = rng.random((4, n)) < 0.3
+    want_f = {i: orc.search_exact(rows, dim, bits, 1, Q[i], k=k, allow=allow[i % 4].astype(np.uint8))
+              for i in range(0, Q.shape[0], 3)}
     with ScanIndex(dim, bits, 1) as ix:
         ix.load(rows)
         errs = []
@@ -362,9 +366,14 @@ def test_concurrent_single_queries_are_coalesced():
             try:
                 for i in range(t, Q.shape[0], 16):
                     kk = k if i % 5 else k - 1        # a second k in the mix: batches are per k
-                    r, d, c = ix.search_topk(Q[i], kk)
-                    assert [int(x) for x in r[0, : c[0]]] == [int(x) for x in want[i][0][:kk]], i
-                    assert (d[0, : c[0]] == want[i][1][:kk]).all()
+                    if i % 3 == 0:                    # every third caller brings its own filter
+                        r, d, c = ix.search_topk(Q[i], kk, allow=allow[i % 4])
+                        w = want_f[i]
+                    else:
+                        r, d, c = ix.search_topk(Q[i], kk)
+                        w = want[i]
+                    assert [int(x) for x in r[0, : c[0]]] == [int(x) for x in w[0][:kk]], i
+                    assert (d[0, : c[0]] == w[1][:kk]).all()
             except Exception as e:  # pragma: no cover
                 errs.append(repr(e))
         th = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
