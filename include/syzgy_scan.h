@@ -199,7 +199,9 @@ int szg_reset_stats(szg_index *ix);
  * 4/8/16/32-bit collections, either metric, share ONE sweep of the corpus, the dot
  * products going to the matrix cores; 0 = every query gets its own sweep), "mq_i8" (default 1: 8- and 4-bit collections run the shared sweep in exact
  * integer arithmetic on the int8 matrix cores, v_mfma_i32_16x16x64_i8; 0 = the float32 MFMA
- * sweep), "coalesce" (default 1: concurrent szg_search_topk calls with ONE query
+ * sweep), "mask_dense" (default 1: sweeps whose filter / tombstone masks pass
+ * at least half the rows read every row and apply the masks at the row finish; 0 = always
+ * test a row before loading it), "coalesce" (default 1: concurrent szg_search_topk calls with ONE query
  * each -- the reference's Searches under RLock -- are answered together, up to 48 per shared
  * sweep, by whichever caller finds no batch in flight; 0 = every call sweeps for itself),
  * "mq_fused" (default 1: threshold-collect selection instead of a score matrix),

@@ -102,6 +102,8 @@ struct ScanArgs {
     float qscale[kMaxSweepsPerLaunch], qconst[kMaxSweepsPerLaunch], qnorm2[kMaxSweepsPerLaunch];
     double norm_bias;
     int no_shape_kernels;       // tuning hook: always take the any-shape kernel
+    int mask_dense;             // masked sweep that reads every row and applies the masks at the row finish
+                                // (most rows pass); 0 = rows are tested before their loads are issued
     int kp;                     // candidates kept per list (top-k mode)
     uint64_t *block_lists;      // [n_queries][grid][kp] sorted ascending (top-k mode)
     // collect mode (radius search / escalation): every row with key <= thr is appended

@@ -366,6 +366,19 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
         return v;
     };
 
+    // Dense phase under masks (a.mask_dense: most rows pass, so every row is read and the masks
+    // only decide at the row finish).  The wave's rows [row0, row0 + gpw) sit in one 64-bit
+    // word of each bitmap; row0 is wave-uniform, so the words come through scalar loads and
+    // never enter the vector-memory queue the ring is counting.
+    auto dense_valid = [&](uint64_t row0) -> bool {
+        if (!MASKED) return true;
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)row0);
+        uint64_t w = ~0ull;
+        if (a.live_bits) w &= a.live_bits[r0 >> 6];
+        if (allow_bits) w &= allow_bits[r0 >> 6];
+        return (w >> ((r0 & 63u) + (uint32_t)grp)) & 1ull;
+    };
+
     // One row is done: reduce the group's L lanes, form the key, select.
     const Grp grp_info{L, lig, LL ? true : a.map.pow2 != 0};
     auto finish_row = [&](uint64_t row0, bool valid, RowAcc<QBITS, METRIC> &acc) {
@@ -484,7 +497,7 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
     // range.  No predicates at all: pointer-increment addressing, unconditional
     // accumulation.  Covers all but (at most) the wave's last row step.
     uint64_t it_dense = 0;
-    if (!MASKED && (LL || a.map.dense) && row_first + (uint64_t)gpw <= a.n_rows)
+    if ((!MASKED || a.mask_dense) && (LL || a.map.dense) && row_first + (uint64_t)gpw <= a.n_rows)
         it_dense = (a.n_rows - (uint64_t)gpw - row_first) / stride + 1;
     if (it_dense * (uint64_t)P < 2 * D) it_dense = 0;  // too short for the ring: general phase
     uint64_t crow0 = row_first;
@@ -512,7 +525,7 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
         const u32x4 v_ = ring[u];                                                       \
         acc.piece(make_uint4(v_.x, v_.y, v_.z, v_.w), smem, jc, r16, a.dim);                     \
         if (++cp == P) {                                                                \
-            finish_row(crow0, true, acc);                                               \
+            finish_row(crow0, dense_valid(crow0), acc);                                 \
             acc.reset();                                                                \
             cp = 0;                                                                     \
             jc = lig;                                                                   \

@@ -253,6 +253,7 @@ struct szg_index {
     int tie_mode = 0;         // 0: exact full replay on ties/NaN, 1: keep the fast answer
     int serialize_scans = 1;  // scan launches of a shard never overlap each other
     int multi_query = 1;      // share one sweep between the queries of a batch (MFMA path)
+    int mask_dense = 1;       // masked sweeps whose masks pass most rows use the dense phase
     int coalesce = 1;         // concurrent single-query calls share sweeps (see Combiner)
     int mq_fused = 1;         // shared sweep: threshold-collect selection instead of a score matrix
     int mq_i8 = 1;            // 8-bit rows: exact integer shared sweep (v_mfma_i32_16x16x64_i8)
@@ -695,11 +696,34 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
     rc = ensure_host(&c->h_out, &c->h_out_cap, (size_t)nq * kp);
     if (rc) return rc;
 
+    // Masked sweeps: when most rows pass (a few tombstones, a mild filter) every row is read and
+    // the masks decide at the row finish -- the predicate-free dense phase; a selective filter
+    // keeps the form that tests a row before issuing its loads.  Pass rates are estimated from
+    // a sample of each mask's words.
+    auto pass_rate = [&](int j) -> double {
+        double live = sh->n_rows ? (double)sh->n_live / (double)sh->n_rows : 1.0;
+        if (!has_allow) return live;
+        const size_t words = shard_words(sh);
+        const uint64_t *m = c->h_allow + (size_t)j * words;
+        const size_t step = std::max<size_t>(1, words / 256);
+        uint64_t ones = 0, seen = 0;
+        for (size_t w = 0; w < words; w += step) {
+            ones += (uint64_t)__builtin_popcountll(m[w]);
+            seen += 64;
+        }
+        return live * (seen ? (double)ones / (double)seen : 1.0);
+    };
+    const bool masked = has_allow || sh->has_dead;
     const int qpl = std::max(1, ix->queries_per_launch);
     std::vector<szg::ScanArgs> args((nq + qpl - 1) / qpl);
     for (int j = 0; j < nq; j += qpl) {  // one sweep per query, results side by side
         szg::ScanArgs &a = args[j / qpl];
         fill_scan_args(ix, sh, c, has_allow, j, std::min(qpl, nq - j), &a);
+        if (masked && ix->mask_dense) {
+            double lowest = 1.0;
+            for (int i = j; i < std::min(nq, j + qpl); i++) lowest = std::min(lowest, pass_rate(i));
+            a.mask_dense = lowest >= 0.5 ? 1 : 0;
+        }
         a.kp = kp;
         a.block_lists = c->d_lists_a + (size_t)j * g.grid * kp;
     }
@@ -2251,6 +2275,8 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
     } else if (n == "mq_blocks") {
         if (value < 1 || value > 3) return fail(SZG_E_INVALID, "mq_blocks must be 1..3");
         ix->mq_blocks_max = (int)value;
+    } else if (n == "mask_dense") {
+        ix->mask_dense = value != 0;
     } else if (n == "coalesce") {
         ix->coalesce = value != 0;
     } else if (n == "mq_fused") {
