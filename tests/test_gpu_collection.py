@@ -380,12 +380,38 @@ def test_concurrent_single_queries_are_coalesced():
         [t.start() for t in th]
         [t.join() for t in th]
         assert not errs, errs[:3]
-        st = ix.stats()
-        assert st["queries"] == 96
-        assert st["mq_queries"] > 0          # some callers shared a sweep
+        assert ix.stats()["queries"] == 96
         ix.set_option("coalesce", 0)
         ix.reset_stats()
         th = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
         [t.start() for t in th]
         [t.join() for t in th]
         assert not errs and ix.stats()["mq_queries"] == 0
+
+    # that sweeps really are shared: a corpus whose sweep takes long enough (~100 us) for 32
+    # threads to pile up behind the leader; answers must equal the one-call-at-a-time ones
+    from syzgydb_amd.synth import synth_vectors
+    dim, n = 128, 1_500_000
+    Q = synth_vectors(43, 0, 64, dim)
+    with ScanIndex(dim, 32, 1) as ix:
+        ix.synth(n, 44)
+        ix.set_option("coalesce", 0)
+        base = [ix.search_topk(Q[i], k)[0][0].copy() for i in range(Q.shape[0])]
+        ix.set_option("coalesce", 1)
+        ix.reset_stats()
+        start = threading.Barrier(32)
+        bad = []
+
+        def hammer(t):
+            start.wait()
+            for rep in range(10):
+                i = (t * 7 + rep * 3) % Q.shape[0]
+                r, _, _ = ix.search_topk(Q[i], k)
+                if not (r[0] == base[i]).all():
+                    bad.append(i)
+        th = [threading.Thread(target=hammer, args=(t,)) for t in range(32)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        st = ix.stats()
+        assert not bad and st["queries"] == 320
+        assert st["mq_queries"] > 0          # some callers shared a sweep
