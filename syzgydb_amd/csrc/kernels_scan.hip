@@ -34,7 +34,8 @@ constexpr int kWave = 64;
 #ifndef SZG_MIN_BLOCKS
 #define SZG_MIN_BLOCKS 4  // 256-thread blocks per CU the register budget allows
 #endif
-[[maybe_unused]] constexpr int kRing = SZG_RING;  // 16-byte loads each lane keeps in flight
+[[maybe_unused]] constexpr int kRing = SZG_RING;
+[[maybe_unused]] constexpr int kStepList = 256;  // row steps a wave compacts at a time (selective masks)  // 16-byte loads each lane keeps in flight
 
 template <int QBITS>
 struct Traits {
@@ -330,6 +331,9 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
 
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem + qbytes);
     uint64_t *mylist = lists + (size_t)wave * a.kp;
+    [[maybe_unused]] uint32_t *steplist =
+        reinterpret_cast<uint32_t *>(smem + qbytes + (size_t)nwaves * (COLLECT ? 0 : a.kp) * sizeof(uint64_t)) +
+        (size_t)wave * kStepList;
     const int L = LL ? LL : a.map.L, P = PP ? PP : a.map.P, gpw = LL ? kWave / LL : a.map.gpw;
     const int grp = lane / L;
     const int lig = lane - grp * L;
@@ -539,18 +543,64 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
 #undef SZG_DN_CONSUME
     }
 
-    // ---- general phase: masks, partial groups, ragged tails
+    // ---- general phase: masks, partial groups, ragged tails.
+    // Under selective masks (MASKED && !mask_dense) most row steps of a wave hold no row that
+    // passes; the wave first compacts the steps that do into its LDS step list (each lane tests
+    // one step: a shift and a mask on the bitmap words), then rings over those only -- the
+    // cost follows the rows that pass, not the corpus.
     {
-    uint32_t okmask = 0;
-    const uint64_t NP = (n_it - it_dense) * (uint64_t)P;  // pieces left for this wave
-    // issue cursor
-    uint64_t irow0 = crow0;
-    int ip = 0;
-    bool ivalid = row_valid(irow0);
-    bool inext = MASKED ? row_valid(irow0 + stride) : false;
     const RowLayout glay{a.pitch, a.tiled, a.steps};
+    // (the test needs a step's gpw rows inside one bitmap word: gpw a power of two)
+    const bool compact = MASKED && !a.mask_dense && (gpw & (gpw - 1)) == 0;
+    uint64_t it_next = it_dense;  // next row step of this wave still to be looked at
+    while (it_next < n_it) {
+    uint64_t n_steps;             // steps of this round
+    const uint64_t it_base = it_next;
+    if (compact) {
+        int nl = 0;
+        while (it_next < n_it && nl <= kStepList - kWave) {
+            const uint64_t it = it_next + lane;
+            bool v = false;
+            if (it < n_it) {
+                const uint64_t r0 = row_first + it * stride;  // gpw rows, inside one bitmap word
+                if (r0 < a.n_rows) {
+                    const uint32_t rr = (uint32_t)r0;
+                    uint64_t w = ~0ull;
+                    if (a.live_bits) w &= a.live_bits[rr >> 6];
+                    if (allow_bits) w &= allow_bits[rr >> 6];
+                    const uint64_t cnt = min((uint64_t)gpw, (uint64_t)a.n_rows - r0);
+                    const uint64_t m = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+                    v = ((w >> (rr & 63u)) & m) != 0;
+                }
+            }
+            const uint64_t bal = __ballot(v);
+            if (v) steplist[nl + __popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)(it - it_base);
+            nl += __popcll(bal);
+            it_next += kWave;
+        }
+        if (it_next > n_it) it_next = n_it;
+        n_steps = (uint64_t)nl;
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        n_steps = n_it - it_next;
+        it_next = n_it;
+    }
+    auto step_row0 = [&](uint64_t i) -> uint64_t {  // first row of the round's i-th step
+        const uint64_t it = compact ? it_base + (i < n_steps ? steplist[i] : 0u) : it_base + i;
+        return row_first + it * stride;
+    };
+    uint32_t okmask = 0;
+    const uint64_t NP = n_steps * (uint64_t)P;  // pieces of this round
+    // issue cursor
+    uint64_t istep = 0;
+    uint64_t irow0 = step_row0(0);
+    int ip = 0;
+    bool ivalid = n_steps ? row_valid(irow0) : false;
+    bool inext = (MASKED && n_steps > 1) ? row_valid(step_row0(1)) : false;
     uint64_t irow = (uint32_t)(irow0 + grp);
     // consume cursor
+    uint64_t cstep = 0;
+    crow0 = irow0;
     int cp = 0;
     bool cvalid = false;
 
@@ -562,11 +612,12 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
         okmask = (okmask & ~(1u << (u))) | ((uint32_t)ok_ << (u));                      \
         if (++ip == P) {                                                                \
             ip = 0;                                                                     \
-            irow0 += stride;                                                            \
+            istep++;                                                                    \
+            irow0 = step_row0(istep);                                                   \
             irow = (uint32_t)(irow0 + grp);                                             \
             if (MASKED) {                                                               \
                 ivalid = inext;                                                         \
-                inext = row_valid(irow0 + stride);                                      \
+                inext = istep + 1 < n_steps ? row_valid(step_row0(istep + 1)) : false;  \
             } else {                                                                    \
                 ivalid = active && irow0 + grp < a.n_rows;                              \
             }                                                                           \
@@ -586,13 +637,15 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
             finish_row(crow0, cvalid, acc);                                             \
             acc.reset();                                                                \
             cp = 0;                                                                     \
-            crow0 += stride;                                                            \
+            cstep++;                                                                    \
+            crow0 = step_row0(cstep);                                                   \
         }                                                                               \
     }
 
     if (NP) SZG_RUN_RING(NP, SZG_ISSUE, SZG_CONSUME)
 #undef SZG_ISSUE
 #undef SZG_CONSUME
+    }  // rounds
     }
 #undef SZG_RUN_RING
 #undef SZG_RUN_RING_DENSE
@@ -801,7 +854,9 @@ hipError_t launch_scan_q64(int, const ScanArgs &, int, int, size_t, hipStream_t)
 
 size_t scan_lds_bytes(int qbits, const RowMap &m, int kp, int block)
 {
-    return query_lds_bytes(qbits, m.r16) + (size_t)(block / kWave) * kp * sizeof(uint64_t);
+    // query image + per-wave candidate lists + per-wave lists of row steps that survive the masks
+    return query_lds_bytes(qbits, m.r16) + (size_t)(block / kWave) * kp * sizeof(uint64_t) +
+           (size_t)(block / kWave) * kStepList * sizeof(uint32_t);
 }
 
 hipError_t launch_scan(int qbits, int metric, const ScanArgs &a, int grid, int block,
