@@ -10,9 +10,10 @@ q = synth_vectors(99, 0, 256, dim)
 rng = np.random.default_rng(1)
 with ScanIndex(dim, bits, metric, devices=[0]) as ix:
     ix.synth(n, 1234)
+    rates = [float(x) for x in os.environ.get("SZG_RATES", "1.0,0.5,0.05,0.001").split(",")]
     for mqo in (0, 1):
         ix.set_option("multi_query", mqo)
-        for rate in (1.0, 0.5, 0.05, 0.001):
+        for rate in rates:
             mask = pack_allow_bits(rng.random(n) < rate)
             masks = np.tile(mask, (256, 1))
             ix.search_topk(q[:32], k, allow=masks[:32])
