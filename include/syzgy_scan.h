@@ -190,29 +190,38 @@ int szg_get_stats(szg_index *ix, szg_stats *out);
 int szg_reset_stats(szg_index *ix);
 
 /*
- * Tunables: "slack" (extra candidates kept beyond k), "blocks_per_cu" (0 = default:
- * chosen from the row format, 8-16 waves per CU),
- * "block_threads", "query_batch" (queries staged, merged, re-ranked and copied back
- * together, default 16), "queries_per_launch" (sweeps one scan launch walks back to
- * back, query-major, default 16: no launch gap or chip-wide tail between the sweeps of
- * a batch; 1 = one launch per sweep), "multi_query" (default 1: batches of >= "mq_min" (default 2) queries on
- * 4/8/16/32-bit collections, either metric, share ONE sweep of the corpus, the dot
- * products going to the matrix cores; 0 = every query gets its own sweep), "mq_i8" (default 1: 8- and 4-bit collections run the shared sweep in exact
- * integer arithmetic on the int8 matrix cores, v_mfma_i32_16x16x64_i8; 0 = the float32 MFMA
- * sweep), "mask_dense" (default 1: sweeps whose filter / tombstone masks pass
- * at least half the rows read every row and apply the masks at the row finish; 0 = always
- * test a row before loading it), "coalesce" (default 1: concurrent szg_search_topk calls with ONE query
- * each -- the reference's Searches under RLock -- are answered together, up to 48 per shared
- * sweep, by whichever caller finds no batch in flight; 0 = every call sweeps for itself),
- * "mq_fused" (default 1: threshold-collect selection instead of a score matrix),
- * "mq_tail_overlap" (default 0; 1 = a shared-sweep batch's
- * selection / rerank / copy-back run beside the next batch's sweep: +3-6 % queries/s, the
- * sweep itself 5 % slower), "contexts" (batches in flight per shard), "serialize_scans",
- * "tie_mode" (0 = default: when two of the best k+1 distances
- * are exactly equal, or one is NaN, the reference's output depends on its whole
- * heap history, so the query is re-answered by an exact replay over every row;
- * 1 = keep the fast answer, which is a valid top-k whose order among equal
- * distances may differ from the reference's), "force_escalate" (tests).
+ * Tunables (name, default, meaning).  All are safe to change between calls.
+ *
+ *   answer semantics
+ *     tie_mode            0   when two of the best k+1 distances are exactly equal, or one is NaN,
+ *                             the reference's output depends on its whole heap history, so the
+ *                             query is re-answered by an exact replay over every row; 1 = keep the
+ *                             fast answer (a valid top-k whose order among equal distances may
+ *                             differ from the reference's)
+ *     slack               16  extra candidates kept beyond k (at least; k/2 when larger)
+ *   one sweep per query
+ *     queries_per_launch  16  sweeps one scan launch walks back to back (query-major): no launch
+ *                             gap or chip-wide tail between the sweeps of a batch
+ *     query_batch         16  queries staged, merged, re-ranked and copied back together
+ *     blocks_per_cu       0   0 = chosen from the row format (8-12 waves per CU); block_threads 256
+ *     mask_dense          1   sweeps whose filter / tombstone masks pass at least half the rows read
+ *                             every row and apply the masks at the row finish; selective masks (and
+ *                             0) compact the row steps that hold a passing row first
+ *     shape_kernels       1   row-shape-specialised kernels where they exist (4-bit rows)
+ *     serialize_scans     1   sweeps of one shard never overlap each other; contexts 3 = batches in flight
+ *   shared sweeps
+ *     multi_query         1   batches of >= mq_min (2) queries share ONE sweep of the corpus, the
+ *                             dot products on the matrix cores (4/8/16/32-bit rows, either metric),
+ *                             up to 16 * mq_blocks (3) queries per sweep; 0 = one sweep per query
+ *     mq_i8               1   8- and 4-bit rows: exact integer sweep on the int8 matrix cores
+ *                             (v_mfma_i32_16x16x64_i8); 0 = the float32 MFMA sweep
+ *     mq_fused            1   threshold-collect selection instead of a score matrix
+ *     mq_tail_overlap     0   1 = a batch's selection / rerank / copy-back run beside the next
+ *                             batch's sweep (+3-6 % queries/s, the sweep itself 5 % slower)
+ *     coalesce            1   concurrent szg_search_topk calls with ONE query each -- the
+ *                             reference's Searches under RLock -- are answered together, up to 48
+ *                             per shared sweep, by whichever caller finds no batch in flight
+ *   tests / tuning hooks: force_escalate, lanes_per_row
  */
 int szg_set_option(szg_index *ix, const char *name, int64_t value);
 
