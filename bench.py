@@ -44,6 +44,13 @@ WORKLOADS = {
 SEED = 0x53595A4700000000
 
 
+# Libraries print to fd 1 (RCCL's version banner on communicator creation, for one): keep the real
+# stdout for the JSON line and point fd 1 at stderr for everything else.
+_REAL_STDOUT = os.fdopen(os.dup(1), "w")
+os.dup2(2, 1)
+sys.stdout = sys.stderr
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -76,6 +83,12 @@ def traffic_for(workload, rows_override, sweeps_per_launch):
         return int(e["hbm_bytes_per_launch"] / float(e.get("sweeps_per_launch", 1)) * sweeps_per_launch)
     except Exception:
         return None
+
+
+def emit(obj):
+    """The ONE JSON line, on the process's real stdout."""
+    _REAL_STDOUT.write(json.dumps(obj) + "\n")
+    _REAL_STDOUT.flush()
 
 
 def main():
@@ -314,11 +327,11 @@ def main():
             log("parity leg: %.1f s" % (time.time() - t0))
             if same != nv:
                 log("bench.py: PARITY FAILURE: GPU ids differ from the oracle's")
-                print(json.dumps(out))
+                emit(out)
                 sys.exit(1)
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     ix.close()
     if dist is not None:
         dist.barrier()
