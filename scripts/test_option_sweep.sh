@@ -4,7 +4,7 @@
 out=$GRAFT_REPO_ROOT/gpurun_out/option_sweep.log
 : > $out
 for opts in "serialize_scans=0" "queries_per_launch=1" "queries_per_launch=3,blocks_per_cu=1" "shape_kernels=0,block_threads=128" \
-            "mq_fused=0,mq_i8=0" "mq_tail_overlap=1,mq_blocks=2" "multi_query=0,query_batch=5" "contexts=1,blocks_per_cu=6"; do
+            "mq_fused=0,mq_i8=0" "mq_tail_overlap=1,mq_blocks=2" "multi_query=0,query_batch=5" "contexts=1,blocks_per_cu=6" "mask_dense=0,coalesce=0" "mq_min=8,tie_mode=0"; do
   echo "== $opts" >> $out
   SZG_OPTIONS=$opts timeout -k 10 600 python -m pytest tests -m gpu -q -x \
       --deselect tests/test_gpu_multiquery.py::test_shared_sweep_matches_oracle \
@@ -13,6 +13,7 @@ for opts in "serialize_scans=0" "queries_per_launch=1" "queries_per_launch=3,blo
       --deselect tests/test_gpu_multiquery.py::test_shared_sweep_euclidean_far_from_origin \
       --deselect tests/test_gpu_multiquery.py::test_shared_sweep_int8_mfma \
       --deselect tests/test_gpu_multiquery.py::test_fused_selection_overflow_falls_back \
+      --deselect tests/test_gpu_collection.py::test_concurrent_single_queries_are_coalesced \
       -k "not two_shards and not masks_tombstones" 2>&1 | tail -3 >> $out
 done
 cat $out
