@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec of the exact (brute-force) scan behind Collection.Search.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--mode ranks|inproc]
 
-A "step" is one exact top-k query over the whole synthetic corpus (one sweep of
-the packed rows through the fused HIP scan, rerank and result assembly
-included).  Default workload = BASELINE.json's headline: 1M x 768 float32,
-cosine (angular) distance, k=10, one query per sweep.  With N>1 (launched by
-torch.distributed.run, one rank per GPU) the corpus is sharded by rows over the
-ranks, every query goes to every rank and the per-shard top-k lists are merged
-after one RCCL all-gather per micro-batch ("scaling": "strong").
+A "step" is one exact query over the whole synthetic corpus (one sweep of the packed
+rows through the fused HIP scan; merges, float64 rerank and result assembly included).
+Default workload = BASELINE.json's headline: 1M x 768 float32, cosine (angular)
+distance, k=10, one query per sweep.
+
+N > 1, two forms of the same row sharding (contiguous 64-row-aligned ranges, every
+query goes to every shard, "scaling": "strong"):
+  --mode ranks   (default) one process per GPU under torch.distributed.run; the per-shard
+                 exact top-(k+1) lists are merged after ONE RCCL all-gather per micro-batch.
+                 Called without WORLD_SIZE in the environment, `python bench.py --gpus N`
+                 starts the N ranks itself (a child torch.distributed.run, spawned before
+                 this process has touched a GPU) and relays the one JSON line.
+  --mode inproc  ONE process, one handle with devices=[0..N-1] -- the form the Go binding
+                 uses (go/syzgy_gpu.go): shards and merge inside the library.
 
 Rank 0 prints ONE JSON line: metric/value/unit/..., plus
-  "roofline":     HBM roofline of the fused scan kernel, from HIP events recorded
-                  on the library's scan stream inside the timed region;
-  "cpu_baseline": the CPU oracle (a C port of the reference's Go scan; there is
-                  no Go toolchain in this image) timed on this box's host cores on
-                  a bounded sample of the same workload (N=1, rank 0 only).
+  "roofline":     HBM roofline of the fused scan kernel from HIP events recorded on the
+                  library's scan stream inside the timed region;
+  "cpu_baseline": the CPU oracle (a C port of the reference's Go scan; there is no Go
+                  toolchain in this image) on this box's host cores, bounded sample (N=1);
+  "batched":      the shared multi-query sweep on the matrix cores (its own fixed query set);
+  "host_us_per_query", "ranks", "rccl_ranks", "other_workloads" (cfg2/cfg3/cfg4/cfg5 per-GPU
+                  shards: one roofline object each).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,9 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TF = 157.3
 
 WORKLOADS = {
     # name: (rows, dim, bits, metric, k, radius)   metric 0 = Euclidean, 1 = Cosine
@@ -38,10 +47,13 @@ WORKLOADS = {
     "cfg2": (1_000_000, 384, 32, 1, 10, 0.0),
     "cfg3": (1_000_000, 768, 8, 1, 10, 0.0),
     "cfg4": (10_000_000, 768, 32, 0, 100, 0.0),
-    "cfg5": (100_000_000, 384, 4, 1, 0, 0.42),
+    "cfg5": (100_000_000, 384, 4, 1, 0, 0.42),          # radius search: K is ignored (collection.go:598-605)
     "plumbing": (10_000, 128, 32, 1, 10, 0.0),
 }
+# the per-GPU shards of the 8-GPU configurations (what one card sweeps per query there)
+SHARD_ROWS = {"cfg4": 1_250_000, "cfg5": 12_500_000}
 SEED = 0x53595A4700000000
+DTYPE = {4: "u4", 8: "u8", 16: "u16", 32: "f32", 64: "f64"}
 
 
 # Libraries print to fd 1 (RCCL's version banner on communicator creation, for one): keep the real
@@ -53,6 +65,12 @@ sys.stdout = sys.stderr
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def emit(obj):
+    """The ONE JSON line, on the process's real stdout."""
+    _REAL_STDOUT.write(json.dumps(obj) + "\n")
+    _REAL_STDOUT.flush()
 
 
 def host_cores():
@@ -71,24 +89,164 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def traffic_for(workload, rows_override, sweeps_per_launch):
-    """HBM bytes per scan launch from the PMC passes recorded in profiles/traffic.json
-    (FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE), scaled from the sweeps per
-    launch of the PMC run to this run's; None when no pass exists for this exact workload."""
+def recorded_traffic(workload, rows_override, sweeps_per_launch):
+    """HBM bytes per scan launch as RECORDED by the PMC passes under profiles/ (FETCH_SIZE with
+    the gfx950 x2 correction + WRITE_SIZE; separate rocprofv3 runs, not this run), scaled from
+    the sweeps per launch of the PMC run to this run's.  (None, None) when no pass exists."""
     if rows_override:
-        return None
+        return None, None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             e = json.load(f)[workload]
-        return int(e["hbm_bytes_per_launch"] / float(e.get("sweeps_per_launch", 1)) * sweeps_per_launch)
+        return (int(e["hbm_bytes_per_launch"] / float(e.get("sweeps_per_launch", 1)) * sweeps_per_launch),
+                "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
+                "not measured in this run)")
     except Exception:
-        return None
+        return None, None
 
 
-def emit(obj):
-    """The ONE JSON line, on the process's real stdout."""
-    _REAL_STDOUT.write(json.dumps(obj) + "\n")
-    _REAL_STDOUT.flush()
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the ranks as a CHILD
+    torch.distributed.run (this process has not touched a GPU and never will) and relay
+    rank 0's JSON line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    log("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)))
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{"):
+            line = ln
+        elif ln.strip():
+            log(ln)
+    if line is not None:
+        _REAL_STDOUT.write(line + "\n")
+        _REAL_STDOUT.flush()
+    if p.returncode != 0 or line is None:
+        log("bench.py: the rank launcher exited with %d%s" % (p.returncode, "" if line else " and no JSON line"))
+        sys.exit(p.returncode or 1)
+    sys.exit(0)
+
+
+def roofline_of(stats, rows, row_bytes, bits, metric, kind):
+    """HBM roofline object of the scan launches timed in `stats` (HIP events on the scan stream)."""
+    launches = max(stats["timed_launches"], 1)
+    scan_ms = stats["scan_ms"] / launches
+    bytes_per_launch = stats["scan_bytes"] / max(stats["scan_launches"], 1)
+    achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    return {
+        "bound": "hbm",
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None,
+        "kernel": "szg::scan_kernel<%d,%d,%s>" % (bits, metric, kind),
+        "bytes_per_launch": int(bytes_per_launch),
+        "sweeps_per_launch": round(bytes_per_launch / float(max(rows * row_bytes, 1)), 2),
+        "avg_launch_ms": round(scan_ms, 5),
+        "launches": int(stats["timed_launches"]),
+    }
+
+
+def calibrated_radius(ix, queries, radius, target_hits=500):
+    """cfg5's radius (calibrate so a query has 1e2-1e3 hits): the distance of the
+    target_hits-th neighbour of the first query, unless the named radius already lands there."""
+    r, d = ix.search_radius(queries[0], radius, capacity=None)
+    if 50 <= len(r) <= 5000:
+        return radius, len(r)
+    kk = min(target_hits, ix.rows)
+    _, dd, cnt = ix.search_topk(queries[0], kk)
+    rad = float(dd[0, int(cnt[0]) - 1])
+    r, d = ix.search_radius(queries[0], rad)
+    return rad, len(r)
+
+
+def timed_leg(ix, queries, k, radius, n_settle=16):
+    """Side workloads (one card, one query per sweep): a short settle, then the queries with HIP
+    events on; returns (queries/s, stats, hits per query or None)."""
+    ix.set_option("multi_query", 0)
+    if radius > 0:
+        for q in queries[:2]:
+            ix.search_radius(q, radius)
+    else:
+        ix.search_topk(queries[:n_settle], k)
+    ix.set_timing(True)
+    ix.reset_stats()
+    t0 = time.perf_counter()
+    hits = None
+    if radius > 0:
+        tot = 0
+        for q in queries:
+            r, _ = ix.search_radius(q, radius)
+            tot += len(r)
+        hits = tot / float(len(queries))
+    else:
+        ix.search_topk(queries, k)
+    el = time.perf_counter() - t0
+    st = ix.stats()
+    ix.set_timing(False)
+    return len(queries) / el, st, hits
+
+
+def side_workload(name, n_queries, devices):
+    """One of the other BASELINE configs on ONE card (the 8-GPU ones at their per-GPU shard size)."""
+    import oracle as orc
+    from syzgydb_amd import ScanIndex
+    from syzgydb_amd.synth import synth_vectors
+    n_rows, dim, bits, metric, k, radius = WORKLOADS[name]
+    rows = SHARD_ROWS.get(name, n_rows)
+    seed = SEED + sorted(WORKLOADS).index(name)
+    t0 = time.time()
+    with ScanIndex(dim, bits, metric, devices=devices) as ix:
+        ix.synth(rows, seed)
+        q = synth_vectors(seed + 1, 0, max(n_queries, 16), dim)
+        hits = None
+        if radius > 0:
+            radius, _ = calibrated_radius(ix, q, radius)
+        qps, st, hits = timed_leg(ix, q[:n_queries], k, radius)
+        rf = roofline_of(st, rows, ix.row_bytes, bits, metric, "collect" if radius > 0 else "topk")
+        out = {
+            "workload": "%s%s: %d x %d, %d-bit, %s, %s, 1 query per sweep" % (
+                name, " (per-GPU shard of %d rows / 8)" % n_rows if name in SHARD_ROWS else "", rows, dim, bits,
+                "cosine" if metric else "euclidean", "radius %.6g" % radius if radius > 0 else "k=%d" % k),
+            "value": round(qps, 1), "unit": "queries/s", "dtype": DTYPE[bits], "roofline": rf,
+            "escalations": int(st["escalations"]), "full_replays": int(st["full_replays"]),
+        }
+        if hits is not None:
+            out["hits_per_query"] = round(hits, 1)
+        # parity on the first rows of the same corpus (a second, small handle): ids and float64 distances
+        nchk = min(rows, 50_000)
+        with ScanIndex(dim, bits, metric, devices=devices) as small:
+            small.synth(nchk, seed)
+            small.set_option("multi_query", 0)
+            ref_rows = small.read_rows(0, nchk)
+            same = 0
+            for i in range(2):
+                if radius > 0:
+                    rr, dd = small.search_radius(q[i], radius + 0.02)  # a few hits on the small corpus too
+                    er, ed, _ = orc.search_exact(ref_rows, dim, bits, metric, q[i], radius=radius + 0.02)
+                else:
+                    rr, dd, cc = small.search_topk(q[i], k)
+                    rr, dd = rr[0, :cc[0]], dd[0, :cc[0]]
+                    er, ed, _ = orc.search_exact(ref_rows, dim, bits, metric, q[i], k=k)
+                same += int(len(rr) == len(er) and (rr == er).all() and (dd == ed).all())
+            out["parity"] = {"rows": nchk, "queries_checked": 2, "identical_to_oracle": same}
+    log("side workload %s: %.1f s, %.0f GB/s" % (name, time.time() - t0, rf["achieved"]))
+    return out
 
 
 def main():
@@ -96,26 +254,39 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS) + ["all"],
+                    help="'all' = the headline plus every other config's roofline (the default at N=1 too)")
+    ap.add_argument("--mode", default="ranks", choices=["ranks", "inproc"],
+                    help="N>1: one process per GPU + RCCL all-gather, or one process driving N devices")
     ap.add_argument("--rows", type=int, default=0, help="override the workload's row count")
-    ap.add_argument("--exchange-every", type=int, default=256,
-                    help="N>1: queries per all-gather micro-batch")
+    ap.add_argument("--exchange-every", type=int, default=0,
+                    help="N>1 ranks: queries per all-gather micro-batch (0 = 256, or steps/4 for short runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--settle-seconds", type=float, default=2.0,
                     help="untimed sweeps before the warm-up steps (clock / TLB settling)")
     ap.add_argument("--no-cpu", action="store_true", help="skip cpu_baseline and the recall check")
+    ap.add_argument("--no-extras", action="store_true", help="skip the batched leg and the other workloads")
     ap.add_argument("--verify", type=int, default=4, help="queries re-checked against the oracle")
     args = ap.parse_args()
+    if args.workload == "all":
+        args.workload, args.no_extras = "headline", False
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and args.mode == "ranks" and env_world is None:
+        spawn_ranks(args.gpus)  # does not return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            log("bench.py: --gpus %d needs torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
-            sys.exit(2)
+    world = int(env_world or "1")
+    if args.mode == "ranks" and world != args.gpus:
+        log("bench.py: --gpus %d but WORLD_SIZE=%d; using the launcher's world size" % (args.gpus, world))
         args.gpus = world
+    inproc = args.mode == "inproc" and args.gpus > 1
+    if inproc and world != 1:
+        log("bench.py: --mode inproc runs in ONE process (WORLD_SIZE=%d)" % world)
+        sys.exit(2)
 
+    import numpy as np
     from syzgydb_amd import ScanIndex
     from syzgydb_amd.synth import synth_vectors
     from syzgydb_amd.sharded import ShardedSearcher, shard_range
@@ -123,21 +294,20 @@ def main():
     n_rows, dim, bits, metric, k, radius = WORKLOADS[args.workload]
     if args.rows:
         n_rows = args.rows
-    if radius > 0:
-        log("bench.py: radius workloads are exercised by tests; timing the top-k form with k=10")
-        k = 10
     seed = SEED + sorted(WORKLOADS).index(args.workload)
+    one_gpu = os.environ.get("SZG_BENCH_ONE_GPU") == "1"  # rehearsal: every shard on device 0
 
     dist = None
     torch = None
     # rehearsal knobs (1-GPU box): SZG_BENCH_BACKEND=gloo exchanges on the CPU,
     # SZG_BENCH_ONE_GPU=1 puts every rank's shard on device 0
     backend = os.environ.get("SZG_BENCH_BACKEND", "nccl")
-    if os.environ.get("SZG_BENCH_ONE_GPU") == "1":
+    if one_gpu:
         local_rank = 0
     # SZG_BENCH_FORCE_DIST=1: take the N>1 code path (process group, all-gather, merge)
     # with a single rank -- lets a 1-GPU box exercise the RCCL plumbing
     dist_path = world > 1 or os.environ.get("SZG_BENCH_FORCE_DIST") == "1"
+    rccl_ranks = None
     if dist_path:
         import torch
         import torch.distributed as dist
@@ -146,52 +316,87 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        # ranks the collective library itself reaches: an all-reduce of ones
+        t = torch.ones(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        rccl_ranks = int(t.item())
     else:
         try:
             import torch  # only for torch.cuda.synchronize() around the timed region
         except Exception:  # pragma: no cover
             torch = None
 
-    lo, hi = shard_range(n_rows, rank, world)
-    ix = ScanIndex(dim, bits, metric, devices=[local_rank])
+    if inproc:
+        devices = [0] * args.gpus if one_gpu else list(range(args.gpus))
+        lo, hi = 0, n_rows
+    else:
+        devices = [local_rank]
+        lo, hi = shard_range(n_rows, rank, world)
+    ix = ScanIndex(dim, bits, metric, devices=devices)
     t0 = time.time()
     ix.synth(hi - lo, seed, first_row=lo)  # corpus generated in HBM, reference encoding rules
     ix.set_row_base(lo)
-    log("[rank %d] corpus rows [%d, %d) x %d B resident in %.2f s" % (rank, lo, hi, ix.row_bytes,
-                                                                     time.time() - t0))
+    log("[rank %d] corpus rows [%d, %d) x %d B resident on device(s) %s in %.2f s" % (
+        rank, lo, hi, ix.row_bytes, devices, time.time() - t0))
     queries = synth_vectors(seed + 1, 0, args.warmup + args.steps, dim)
     qw, qt = queries[: args.warmup], queries[args.warmup:]
-
-    if dist_path:
-        searcher = ShardedSearcher(lambda q, kk: ix.search_topk(q, kk),
-                                   device=torch.device("cuda", local_rank) if backend == "nccl" else None)
-
-        def run(q):
-            r, d, _, _ = searcher.search_stream(q, k, args.exchange_every)
-            return r, d
-    else:
-        def run(q):
-            r, d, _ = ix.search_topk(q, k)
-            return r, d
-
-    def sync():
-        if torch is not None and backend == "nccl" and torch.cuda.is_available():
-            torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
 
     # the headline is one query per sweep (HBM roofline); the shared multi-query
     # sweep is measured separately below and reported under "batched"
     ix.set_option("multi_query", 0)
+    hits_per_query = None
+    if radius > 0:
+        # radius calibrated once on rank 0's shard-independent view: every rank derives it from
+        # the same full-corpus rule when it holds everything, else rank 0 broadcasts it
+        if world == 1:
+            radius, _ = calibrated_radius(ix, qt, radius)
+        else:
+            rad = torch.tensor([radius], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.broadcast(rad, 0)
+            radius = float(rad.item())
+
+    chunk = args.exchange_every or (256 if args.steps >= 1024 else max(16, (args.steps // 4 + 15) // 16 * 16))
+    searcher = None
+    if dist_path:
+        searcher = ShardedSearcher(lambda q, kk: ix.search_topk(q, kk),
+                                   device=torch.device("cuda", local_rank) if backend == "nccl" else None)
+
+    def local_radius(q, rad):
+        return ix.search_radius(q, rad)
+
+    def run(q):
+        if radius > 0:
+            if dist_path:
+                outs = searcher.search_radius_stream(local_radius, q, radius)
+            else:
+                outs = [ix.search_radius(x, radius) for x in q]
+            return [o[0] for o in outs], [o[1] for o in outs]
+        if dist_path:
+            r, d, _, _ = searcher.search_stream(q, k, chunk)
+            return r, d
+        r, d, _ = ix.search_topk(q, k)
+        return r, d
+
+    def sync():
+        if torch is not None and (backend == "nccl" or not dist_path) and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
     # settle the card first (clocks, TLBs, allocator): a fresh process measures 3-5 % low for
     # its first second or two of sweeps.  Untimed, outside the W warm-up steps, same on every rank.
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < args.settle_seconds:
-        ix.search_topk(qt[:64], k)
+        if radius > 0:
+            ix.search_radius(qt[0], radius)
+        else:
+            ix.search_topk(qt[:64], k)
     if args.warmup:
         run(qw)
     ix.set_timing(True)
     ix.reset_stats()
+    if searcher is not None:
+        searcher.reset_timers()
     sync()
     t0 = time.perf_counter()
     res_rows, res_dist = run(qt)  # returns when every result is on the host
@@ -199,86 +404,140 @@ def main():
     elapsed = time.perf_counter() - t0
     stats = ix.stats()
     ix.set_timing(False)
+    if radius > 0:
+        hits_per_query = float(np.mean([len(r) for r in res_rows]))
+    my_elapsed = elapsed
+    per_rank = None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = roofline_of(stats, hi - lo, ix.row_bytes, bits, metric, "")
+        row = {"rank": rank, "device": devices[0], "rows": hi - lo, "elapsed_s": round(my_elapsed, 6),
+               "scan_GBps": mine["achieved"], "avg_launch_ms": mine["avg_launch_ms"],
+               "host_us_per_query": round((stats["host_prep_us"] + stats["host_finish_us"]) / max(args.steps, 1) +
+                                          1e6 * searcher.exchange_host_s / max(args.steps, 1), 2),
+               "exchange_ms_per_batch": round(1e3 * searcher.exchange_s / max(searcher.exchanges, 1), 3)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, row)
 
     out = None
     if rank == 0:
         qps = args.steps / elapsed
-        scan_ms = stats["scan_ms"] / max(stats["timed_launches"], 1)
-        bytes_per_launch = stats["scan_bytes"] / max(stats["scan_launches"], 1)
-        achieved = bytes_per_launch / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-        sweeps_per_launch = bytes_per_launch / float(max((hi - lo) * ix.row_bytes, 1))
+        rf = roofline_of(stats, hi - lo if not inproc else (n_rows + args.gpus - 1) // args.gpus, ix.row_bytes,
+                         bits, metric, "collect" if radius > 0 else "topk")
+        n_dev = args.gpus
+        if world == 1 and not inproc:
+            rf["traffic"], src = recorded_traffic(args.workload, args.rows, rf["sweeps_per_launch"])
+            if src:
+                rf["traffic_source"] = src
+        host_us = (stats["host_prep_us"] + stats["host_finish_us"]) / max(args.steps, 1)
+        if searcher is not None:
+            host_us += 1e6 * searcher.exchange_host_s / max(args.steps, 1)
         out = {
             "metric": "queries/sec, exact scan 1M x 768 cosine k=10" if args.workload == "headline"
             else "queries/sec, exact scan (%s)" % args.workload,
             "value": round(qps, 2),
             "unit": "queries/s",
-            "n_gpus": world,
+            "n_gpus": n_dev,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 5),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": {4: "u4", 8: "u8", 16: "u16", 32: "f32", 64: "f64"}[bits],
+            "dtype": DTYPE[bits],
             "data": "synthetic",
             "config": {
-                "workload": "%s: %d x %d, %d-bit, %s, k=%d, 1 query per sweep" % (
-                    args.workload, n_rows, dim, bits, "cosine" if metric else "euclidean", k),
+                "workload": "%s: %d x %d, %d-bit, %s, %s, 1 query per sweep" % (
+                    args.workload, n_rows, dim, bits, "cosine" if metric else "euclidean",
+                    "radius %.6g" % radius if radius > 0 else "k=%d" % k),
                 "rows": n_rows, "dim": dim, "quantization": bits,
                 "distance": "cosine" if metric else "euclidean", "k": k,
+                "radius": radius if radius > 0 else None,
                 "queries_per_sweep": 1,
+                "mode": "inproc" if inproc else ("ranks" if dist_path else "single"),
                 "parallelism": "rows sharded over %d GPU(s)%s" % (
-                    world, ", 1 all-gather per %d queries" % args.exchange_every if world > 1 else ""),
+                    n_dev, (", one handle with %d device shards in one process" % n_dev) if inproc else
+                    (", one process per GPU, 1 %s all-gather per %d queries" % (
+                        "RCCL" if backend == "nccl" else backend, chunk) if dist_path else "")),
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic_for(args.workload, args.rows, sweeps_per_launch) if world == 1 else None,
-                "kernel": "szg::scan_kernel<%d,%d,...>" % (bits, metric),
-                "bytes_per_launch": int(bytes_per_launch),
-                "sweeps_per_launch": round(sweeps_per_launch, 2),
-                "avg_launch_ms": round(scan_ms, 5),
-                "launches": int(stats["timed_launches"]),
-            },
+            "roofline": rf,
+            "host_us_per_query": round(host_us, 2),
+            "host_us_breakdown": {"prepare_enqueue": round(stats["host_prep_us"] / max(args.steps, 1), 2),
+                                  "assemble": round(stats["host_finish_us"] / max(args.steps, 1), 2),
+                                  "exchange_pack_merge": round(1e6 * searcher.exchange_host_s / max(args.steps, 1), 2)
+                                  if searcher is not None else 0.0},
             "escalations": int(stats["escalations"]),
             "full_replays": int(stats["full_replays"]),
         }
+        if hits_per_query is not None:
+            out["hits_per_query"] = round(hits_per_query, 1)
+        if dist_path:
+            out["rccl_ranks"] = rccl_ranks if backend == "nccl" else 0
+            out["exchange_backend"] = backend
+            out["ranks"] = per_rank
+        if inproc:
+            out["roofline"]["note"] = "per device shard; the N shards sweep concurrently"
+
+    # ---- N>1 parity: the oracle on every rank's own rows, merged on rank 0 -------------
+    if dist_path and not args.no_cpu and radius == 0 and args.verify > 0:
+        import oracle as orc
+        orc.build()
+        nv = min(2, args.verify, len(qt))
+        local = ix.read_rows(0, hi - lo)
+        mine = []
+        for i in range(nv):
+            er, ed, _ = orc.search_exact(local, dim, bits, metric, qt[i], k=k)
+            mine.append(((np.asarray(er, dtype=np.uint64) + np.uint64(lo)).tolist(), [float(x) for x in ed]))
+        del local
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        if rank == 0:
+            same = 0
+            for i in range(nv):
+                pairs = sorted((d, r) for part in everyone for r, d in zip(part[i][0], part[i][1]))[:k]
+                same += int([int(r) for _, r in pairs] == [int(x) for x in res_rows[i]] and
+                            [d for d, _ in pairs] == [float(x) for x in res_dist[i]])
+            out["parity"] = {"queries_checked": nv, "ids_identical": same,
+                             "recall_at_k": 1.0 if same == nv else None,
+                             "how": "oracle top-k of every rank's own rows, merged by (distance, row) on rank 0"}
+            if same != nv:
+                log("bench.py: PARITY FAILURE: merged GPU result differs from the oracle's")
 
     # ---- shared multi-query sweep (MFMA), 32-bit cosine only, N=1 -----------------
-    if world == 1 and bits == 32 and metric == 1 and args.steps >= 64:
+    if world == 1 and not inproc and bits == 32 and metric == 1 and radius == 0 and not args.no_extras:
+        qb = synth_vectors(seed + 2, 0, 1024, dim)  # its own fixed set, whatever --steps is
         ix.set_option("multi_query", 1)
         # untimed warm-up with the same call: the first full-size shared-sweep call after
         # allocation runs ~1.7x slower (buffer first use); steady state is what is reported
-        ix.search_topk(qt, k)
+        ix.search_topk(qb, k)
         t0 = time.perf_counter()
-        b_rows, _, _ = ix.search_topk(qt, k)          # throughput: no per-kernel events
+        b_rows, _, _ = ix.search_topk(qb, k)          # throughput: no per-kernel events
         b_elapsed = time.perf_counter() - t0
         ix.set_timing(True)
         ix.reset_stats()
-        ix.search_topk(qt, k)                         # same call again with HIP events: per-sweep time
+        ix.search_topk(qb, k)                         # same call again with HIP events: per-sweep time
         bst = ix.stats()
         ix.set_timing(False)
         ix.set_option("multi_query", 0)
+        s_rows, _, _ = ix.search_topk(qb[:64], k)     # the single-query path on the same queries
         sweep_ms = bst["scan_ms"] / max(bst["timed_launches"], 1)
-        qps_b = args.steps / b_elapsed
         per_sweep = bst["mq_queries"] / max(bst["mq_launches"], 1)
         flops = 2.0 * n_rows * dim * per_sweep
+        tf = flops / (sweep_ms * 1e-3) / 1e12
         out["batched"] = {
+            "queries": 1024,
             "queries_per_sweep": round(per_sweep, 2),
-            "value": round(qps_b, 1), "unit": "queries/s",
+            "value": round(1024 / b_elapsed, 1), "unit": "queries/s",
             "kernel": "szg::mq_score_kernel<3,32,cosine,collect> (v_mfma_f32_16x16x4_f32)",
             "avg_sweep_ms": round(sweep_ms, 5),
             "hbm_GBps": round(n_rows * ix.row_bytes / (sweep_ms * 1e-3) / 1e9, 1),
-            "mfma_TFLOPs": round(flops / (sweep_ms * 1e-3) / 1e12, 2),
-            "mfma_peak_TFLOPs": 157.3,
-            "ids_identical_to_single_query_path": bool((b_rows == res_rows).all()),
+            "mfma_TFLOPs": round(tf, 2),
+            "mfma_peak_TFLOPs": MFMA_F32_PEAK_TF,
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None},
+            "ids_identical_to_single_query_path": bool((b_rows[:64] == s_rows).all()),
         }
 
     # ---- recall / parity spot check + CPU baseline (rank 0, N=1) -----------------
@@ -286,37 +545,39 @@ def main():
         import oracle as orc
         orc.build()
         cores = host_cores()
-        t0 = time.time()
         sample_rows = min(n_rows, 100_000)
         rows_host = ix.read_rows(0, sample_rows)  # the same bytes the GPU scans
-        # single-thread rate first, to size the all-core sample
-        secs1, _ = orc.bench_topk(rows_host, dim, bits, metric, qt[:1], k, 1)
-        per_query = max(secs1, 1e-6)
-        nq = int(max(cores, min(len(qt), cores * args.cpu_seconds / per_query)))
-        nq = min(nq, len(qt))
-        secs, cpu_rows = orc.bench_topk(rows_host, dim, bits, metric, qt[:nq], k, cores)
-        scale = sample_rows / float(n_rows)
-        out["cpu_baseline"] = {
-            "value": round(nq / secs * scale, 3),
-            "unit": "queries/s",
-            "cores": cores,
-            "kind": "port",
-            "sample": "%d queries x first %d of %d rows on %d threads (%.1f s), scaled linearly to "
-                      "%d rows; C port of the reference's Go scan (no Go toolchain here)" % (
-                          nq, sample_rows, n_rows, cores, secs, n_rows),
-            "single_thread": round(1.0 / per_query * scale, 4),
-        }
-        # the reference also CRCs and re-parses each record's span and allocates a decode
-        # buffer on every visit (spanfile.go:757, collection.go:769): one query with that
-        # per-record work included, single thread, on a smaller sample
-        fs_rows = min(sample_rows, 20_000)
-        fsecs, frows = orc.bench_topk_faithful(rows_host[:fs_rows], dim, bits, metric, qt[:1], k)
-        out["cpu_baseline"]["single_thread_with_span_crc_parse_alloc"] = round(
-            1.0 / fsecs * (fs_rows / float(n_rows)), 4)
-        log("cpu_baseline leg: %.1f s" % (time.time() - t0))
+        if not inproc:
+            t0 = time.time()
+            kk = k if radius == 0 else 10
+            # single-thread rate first, to size the all-core sample
+            secs1, _ = orc.bench_topk(rows_host, dim, bits, metric, qt[:1], kk, 1)
+            per_query = max(secs1, 1e-6)
+            nq = int(max(cores, min(len(qt), cores * args.cpu_seconds / per_query)))
+            nq = min(nq, len(qt))
+            secs, cpu_rows = orc.bench_topk(rows_host, dim, bits, metric, qt[:nq], kk, cores)
+            scale = sample_rows / float(n_rows)
+            out["cpu_baseline"] = {
+                "value": round(nq / secs * scale, 3),
+                "unit": "queries/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": "%d queries x first %d of %d rows on %d threads (%.1f s), scaled linearly to "
+                          "%d rows; C port of the reference's Go scan (no Go toolchain here)" % (
+                              nq, sample_rows, n_rows, cores, secs, n_rows),
+                "single_thread": round(1.0 / per_query * scale, 4),
+            }
+            # the reference also CRCs and re-parses each record's span and allocates a decode
+            # buffer on every visit (spanfile.go:757, collection.go:769): one query with that
+            # per-record work included, single thread, on a smaller sample
+            fs_rows = min(sample_rows, 20_000)
+            fsecs, frows = orc.bench_topk_faithful(rows_host[:fs_rows], dim, bits, metric, qt[:1], kk)
+            out["cpu_baseline"]["single_thread_with_span_crc_parse_alloc"] = round(
+                1.0 / fsecs * (fs_rows / float(n_rows)), 4)
+            log("cpu_baseline leg: %.1f s" % (time.time() - t0))
         # parity on the FULL corpus for a few queries: ids identical, distances bit-equal
         nv = min(args.verify, len(qt))
-        if nv > 0:
+        if nv > 0 and radius == 0 and n_rows <= 2_000_000:
             t0 = time.time()
             rows_all = rows_host if sample_rows == n_rows else ix.read_rows(0, n_rows)
             _, ref_rows = orc.bench_topk(rows_all, dim, bits, metric, qt[:nv], k, min(cores, nv))
@@ -329,10 +590,22 @@ def main():
                 log("bench.py: PARITY FAILURE: GPU ids differ from the oracle's")
                 emit(out)
                 sys.exit(1)
+    ix.close()
+
+    # ---- the other BASELINE configs, one roofline object each (N=1) ----------------
+    if rank == 0 and world == 1 and not inproc and not args.no_extras and not args.rows:
+        extras = {}
+        for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
+            if name == args.workload:
+                continue
+            try:
+                extras[name] = side_workload(name, 48 if name != "cfg5" else 24, devices)
+            except Exception as e:  # a side leg never takes the headline line down with it
+                extras[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["other_workloads"] = extras
 
     if rank == 0:
         emit(out)
-    ix.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SZG_ABI_VERSION 1
+#define SZG_ABI_VERSION 2
 
 /* DistanceMethod, collection.go:186-189 */
 #define SZG_EUCLIDEAN 0
@@ -161,6 +161,12 @@ int szg_pair_distances(szg_index *ix, const uint64_t *rows_a, const uint64_t *ro
 int szg_merge_topk(int k, int n_lists, int list_len, int n_queries, const uint64_t *rows,
                    const double *dist, const int32_t *counts, uint64_t *out_rows,
                    double *out_dist, int32_t *out_count, uint8_t *out_history_dependent);
+/* The same merge straight from the exchanged buffer, no repacking on the caller's side:
+ * records[n_lists][n_queries][2*list_len + 1] int64 = list_len rows | list_len float64 bit
+ * patterns | count, i.e. what each rank contributes to the all-gather. */
+int szg_merge_topk_records(int k, int n_lists, int list_len, int n_queries, const int64_t *records,
+                           uint64_t *out_rows, double *out_dist, int32_t *out_count,
+                           uint8_t *out_history_dependent);
 
 /* ---- diagnostics -------------------------------------------------------- */
 
@@ -182,6 +188,10 @@ typedef struct szg_stats {
     uint64_t mq_launches;      /* shared (multi-query) sweeps; each is also one scan launch */
     uint64_t mq_queries;       /* queries answered through shared sweeps */
     uint64_t mq_fallbacks;     /* shared-sweep batches redone through the score matrix (candidate buffer overflow) */
+    /* host CPU time of szg_search_topk outside any wait for the device (always measured):
+     * query preparation + enqueueing, and result assembly (gather, certification, heap replay) */
+    double host_prep_us;
+    double host_finish_us;
 } szg_stats;
 
 /* Per-kernel HIP-event timing on the library's own streams (off by default). */

@@ -30,7 +30,7 @@ EXPORTS = [
     "szg_index_live_rows", "szg_index_read_rows", "szg_search_topk", "szg_search_radius",
     "szg_strerror", "szg_last_error", "szg_abi_version", "szg_set_timing", "szg_get_stats",
     "szg_reset_stats", "szg_set_option", "szg_index_synth", "szg_index_set_row_base",
-    "szg_merge_topk", "szg_index_append_f64", "szg_distances", "szg_pair_distances", "szg_index_overwrite_f64",
+    "szg_merge_topk", "szg_merge_topk_records", "szg_index_append_f64", "szg_distances", "szg_pair_distances", "szg_index_overwrite_f64",
 ]
 # include/syzgy_pager.h
 PAGER_EXPORTS = [
@@ -54,6 +54,8 @@ class SzgStats(ctypes.Structure):
         ("mq_launches", ctypes.c_uint64),
         ("mq_queries", ctypes.c_uint64),
         ("mq_fallbacks", ctypes.c_uint64),
+        ("host_prep_us", ctypes.c_double),
+        ("host_finish_us", ctypes.c_double),
     ]
 
 
@@ -133,6 +135,9 @@ def load():
     L.szg_merge_topk.restype = ctypes.c_int
     L.szg_merge_topk.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, u64p, f64p,
                                  i32p, u64p, f64p, i32p, u8p]
+    L.szg_merge_topk_records.restype = ctypes.c_int
+    L.szg_merge_topk_records.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_int64), u64p, f64p, i32p, u8p]
     L.szg_index_append_f64.restype = ctypes.c_int
     L.szg_index_append_f64.argtypes = [vp, f64p, ctypes.c_uint64]
     L.szg_index_overwrite_f64.restype = ctypes.c_int

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -22,6 +23,7 @@
 #include <cstring>
 #include <deque>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -47,6 +49,14 @@ int fail(int code, const char *what, hipError_t e = hipSuccess)
         hipError_t e__ = (expr);                                        \
         if (e__ != hipSuccess) return fail(SZG_E_DEVICE, #expr, e__);   \
     } while (0)
+
+// No exception crosses the C boundary: std::vector / std::string growth inside an entry point
+// becomes SZG_E_NOMEM.
+#define SZG_TRY try {
+#define SZG_CATCH                                                          \
+    }                                                                      \
+    catch (const std::bad_alloc &) { return fail(SZG_E_NOMEM, "out of memory (host)"); } \
+    catch (...) { return fail(SZG_E_DEVICE, "unexpected exception"); }
 
 int64_t row_bytes_of(int bits, int dim)
 {   // getVectorSize, collection.go:796-811
@@ -188,6 +198,14 @@ struct Ctx {
     bool mq_has_allow = false;
     bool timed_scan = false;
     int timed_n = 0;               // scan launches between ev_scan0 and ev_scan1
+    // the first k eligible rows of each staged query in visit order (those consider() pushes
+    // whatever their distance, collection.go:608) and their float64 distances: a NaN there
+    // poisons the reference's heap, so the query takes the exact replay
+    uint64_t *h_sent = nullptr, *d_sent = nullptr;
+    size_t h_sent_cap = 0, d_sent_cap = 0;
+    szg::RerankOut *h_sent_out = nullptr, *d_sent_out = nullptr;
+    size_t h_sent_out_cap = 0, d_sent_out_cap = 0;
+    int sent_n = 0;                // entries per query (0 = none staged)
     QMeta meta[kMaxBatch];         // constants of the staged queries
 };
 
@@ -200,6 +218,7 @@ struct Shard {
     uint8_t *rows = nullptr;
     uint64_t *live_bits = nullptr;
     uint64_t bits_cap = 0;     // words
+    std::vector<uint64_t> live_host;  // host copy of live_bits (tombstone / append bookkeeping, first-k rows)
     bool has_dead = false;
     int cu_count = 256;
     std::vector<Ctx *> free_ctx;
@@ -499,6 +518,10 @@ void ctx_free(Ctx *c)
     (void)hipFree(c->d_cand_count);
     (void)hipHostFree(c->h_cand_count);
     (void)hipFree(c->d_keys);
+    (void)hipHostFree(c->h_sent);
+    (void)hipFree(c->d_sent);
+    (void)hipHostFree(c->h_sent_out);
+    (void)hipFree(c->d_sent_out);
     delete c;
 }
 
@@ -526,6 +549,12 @@ void ctx_release(Shard *sh, Ctx *c)
     }
     sh->cv.notify_one();
 }
+
+struct CtxGuard {  // returns a borrowed context on every exit path
+    Shard *sh;
+    Ctx *c;
+    ~CtxGuard() { ctx_release(sh, c); }
+};
 
 template <typename T>
 int ensure_dev(T **p, size_t *cap, size_t need)
@@ -1185,6 +1214,81 @@ int run_full_replay(szg_index *ix, std::vector<Ctx *> &ctx, int slot, const uint
     return SZG_OK;
 }
 
+// The first k eligible rows of a query in visit order are pushed by consider() whatever their
+// distance (collection.go:608, `len < K`); a NaN among them -- an antipodal or parallel row
+// under the unclamped acos (:831), a NaN / Inf element -- sits in the reference's heap and
+// decides what is accepted afterwards.  Such a row need not be anywhere near the best keys,
+// so the scan's candidates do not show it: the exact distances of these k rows are computed
+// beside every batch and a NaN sends the query to the exact replay.
+// rows_out: index-level rows, ascending; at most k.
+void first_eligible_rows(const szg_index *ix, const uint64_t *allow, int k, std::vector<uint64_t> *rows_out)
+{
+    rows_out->clear();
+    for (const Shard *sh : ix->shards) {
+        if ((int)rows_out->size() >= k) break;
+        if (sh->n_rows == 0) continue;
+        if (!allow && !sh->has_dead) {
+            for (uint64_t r = 0; r < sh->n_rows && (int)rows_out->size() < k; r++) rows_out->push_back(sh->first + r);
+            continue;
+        }
+        const uint64_t words = (sh->n_rows + 63) / 64;
+        const uint64_t *aw = allow ? allow + sh->first / 64 : nullptr;
+        for (uint64_t w = 0; w < words && (int)rows_out->size() < k; w++) {
+            uint64_t m = sh->live_host[w];
+            if (aw) m &= aw[w];
+            const uint64_t left = sh->n_rows - w * 64;
+            if (left < 64) m &= (1ull << left) - 1ull;
+            while (m && (int)rows_out->size() < k) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                rows_out->push_back(sh->first + w * 64 + (uint64_t)b);
+            }
+        }
+    }
+}
+
+// Stage the sentinel rows of the batch that fall into this shard and enqueue their float64
+// distances on the ctx stream (lists: one vector of index-level rows per staged query).
+int enqueue_sentinels(szg_index *ix, Shard *sh, Ctx *c, const std::vector<std::vector<uint64_t>> &lists, int nq)
+{
+    c->sent_n = 0;
+    size_t most = 0;
+    for (int j = 0; j < nq; j++) {
+        size_t n = 0;
+        for (uint64_t r : lists[j]) n += (r >= sh->first && r < sh->first + sh->n_rows) ? 1 : 0;
+        most = std::max(most, n);
+    }
+    if (most == 0) return SZG_OK;
+    HIPCHK(hipSetDevice(sh->device));
+    const size_t total = most * (size_t)nq;
+    int rc = ensure_host(&c->h_sent, &c->h_sent_cap, total);
+    if (rc) return rc;
+    rc = ensure_dev(&c->d_sent, &c->d_sent_cap, total);
+    if (rc) return rc;
+    rc = ensure_host(&c->h_sent_out, &c->h_sent_out_cap, total);
+    if (rc) return rc;
+    rc = ensure_dev(&c->d_sent_out, &c->d_sent_out_cap, total);
+    if (rc) return rc;
+    for (int j = 0; j < nq; j++) {
+        size_t n = 0;
+        for (uint64_t r : lists[j])
+            if (r >= sh->first && r < sh->first + sh->n_rows) c->h_sent[(size_t)j * most + n++] = r - sh->first;
+        for (; n < most; n++) c->h_sent[(size_t)j * most + n] = szg::kInvalidCand;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_sent, c->h_sent, total * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, c->d_sent, nullptr,
+                              (uint32_t)most, nq, c->d_sent_out, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_sent_out, c->d_sent_out, total * sizeof(szg::RerankOut), hipMemcpyDeviceToHost,
+                          c->stream));
+    c->sent_n = (int)most;
+    return SZG_OK;
+}
+
+double now_us()
+{
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 struct Ticket {
     int first = 0, nq = 0;       // queries [first, first+nq) of the call
     std::vector<Ctx *> ctx;      // one per shard
@@ -1192,6 +1296,24 @@ struct Ticket {
     int kp = 0;
     bool failed = false;         // enqueueing failed part-way: drain and release only
     bool any_mask = false;       // some query of the batch carries a filter mask
+    szg_index *owner = nullptr;
+    Ticket() = default;
+    Ticket(Ticket &&) = default;
+    Ticket(const Ticket &) = delete;
+    Ticket &operator=(const Ticket &) = delete;
+    // a ticket dropped with contexts still attached (an exception unwinding the call) drains
+    // and returns them, so later calls do not wait for contexts that never come back
+    ~Ticket()
+    {
+        if (!owner) return;
+        for (size_t s = 0; s < ctx.size(); s++) {
+            if (!ctx[s]) continue;
+            (void)hipSetDevice(owner->shards[s]->device);
+            (void)hipStreamSynchronize(ctx[s]->stream);
+            ctx[s]->mq_fused_used = false;
+            ctx_release(owner->shards[s], ctx[s]);
+        }
+    }
 };
 
 // allow_bits: n_queries masks back to back, or nullptr; allow_ptrs (used instead when given):
@@ -1208,13 +1330,18 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
         if (allow_ptrs) return allow_ptrs[qi];
         return allow_bits ? allow_bits + (size_t)qi * allow_stride : nullptr;
     };
-    const int kp = k + std::max(ix->slack_min, k / 2);
+    int kp = k + std::max(ix->slack_min, k / 2);
+    // The reference bounds K by nothing (collection.go:606-619).  The fused selection keeps kp
+    // candidates per wave in LDS; beyond that (kp > 4096 or 64 KiB of lists) every query of the
+    // call takes the exact replay: float64 distances of all rows
+    // on the device, consider() over them on the host.
+    bool replay_all = false;
     for (Shard *s : ix->shards) {
-        if (s->n_rows == 0) continue;
+        if (s->n_rows == 0 || replay_all) continue;
         const LaunchGeom g = scan_geometry(ix, s, kp);
-        if (szg::scan_lds_bytes(ix->bits, ix->map, kp, g.block) > 64u * 1024u || kp > 4096)
-            return fail(SZG_E_UNSUPPORTED, "k too large for the fused selection (LDS)");
+        if (szg::scan_lds_bytes(ix->bits, ix->map, kp, g.block) > 64u * 1024u || kp > 4096) replay_all = true;
     }
+    if (replay_all) kp = 1;  // the batches only stage their queries
 
     // result assembly for one finished batch
     auto finish = [&](Ticket &t) -> int {
@@ -1260,11 +1387,14 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 }
             }
         }
+        const double t_fin0 = now_us();
+        double t_dev = 0;  // time spent waiting on escalation / replay passes (device work)
         // gather every query's candidates first: the escalation and replay paths
         // below reuse the contexts' output buffers
         std::vector<std::vector<Cand>> all(t.nq);
         std::vector<double> thr_min(t.nq, INFINITY);
-        if (rc == SZG_OK) {
+        std::vector<uint8_t> nan_first(t.nq, 0);  // a NaN distance among the query's first k eligible rows
+        if (rc == SZG_OK && !replay_all) {
             for (int j = 0; j < t.nq; j++) {
                 for (size_t s = 0; s < n_sh; s++) {
                     Shard *sh = ix->shards[s];
@@ -1272,6 +1402,11 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                     double thr;
                     gather_topk(sh, t.ctx[s], t.kp, j, &all[j], &thr);
                     thr_min[j] = std::min(thr_min[j], thr);
+                    const Ctx *c = t.ctx[s];
+                    for (int i = 0; i < c->sent_n; i++) {
+                        const szg::RerankOut &r = c->h_sent_out[(size_t)j * c->sent_n + i];
+                        if (r.row != 0xFFFFFFFFu && std::isnan(r.dist)) nan_first[j] = 1;
+                    }
                 }
             }
         }
@@ -1280,6 +1415,15 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
             const uint64_t *allow = mask_of(qi);
             std::vector<Cand> &cands = all[j];
             std::vector<HeapItem> res;
+            if (replay_all) {
+                const double td = now_us();
+                rc = run_full_replay(ix, t.ctx, j, allow, k, &res);
+                t_dev += now_us() - td;
+                if (rc == SZG_OK) {
+                    std::lock_guard<std::mutex> lk(ix->stats_mu);
+                    ix->stats.full_replays++;
+                }
+            } else {
             replay_topk(cands, k, &res);
             // certification: every row outside the lists has scan key >= thr_min, so
             // the result is final once its worst key clears thr_min by the error bound
@@ -1300,6 +1444,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 certified = (int)res.size() == k && lhs < thr_min[j];
             }
             if (ix->force_escalate && std::isfinite(thr_min[j])) certified = false;
+            if (nan_first[j] && ix->tie_mode == 0) certified = true;  // answered by the replay below
             if (!certified) {
                 {
                     std::lock_guard<std::mutex> lk(ix->stats_mu);
@@ -1318,23 +1463,28 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 }
                 const float thr_f = thr >= 3.0e38 ? 3.0e38f : std::nextafter((float)thr, INFINITY);
                 cands.clear();
+                const double td = now_us();
                 for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
                     Shard *sh = ix->shards[s];
                     if (sh->n_rows == 0) continue;
                     rc = run_collect(ix, sh, t.ctx[s], j, thr_f, t.any_mask, &cands);
                 }
+                t_dev += now_us() - td;
                 if (rc == SZG_OK) replay_topk(cands, k, &res);
             }
             if (rc == SZG_OK && ix->tie_mode == 0) {
                 std::vector<double> d(cands.size());
                 for (size_t i = 0; i < cands.size(); i++) d[i] = cands[i].dist;
-                if (history_dependent(d.data(), d.size(), k)) {
+                if (nan_first[j] || history_dependent(d.data(), d.size(), k)) {
                     {
                         std::lock_guard<std::mutex> lk(ix->stats_mu);
                         ix->stats.full_replays++;
                     }
+                    const double td = now_us();
                     rc = run_full_replay(ix, t.ctx, j, allow, k, &res);
+                    t_dev += now_us() - td;
                 }
+            }
             }
             if (rc) break;
             for (int i = 0; i < k; i++) {
@@ -1343,6 +1493,10 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 out_dist[(size_t)qi * k + i] = have ? res[i].priority : 0.0;
             }
             if (out_count) out_count[qi] = (int32_t)res.size();
+        }
+        {
+            std::lock_guard<std::mutex> lk(ix->stats_mu);
+            ix->stats.host_finish_us += now_us() - t_fin0 - t_dev;
         }
         for (size_t s = 0; s < n_sh; s++)
             if (t.ctx[s]) ctx_release(ix->shards[s], t.ctx[s]);
@@ -1359,10 +1513,11 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
     const int B1 = std::max(1, std::min(ix->query_batch, kMaxBatch));
     for (int q0 = 0; q0 < n_queries && rc == SZG_OK;) {
         Ticket t;
+        t.owner = ix;
         t.first = q0;
         // batches of up to 32 share one sweep when the multi-query path applies
         const int left = n_queries - q0;
-        const int nb = mq_blocks(ix, std::min(left, 16 * ix->mq_blocks_max));
+        const int nb = replay_all ? 0 : mq_blocks(ix, std::min(left, 16 * ix->mq_blocks_max));
         t.nq = nb ? std::min(left, 16 * nb) : std::min(B1, left);
         t.kp = kp;
         t.ctx.assign(n_sh, nullptr);
@@ -1381,6 +1536,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
         if (!got) {
             for (size_t s = 0; s < n_sh; s++)
                 if (t.ctx[s]) ctx_release(ix->shards[s], t.ctx[s]);
+            t.ctx.assign(n_sh, nullptr);
             rc = finish(inflight.front());
             inflight.pop_front();
             continue;
@@ -1392,28 +1548,62 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
             t.any_mask |= masks[j] != nullptr;
         }
         const uint64_t *const *mptr = t.any_mask ? masks.data() : nullptr;
+        const double t_prep0 = now_us();
+        // the batch is prepared ONCE (swizzled / digit-plane forms, constants) into the first
+        // shard's staging buffers; the other shards get copies
+        Ctx *c0 = nullptr;
+        const bool int4_planes = nb > 0 && mq_uses_i8(ix) && ix->bits == 4;
+        for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
+            if (ix->shards[s]->n_rows == 0) continue;
+            Ctx *cx = t.ctx[s];
+            if (int4_planes && !cx->h_mqQ) {
+                cx->h_mqQ = (int32_t *)malloc(sizeof(int32_t) * (size_t)kMaxBatch * ix->dim);
+                if (!cx->h_mqQ) {
+                    rc = fail(SZG_E_NOMEM, "host scratch");  // the ticket is still finished below
+                    break;
+                }
+            }
+            if (!c0) {
+                c0 = cx;
+                for (int j = 0; j < t.nq; j++) {
+                    prep_query(ix, q + (size_t)j * ix->dim, cx->h_qsw + (size_t)j * ix->qsw_bytes, &t.meta[j]);
+                    t.meta[j].mq = nb > 0 && !mq_uses_i8(ix);  // the integer sweeps keep the integer bound
+                    if (int4_planes)
+                        prep_mq_int4(ix, q + (size_t)j * ix->dim, &t.meta[j], cx->h_mqQ + (size_t)j * ix->dim);
+                    cx->meta[j] = t.meta[j];
+                }
+            } else {
+                memcpy(cx->h_qsw, c0->h_qsw, ix->qsw_bytes * (size_t)t.nq);
+                if (int4_planes) memcpy(cx->h_mqQ, c0->h_mqQ, sizeof(int32_t) * (size_t)t.nq * ix->dim);
+                for (int j = 0; j < t.nq; j++) cx->meta[j] = t.meta[j];
+            }
+        }
+        // rows consider() pushes unconditionally: the first k eligible ones per query
+        std::vector<std::vector<uint64_t>> sent;
+        if (rc == SZG_OK && ix->tie_mode == 0 && !replay_all) {
+            sent.resize(t.nq);
+            for (int j = 0; j < t.nq; j++) {
+                if (j > 0 && !masks[j] && !masks[j - 1]) sent[j] = sent[j - 1];
+                else first_eligible_rows(ix, masks[j], k, &sent[j]);
+            }
+        }
         for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
             Shard *sh = ix->shards[s];
             if (sh->n_rows == 0) continue;
-            for (int j = 0; j < t.nq; j++) {
-                prep_query(ix, q + (size_t)j * ix->dim, t.ctx[s]->h_qsw + (size_t)j * ix->qsw_bytes,
-                           &t.meta[j]);
-                t.meta[j].mq = nb > 0 && !mq_uses_i8(ix);  // the integer sweeps keep the integer bound
-                if (nb > 0 && mq_uses_i8(ix) && ix->bits == 4) {
-                    Ctx *cx = t.ctx[s];
-                    if (!cx->h_mqQ) cx->h_mqQ = (int32_t *)malloc(sizeof(int32_t) * (size_t)kMaxBatch * ix->dim);
-                    if (!cx->h_mqQ) {
-                        rc = fail(SZG_E_NOMEM, "host scratch");  // the ticket is still finished below
-                        break;
-                    }
-                    prep_mq_int4(ix, q + (size_t)j * ix->dim, &t.meta[j], cx->h_mqQ + (size_t)j * ix->dim);
-                }
-                t.ctx[s]->meta[j] = t.meta[j];
-            }
-            if (rc == SZG_OK) rc = enqueue_queries(ix, sh, t.ctx[s], q, t.nq, mptr);
-            if (rc == SZG_OK)
+            t.ctx[s]->sent_n = 0;
+            rc = enqueue_queries(ix, sh, t.ctx[s], q, t.nq, mptr);
+            if (rc == SZG_OK && !replay_all)
                 rc = nb ? enqueue_topk_mq(ix, sh, t.ctx[s], kp, t.nq, nb, t.any_mask)
                         : enqueue_topk(ix, sh, t.ctx[s], kp, t.nq, t.any_mask);
+            if (rc == SZG_OK && !sent.empty()) rc = enqueue_sentinels(ix, sh, t.ctx[s], sent, t.nq);
+            if (rc == SZG_OK && replay_all && ix->timing) {
+                const hipError_t e = hipEventRecord(t.ctx[s]->ev_all1, t.ctx[s]->stream);
+                if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "hipEventRecord", e);
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(ix->stats_mu);
+            ix->stats.host_prep_us += now_us() - t_prep0;
         }
         t.failed = rc != SZG_OK;  // nothing to gather: finish() only drains and releases
         inflight.push_back(std::move(t));
@@ -1460,9 +1650,14 @@ int shard_reserve(szg_index *ix, Shard *sh, uint64_t rows_needed)
         uint8_t *nr = nullptr;
         hipError_t e = hipMalloc((void **)&nr, szg::layout_bytes(ix->layout, cap) + 64);
         if (e != hipSuccess) return fail(SZG_E_NOMEM, "hipMalloc(corpus)", e);
-        if (sh->rows && sh->n_rows)
-            HIPCHK(hipMemcpy(nr, sh->rows, szg::layout_bytes(ix->layout, sh->n_rows), hipMemcpyDeviceToDevice));
-        if (sh->rows) HIPCHK(hipFree(sh->rows));
+        if (sh->rows && sh->n_rows) {
+            e = hipMemcpy(nr, sh->rows, szg::layout_bytes(ix->layout, sh->n_rows), hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(nr);
+                return fail(SZG_E_DEVICE, "hipMemcpy(corpus)", e);
+            }
+        }
+        if (sh->rows) (void)hipFree(sh->rows);
         sh->rows = nr;
         sh->cap_rows = cap;
     }
@@ -1471,35 +1666,38 @@ int shard_reserve(szg_index *ix, Shard *sh, uint64_t rows_needed)
         uint64_t *nb = nullptr;
         hipError_t e = hipMalloc((void **)&nb, words * sizeof(uint64_t));
         if (e != hipSuccess) return fail(SZG_E_NOMEM, "hipMalloc(live bits)", e);
-        HIPCHK(hipMemset(nb, 0, words * sizeof(uint64_t)));
-        if (sh->live_bits && sh->bits_cap)
-            HIPCHK(hipMemcpy(nb, sh->live_bits, sh->bits_cap * sizeof(uint64_t),
-                             hipMemcpyDeviceToDevice));
-        if (sh->live_bits) HIPCHK(hipFree(sh->live_bits));
+        e = hipMemset(nb, 0, words * sizeof(uint64_t));
+        if (e == hipSuccess && sh->live_bits && sh->bits_cap)
+            e = hipMemcpy(nb, sh->live_bits, sh->bits_cap * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(nb);
+            return fail(SZG_E_DEVICE, "hipMemcpy(live bits)", e);
+        }
+        if (sh->live_bits) (void)hipFree(sh->live_bits);
         sh->live_bits = nb;
         sh->bits_cap = words;
     }
+    if (sh->live_host.size() < words) sh->live_host.resize(words, 0);
     return SZG_OK;
 }
 
-// set live bits for rows [lo, hi) of a shard (host read-modify-write of the edge words)
+// set live bits for rows [lo, hi) of a shard: the host copy is the master, the touched words
+// follow it to the device (no read-back)
 int shard_set_live(Shard *sh, uint64_t lo, uint64_t hi)
 {
     if (hi <= lo) return SZG_OK;
     HIPCHK(hipSetDevice(sh->device));
     const uint64_t w0 = lo / 64, w1 = (hi - 1) / 64;
-    std::vector<uint64_t> words(w1 - w0 + 1);
-    HIPCHK(hipMemcpy(words.data(), sh->live_bits + w0, words.size() * sizeof(uint64_t),
-                     hipMemcpyDeviceToHost));
+    if (sh->live_host.size() <= w1) return fail(SZG_E_RANGE, "live bitmap smaller than the shard");
     for (uint64_t r = lo; r < hi;) {
         const uint64_t w = r / 64;
         const uint64_t end = std::min(hi, (w + 1) * 64);
         const uint64_t nb = end - r;
         const uint64_t mask = (nb == 64 ? ~0ull : ((1ull << nb) - 1ull)) << (r % 64);
-        words[w - w0] |= mask;
+        sh->live_host[w] |= mask;
         r = end;
     }
-    HIPCHK(hipMemcpy(sh->live_bits + w0, words.data(), words.size() * sizeof(uint64_t),
+    HIPCHK(hipMemcpy(sh->live_bits + w0, sh->live_host.data() + w0, (w1 - w0 + 1) * sizeof(uint64_t),
                      hipMemcpyHostToDevice));
     return SZG_OK;
 }
@@ -1546,7 +1744,44 @@ int reset_shards(szg_index *ix, const std::vector<uint64_t> &counts)
         if (rc) return rc;
         HIPCHK(szg::launch_fill_bits(sh->live_bits, counts[s], sh->bits_cap, nullptr));
         HIPCHK(hipDeviceSynchronize());
+        std::fill(sh->live_host.begin(), sh->live_host.end(), 0ull);
+        for (uint64_t w = 0; w * 64 < counts[s]; w++)
+            sh->live_host[w] = counts[s] - w * 64 >= 64 ? ~0ull : ((1ull << (counts[s] - w * 64)) - 1ull);
         first += counts[s];
+    }
+    return SZG_OK;
+}
+
+// consider()'s top-k branch over the union of the lists in visit order; get(l, q, i, &row, &dist)
+template <typename Count, typename Get>
+int merge_lists(int k, int n_lists, int list_len, int n_queries, Count count_of, Get get, uint64_t *out_rows,
+                double *out_dist, int32_t *out_count, uint8_t *out_history_dependent)
+{
+    std::vector<Cand> cands;
+    std::vector<HeapItem> res;
+    std::vector<double> d;
+    for (int q = 0; q < n_queries; q++) {
+        cands.clear();
+        for (int l = 0; l < n_lists; l++) {
+            const int n = std::min<int>(std::max<int>(count_of(l, q), 0), list_len);
+            for (int i = 0; i < n; i++) {
+                Cand c{0, 0.0, 0.0f};
+                get(l, q, i, &c.row, &c.dist);
+                cands.push_back(c);
+            }
+        }
+        replay_topk(cands, k, &res);
+        if (out_history_dependent) {
+            d.resize(cands.size());
+            for (size_t i = 0; i < cands.size(); i++) d[i] = cands[i].dist;
+            out_history_dependent[q] = history_dependent(d.data(), d.size(), k) ? 1 : 0;
+        }
+        for (int i = 0; i < k; i++) {
+            const bool have = i < (int)res.size();
+            out_rows[(size_t)q * k + i] = have ? res[i].row : UINT64_MAX;
+            out_dist[(size_t)q * k + i] = have ? res[i].priority : 0.0;
+        }
+        if (out_count) out_count[q] = (int32_t)res.size();
     }
     return SZG_OK;
 }
@@ -1585,6 +1820,7 @@ int64_t szg_row_bytes(int quant_bits, int dim)
 int szg_index_create(szg_index **out, int dim, int quant_bits, int metric, const int *devices,
                      int n_devices)
 {
+    SZG_TRY
     if (!out) return fail(SZG_E_INVALID, "out is null");
     *out = nullptr;
     if (dim <= 0 || dim > (1 << 20)) return fail(SZG_E_INVALID, "dim out of range");
@@ -1672,6 +1908,7 @@ int szg_index_create(szg_index **out, int dim, int quant_bits, int metric, const
     }
     *out = ix;
     return SZG_OK;
+    SZG_CATCH
 }
 
 void szg_index_destroy(szg_index *ix)
@@ -1706,6 +1943,7 @@ uint64_t szg_index_live_rows(const szg_index *ix)
 
 int szg_index_load(szg_index *ix, const uint8_t *rows, uint64_t n_rows)
 {
+    SZG_TRY
     if (!ix || (!rows && n_rows)) return fail(SZG_E_INVALID, "null argument");
     std::vector<uint64_t> counts;
     split_rows(ix, n_rows, &counts);
@@ -1719,10 +1957,12 @@ int szg_index_load(szg_index *ix, const uint8_t *rows, uint64_t n_rows)
         sh->n_live = counts[s];
     }
     return SZG_OK;
+    SZG_CATCH
 }
 
 int szg_index_synth(szg_index *ix, uint64_t n_rows, uint64_t seed, uint64_t first_row)
 {
+    SZG_TRY
     if (!ix) return fail(SZG_E_INVALID, "null argument");
     std::vector<uint64_t> counts;
     split_rows(ix, n_rows, &counts);
@@ -1738,6 +1978,7 @@ int szg_index_synth(szg_index *ix, uint64_t n_rows, uint64_t seed, uint64_t firs
         sh->n_live = counts[s];
     }
     return SZG_OK;
+    SZG_CATCH
 }
 
 // The shard new rows go to.  Ranges stay contiguous in row order, so only the last shard
@@ -1761,6 +2002,7 @@ Shard *append_target(szg_index *ix)
 
 int szg_index_append(szg_index *ix, const uint8_t *rows, uint64_t n_rows)
 {
+    SZG_TRY
     if (!ix || (!rows && n_rows)) return fail(SZG_E_INVALID, "null argument");
     if (n_rows == 0) return SZG_OK;
     Shard *sh = append_target(ix);
@@ -1775,11 +2017,13 @@ int szg_index_append(szg_index *ix, const uint8_t *rows, uint64_t n_rows)
     sh->n_rows += n_rows;
     sh->n_live += n_rows;
     return SZG_OK;
+    SZG_CATCH
 }
 
 // AddDocument for a block of float64 vectors: quantize + pack on the device
 int szg_index_append_f64(szg_index *ix, const double *vectors, uint64_t n_rows)
 {
+    SZG_TRY
     if (!ix || (!vectors && n_rows)) return fail(SZG_E_INVALID, "null argument");
     if (n_rows == 0) return SZG_OK;
     Shard *sh = append_target(ix);
@@ -1807,11 +2051,13 @@ int szg_index_append_f64(szg_index *ix, const double *vectors, uint64_t n_rows)
     sh->n_rows += n_rows;
     sh->n_live += n_rows;
     return SZG_OK;
+    SZG_CATCH
 }
 
 // AddDocument on an existing id from a float64 vector: re-encode one row in place
 int szg_index_overwrite_f64(szg_index *ix, uint64_t row, const double *vector)
 {
+    SZG_TRY
     if (!ix || !vector) return fail(SZG_E_INVALID, "null argument");
     uint64_t local;
     Shard *sh = shard_of(ix, row, &local);
@@ -1827,11 +2073,13 @@ int szg_index_overwrite_f64(szg_index *ix, uint64_t row, const double *vector)
     (void)hipFree(stage);
     if (e != hipSuccess) return fail(SZG_E_DEVICE, "overwrite_f64", e);
     return SZG_OK;
+    SZG_CATCH
 }
 
 // The reference's float64 distance from one query to each listed row
 int szg_distances(szg_index *ix, const double *query, const uint64_t *rows, uint64_t n, double *out_dist)
 {
+    SZG_TRY
     if (!ix || !query || (!rows && n) || (!out_dist && n)) return fail(SZG_E_INVALID, "null argument");
     if (n == 0) return SZG_OK;
     const uint64_t total = szg_index_rows(ix);
@@ -1850,6 +2098,7 @@ int szg_distances(szg_index *ix, const double *query, const uint64_t *rows, uint
         }
         if (cands.empty()) continue;
         Ctx *c = ctx_acquire(sh);
+        CtxGuard guard{sh, c};
         int rc = SZG_OK;
         auto body = [&]() -> int {
             HIPCHK(hipSetDevice(sh->device));
@@ -1873,10 +2122,10 @@ int szg_distances(szg_index *ix, const double *query, const uint64_t *rows, uint
             return SZG_OK;
         };
         rc = body();
-        ctx_release(sh, c);
         if (rc) return rc;
     }
     return SZG_OK;
+    SZG_CATCH
 }
 
 // decodeVector + dequantize on the host (collection.go:768-794, quantization.go:25-36);
@@ -1910,6 +2159,7 @@ static void decode_row_host(const uint8_t *data, int dim, int q, double *out)
 int szg_pair_distances(szg_index *ix, const uint64_t *rows_a, const uint64_t *rows_b, uint64_t n_pairs,
                        double *out_dist)
 {
+    SZG_TRY
     if (!ix || ((!rows_a || !rows_b || !out_dist) && n_pairs)) return fail(SZG_E_INVALID, "null argument");
     if (n_pairs == 0) return SZG_OK;
     // pairs sharing a left row go down in one szg_distances call with that row as the query
@@ -1936,10 +2186,12 @@ int szg_pair_distances(szg_index *ix, const uint64_t *rows_a, const uint64_t *ro
         s = e;
     }
     return SZG_OK;
+    SZG_CATCH
 }
 
 int szg_index_overwrite(szg_index *ix, uint64_t row, const uint8_t *row_bytes)
 {
+    SZG_TRY
     if (!ix || !row_bytes) return fail(SZG_E_INVALID, "null argument");
     uint64_t local;
     Shard *sh = shard_of(ix, row, &local);
@@ -1947,6 +2199,7 @@ int szg_index_overwrite(szg_index *ix, uint64_t row, const uint8_t *row_bytes)
     HIPCHK(hipSetDevice(sh->device));
     HIPCHK(hipDeviceSynchronize());
     return upload_rows(ix, sh, local, row_bytes, 1);
+    SZG_CATCH
 }
 
 int szg_index_tombstone(szg_index *ix, uint64_t row)
@@ -1956,11 +2209,12 @@ int szg_index_tombstone(szg_index *ix, uint64_t row)
     Shard *sh = shard_of(ix, row, &local);
     if (!sh) return fail(SZG_E_RANGE, "row out of range");
     HIPCHK(hipSetDevice(sh->device));
-    HIPCHK(hipDeviceSynchronize());
-    uint64_t w = 0;
-    HIPCHK(hipMemcpy(&w, sh->live_bits + local / 64, sizeof(w), hipMemcpyDeviceToHost));
     const uint64_t bit = 1ull << (local % 64);
+    uint64_t &w = sh->live_host[local / 64];
     if (w & bit) {
+        // searches in flight on this device finish first (callers hold the write lock; this
+        // also covers a search that failed half-way)
+        HIPCHK(hipDeviceSynchronize());
         w &= ~bit;
         HIPCHK(hipMemcpy(sh->live_bits + local / 64, &w, sizeof(w), hipMemcpyHostToDevice));
         sh->n_live--;
@@ -1971,6 +2225,7 @@ int szg_index_tombstone(szg_index *ix, uint64_t row)
 
 int szg_index_read_rows(szg_index *ix, uint64_t first_row, uint64_t n_rows, uint8_t *out)
 {
+    SZG_TRY
     if (!ix || (!out && n_rows)) return fail(SZG_E_INVALID, "null argument");
     if (first_row + n_rows > szg_index_rows(ix)) return fail(SZG_E_RANGE, "row range out of bounds");
     for (Shard *sh : ix->shards) {
@@ -1990,6 +2245,7 @@ int szg_index_read_rows(szg_index *ix, uint64_t first_row, uint64_t n_rows, uint
         if (e != hipSuccess) return fail(SZG_E_DEVICE, "read_rows", e);
     }
     return SZG_OK;
+    SZG_CATCH
 }
 
 int szg_index_set_row_base(szg_index *ix, uint64_t base)
@@ -2014,8 +2270,11 @@ int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
         if (out_count) for (int i = 0; i < n_queries; i++) out_count[i] = 0;
         return SZG_OK;
     }
-    if (!(ix->coalesce && n_queries == 1 && ix->multi_query))
+    if (!(ix->coalesce && n_queries == 1 && ix->multi_query)) {
+        SZG_TRY
         return search_topk_impl(ix, queries, n_queries, k, allow_bits, out_rows, out_dist, out_count);
+        SZG_CATCH
+    }
 
     // Search holds only RLock in the reference (collection.go:570), so many goroutines call in
     // at once, each with ONE query.  Whoever finds no batch in flight becomes the leader: it
@@ -2029,14 +2288,19 @@ int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
     me.out_rows = out_rows;
     me.out_dist = out_dist;
     me.out_count = out_count;
+    std::vector<PendingSearch *> batch;
     std::unique_lock<std::mutex> lk(ix->comb_mu);
-    ix->comb_waiting.push_back(&me);
+    try {
+        batch.reserve(48);  // nothing below that touches the combiner's state may throw
+        ix->comb_waiting.push_back(&me);
+    } catch (...) {
+        return fail(SZG_E_NOMEM, "out of memory (host)");
+    }
     if (ix->comb_leader) {
         me.cv.wait(lk, [&] { return me.done || me.lead; });
         if (me.done) return me.rc;
     }
     ix->comb_leader = true;
-    std::vector<PendingSearch *> batch;
     std::vector<double> q;
     std::vector<uint64_t> rows;
     std::vector<double> dist;
@@ -2047,7 +2311,7 @@ int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
         const int kk = ix->comb_waiting.front()->k;  // never empty here: `me` is in it until done
         for (auto it = ix->comb_waiting.begin(); it != ix->comb_waiting.end() && batch.size() < 48;) {
             if ((*it)->k == kk) {
-                batch.push_back(*it);
+                batch.push_back(*it);  // within the reserved capacity
                 it = ix->comb_waiting.erase(it);
             } else {
                 ++it;
@@ -2056,28 +2320,34 @@ int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
         lk.unlock();
         const int nq = (int)batch.size();
         int rc;
-        if (nq == 1) {
-            PendingSearch *p = batch[0];
-            rc = search_topk_impl(ix, p->query, 1, kk, p->allow, p->out_rows, p->out_dist, p->out_count);
-        } else {
-            q.resize((size_t)nq * ix->dim);
-            rows.resize((size_t)nq * kk);
-            dist.resize((size_t)nq * kk);
-            count.resize(nq);
-            masks.resize(nq);
-            bool any = false;
-            for (int i = 0; i < nq; i++) {
-                memcpy(&q[(size_t)i * ix->dim], batch[i]->query, sizeof(double) * ix->dim);
-                masks[i] = batch[i]->allow;  // each caller's own filter, if it has one
-                any |= masks[i] != nullptr;
+        try {
+            if (nq == 1) {
+                PendingSearch *p = batch[0];
+                rc = search_topk_impl(ix, p->query, 1, kk, p->allow, p->out_rows, p->out_dist, p->out_count);
+            } else {
+                q.resize((size_t)nq * ix->dim);
+                rows.resize((size_t)nq * kk);
+                dist.resize((size_t)nq * kk);
+                count.resize(nq);
+                masks.resize(nq);
+                bool any = false;
+                for (int i = 0; i < nq; i++) {
+                    memcpy(&q[(size_t)i * ix->dim], batch[i]->query, sizeof(double) * ix->dim);
+                    masks[i] = batch[i]->allow;  // each caller's own filter, if it has one
+                    any |= masks[i] != nullptr;
+                }
+                rc = search_topk_impl(ix, q.data(), nq, kk, nullptr, rows.data(), dist.data(), count.data(),
+                                      any ? masks.data() : nullptr);
+                for (int i = 0; i < nq && rc == SZG_OK; i++) {
+                    memcpy(batch[i]->out_rows, &rows[(size_t)i * kk], sizeof(uint64_t) * kk);
+                    memcpy(batch[i]->out_dist, &dist[(size_t)i * kk], sizeof(double) * kk);
+                    if (batch[i]->out_count) *batch[i]->out_count = count[i];
+                }
             }
-            rc = search_topk_impl(ix, q.data(), nq, kk, nullptr, rows.data(), dist.data(), count.data(),
-                                  any ? masks.data() : nullptr);
-            for (int i = 0; i < nq && rc == SZG_OK; i++) {
-                memcpy(batch[i]->out_rows, &rows[(size_t)i * kk], sizeof(uint64_t) * kk);
-                memcpy(batch[i]->out_dist, &dist[(size_t)i * kk], sizeof(double) * kk);
-                if (batch[i]->out_count) *batch[i]->out_count = count[i];
-            }
+        } catch (const std::bad_alloc &) {
+            rc = fail(SZG_E_NOMEM, "out of memory (host)");
+        } catch (...) {
+            rc = fail(SZG_E_DEVICE, "unexpected exception");
         }
         lk.lock();
         for (PendingSearch *p : batch) {
@@ -2099,6 +2369,7 @@ int szg_search_radius(szg_index *ix, const double *query, double radius,
                       const uint64_t *allow_bits, uint64_t *out_rows, double *out_dist,
                       uint64_t capacity, uint64_t *out_total)
 {
+    SZG_TRY
     if (!ix || !query || !out_total) return fail(SZG_E_INVALID, "null argument");
     if (!(radius > 0)) return fail(SZG_E_INVALID, "radius must be > 0 (collection.go:598)");
     if (capacity && (!out_rows || !out_dist)) return fail(SZG_E_INVALID, "null output buffer");
@@ -2132,11 +2403,11 @@ int szg_search_radius(szg_index *ix, const double *query, double radius,
         Shard *sh = ix->shards[s];
         if (sh->n_rows == 0) continue;
         Ctx *c = ctx_acquire(sh);
+        CtxGuard guard{sh, c};
         memcpy(c->h_qsw, tmp.data(), ix->qsw_bytes);
         c->meta[0] = meta;
         rc = enqueue_queries(ix, sh, c, query, 1, allow_bits ? &allow_bits : nullptr);
         if (rc == SZG_OK) rc = run_collect(ix, sh, c, 0, thr_f, allow_bits != nullptr, &cands);
-        ctx_release(sh, c);
     }
     if (rc) return rc;
     // consider()'s radius branch (collection.go:598-605) in visit order, then the pop loop
@@ -2159,6 +2430,7 @@ int szg_search_radius(szg_index *ix, const double *query, double radius,
     }
     if (total > capacity) return fail(SZG_E_TRUNCATED, "radius search: capacity too small");
     return SZG_OK;
+    SZG_CATCH
 }
 
 /*
@@ -2175,29 +2447,43 @@ int szg_merge_topk(int k, int n_lists, int list_len, int n_queries, const uint64
     if (k <= 0 || n_lists <= 0 || list_len <= 0 || n_queries < 0 || !rows || !dist || !counts ||
         !out_rows || !out_dist)
         return fail(SZG_E_INVALID, "bad argument");
-    std::vector<Cand> cands;
-    std::vector<HeapItem> res;
-    for (int q = 0; q < n_queries; q++) {
-        cands.clear();
-        for (int l = 0; l < n_lists; l++) {
-            const size_t base = ((size_t)l * n_queries + q) * list_len;
-            const int n = std::min<int>(counts[(size_t)l * n_queries + q], list_len);
-            for (int i = 0; i < n; i++) cands.push_back(Cand{rows[base + i], dist[base + i], 0.0f});
-        }
-        replay_topk(cands, k, &res);
-        if (out_history_dependent) {
-            std::vector<double> d(cands.size());
-            for (size_t i = 0; i < cands.size(); i++) d[i] = cands[i].dist;
-            out_history_dependent[q] = history_dependent(d.data(), d.size(), k) ? 1 : 0;
-        }
-        for (int i = 0; i < k; i++) {
-            const bool have = i < (int)res.size();
-            out_rows[(size_t)q * k + i] = have ? res[i].row : UINT64_MAX;
-            out_dist[(size_t)q * k + i] = have ? res[i].priority : 0.0;
-        }
-        if (out_count) out_count[q] = (int32_t)res.size();
+    try {
+        return merge_lists(
+            k, n_lists, list_len, n_queries, [&](int l, int q) { return counts[(size_t)l * n_queries + q]; },
+            [&](int l, int q, int i, uint64_t *r, double *d) {
+                const size_t at = ((size_t)l * n_queries + q) * list_len + i;
+                *r = rows[at];
+                *d = dist[at];
+            },
+            out_rows, out_dist, out_count, out_history_dependent);
+    } catch (const std::bad_alloc &) {
+        return fail(SZG_E_NOMEM, "out of memory");
     }
-    return SZG_OK;
+}
+
+/* The same merge straight from the exchanged records (no repacking on the caller's side):
+ * records[n_lists][n_queries][2*list_len + 1] int64 = list_len rows | list_len float64 bit
+ * patterns | count -- exactly what each rank contributes to the all-gather. */
+int szg_merge_topk_records(int k, int n_lists, int list_len, int n_queries, const int64_t *records,
+                           uint64_t *out_rows, double *out_dist, int32_t *out_count,
+                           uint8_t *out_history_dependent)
+{
+    if (k <= 0 || n_lists <= 0 || list_len <= 0 || n_queries < 0 || !records || !out_rows || !out_dist)
+        return fail(SZG_E_INVALID, "bad argument");
+    const size_t rec = 2 * (size_t)list_len + 1;
+    try {
+        return merge_lists(
+            k, n_lists, list_len, n_queries,
+            [&](int l, int q) { return (int)records[((size_t)l * n_queries + q) * rec + 2 * list_len]; },
+            [&](int l, int q, int i, uint64_t *r, double *d) {
+                const int64_t *p = records + ((size_t)l * n_queries + q) * rec;
+                *r = (uint64_t)p[i];
+                memcpy(d, &p[list_len + i], sizeof(double));
+            },
+            out_rows, out_dist, out_count, out_history_dependent);
+    } catch (const std::bad_alloc &) {
+        return fail(SZG_E_NOMEM, "out of memory");
+    }
 }
 
 int szg_set_timing(szg_index *ix, int enabled)
@@ -2229,6 +2515,7 @@ int szg_reset_stats(szg_index *ix)
 
 int szg_set_option(szg_index *ix, const char *name, int64_t value)
 {
+    SZG_TRY
     if (!ix || !name) return fail(SZG_E_INVALID, "null argument");
     const std::string n(name);
     if (n == "slack") {
@@ -2299,6 +2586,7 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
         return fail(SZG_E_INVALID, "unknown option");
     }
     return SZG_OK;
+    SZG_CATCH
 }
 
 // test hook: device float64 primitives (0 div, 1 sqrt, 2 go acos, 3 round, 4 f32 narrowing)

@@ -51,6 +51,26 @@ def merge_topk(k, rows, dist, counts):
     return out_rows, out_dist, out_count, hist.astype(bool)
 
 
+def merge_topk_records(k, records, kk):
+    """Merge straight from the all-gathered buffer: records int64 [G, nq, 2*kk+1]
+    (kk rows | kk float64 bit patterns | count per query), one C call, no repacking."""
+    L = _lib.load()
+    G, nq, w = records.shape
+    assert w == 2 * kk + 1 and records.dtype == np.int64 and records.flags.c_contiguous
+    out_rows = np.empty((nq, k), dtype=np.uint64)
+    out_dist = np.empty((nq, k), dtype=np.float64)
+    out_count = np.empty(nq, dtype=np.int32)
+    hist = np.empty(nq, dtype=np.uint8)
+    _lib.check(L.szg_merge_topk_records(
+        int(k), int(G), int(kk), int(nq),
+        records.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+        out_rows.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+        out_dist.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+        out_count.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+        hist.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))), "szg_merge_topk_records")
+    return out_rows, out_dist, out_count, hist.astype(bool)
+
+
 class ShardedSearcher:
     """Exact top-k over a corpus sharded across the ranks of a process group.
 
@@ -66,6 +86,14 @@ class ShardedSearcher:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.device = device  # torch device of the exchange buffers ("cuda:N" for nccl)
+        self._bufs = {}       # (nq, kk) -> staging of one exchange, reused call after call
+        self.exchange_s = 0.0     # wall time spent in exchange() (collective + merge)
+        self.exchange_host_s = 0.0  # of which: packing and merging on the host
+        self.exchanges = 0
+
+    def reset_timers(self):
+        self.exchange_s = self.exchange_host_s = 0.0
+        self.exchanges = 0
 
     def search(self, queries, k):
         q = np.ascontiguousarray(queries, dtype=np.float64)
@@ -74,28 +102,54 @@ class ShardedSearcher:
         # one extra per shard so equal distances at the k boundary are visible
         return self.exchange(self.local_search(q, k + 1), k)
 
+    def _staging(self, nq, kk):
+        """Pinned host record buffers (+ device twins for RCCL) for one (nq, kk) shape."""
+        import torch
+        b = self._bufs.get((nq, kk))
+        if b is None:
+            w = 2 * kk + 1
+            pin = self.device is not None
+            mine_h = torch.empty((nq, w), dtype=torch.int64, pin_memory=pin)
+            all_h = torch.empty((self.world * nq, w), dtype=torch.int64, pin_memory=pin)
+            b = {"mine_h": mine_h, "mine_np": mine_h.numpy(), "all_h": all_h,
+                 "all_np": all_h.numpy().reshape(self.world, nq, w)}
+            if self.device is not None:
+                b["mine_d"] = torch.empty((nq, w), dtype=torch.int64, device=self.device)
+                b["all_d"] = torch.empty((self.world * nq, w), dtype=torch.int64, device=self.device)
+            if len(self._bufs) > 8:
+                self._bufs.clear()
+            self._bufs[(nq, kk)] = b
+        return b
+
     def exchange(self, local, k):
         """All-gather the ranks' local (rows, dist, count) top-(k+1) lists and merge."""
+        import time
         import torch
+        t0 = time.perf_counter()
         rows, dist, count = local
         nq, kk = rows.shape
+        b = self._staging(nq, kk)
         # one int64 record per query: kk rows | kk distance bit patterns | count
-        rec = np.zeros((nq, 2 * kk + 1), dtype=np.int64)
+        rec = b["mine_np"]
         rec[:, :kk] = rows.view(np.int64)
         rec[:, kk:2 * kk] = dist.view(np.int64)
         rec[:, 2 * kk] = count
-        mine = torch.from_numpy(rec)
-        if self.device is not None:
-            mine = mine.to(self.device)
+        t1 = time.perf_counter()
         # concatenated along dim 0 (the form both RCCL and gloo accept), viewed [world, nq, .]
-        gathered = torch.empty((self.world * nq, mine.shape[1]), dtype=mine.dtype,
-                               device=mine.device)
-        self._dist.all_gather_into_tensor(gathered, mine, group=self.group)
-        g = gathered.cpu().numpy().reshape(self.world, nq, -1)
-        g_rows = np.ascontiguousarray(g[:, :, :kk]).view(np.uint64)
-        g_dist = np.ascontiguousarray(g[:, :, kk:2 * kk]).view(np.float64)
-        g_count = np.ascontiguousarray(g[:, :, 2 * kk]).astype(np.int32)
-        return merge_topk(k, g_rows, g_dist, g_count)
+        if self.device is not None:
+            b["mine_d"].copy_(b["mine_h"], non_blocking=True)
+            self._dist.all_gather_into_tensor(b["all_d"], b["mine_d"], group=self.group)
+            b["all_h"].copy_(b["all_d"], non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+        else:
+            self._dist.all_gather_into_tensor(b["all_h"], b["mine_h"], group=self.group)
+        t2 = time.perf_counter()
+        out = merge_topk_records(k, b["all_np"], kk)
+        t3 = time.perf_counter()
+        self.exchange_s += t3 - t0
+        self.exchange_host_s += (t1 - t0) + (t3 - t2)
+        self.exchanges += 1
+        return out
 
     def search_radius(self, local_radius, query, radius):
         """Radius search over the sharded corpus (config #5's mode).
@@ -133,6 +187,19 @@ class ShardedSearcher:
         g_dist = np.ascontiguousarray(g[..., 1]).view(np.float64)
         r, d, c, _ = merge_topk(total, g_rows, g_dist, counts.astype(np.int32).reshape(self.world, 1))
         return r[0, :c[0]], d[0, :c[0]]
+
+    def search_radius_stream(self, local_radius, queries, radius):
+        """Radius searches back to back: the rank's sweep for query i+1 runs in a worker thread
+        while this thread exchanges and merges query i (every rank calls with the same queries)."""
+        from concurrent.futures import ThreadPoolExecutor
+        q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, queries.shape[-1])
+        outs = []
+        with ThreadPoolExecutor(max_workers=1) as ex:
+            futs = [ex.submit(local_radius, q[i], float(radius)) for i in range(q.shape[0])]
+            for i, f in enumerate(futs):
+                res = f.result()
+                outs.append(self.search_radius(lambda _q, _r, res=res: res, q[i], radius))
+        return outs
 
     def search_stream(self, queries, k, chunk):
         """Pipelined form for throughput: the local sweeps of chunk i+1 run in a worker

@@ -1,0 +1,53 @@
+"""bench.py's launch forms: the plain `python3 bench.py --gpus N` must start
+its own ranks (a child torch.distributed.run, spawned before the parent touches a GPU) and relay
+ONE JSON line; `--mode inproc` drives N device shards from one process (the Go binding's form).
+Rehearsed on one card: SZG_BENCH_ONE_GPU=1 puts every shard on device 0, SZG_BENCH_BACKEND=gloo
+exchanges on the CPU (RCCL wants one GPU per rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(extra, env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines          # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+def test_plain_command_starts_its_own_ranks():
+    out = run_bench(["--gpus", "2", "--steps", "48", "--warmup", "8", "--rows", "200000", "--settle-seconds", "0.2"],
+                    {"SZG_BENCH_ONE_GPU": "1", "SZG_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["config"]["mode"] == "ranks"
+    assert out["steps"] == 48 and out["warmup"] == 8
+    assert len(out["ranks"]) == 2 and {r["rank"] for r in out["ranks"]} == {0, 1}
+    assert sum(r["rows"] for r in out["ranks"]) == 200000
+    assert out["parity"]["ids_identical"] == out["parity"]["queries_checked"] > 0
+    assert out["roofline"]["achieved"] > 0 and out["host_us_per_query"] > 0
+    assert out["value"] > 0
+
+
+def test_inproc_mode_and_unchanged_single_gpu_form():
+    out = run_bench(["--gpus", "2", "--mode", "inproc", "--steps", "48", "--warmup", "8", "--rows", "200000",
+                     "--settle-seconds", "0.2"], {"SZG_BENCH_ONE_GPU": "1"})
+    assert out["n_gpus"] == 2 and out["config"]["mode"] == "inproc"
+    assert out["parity"]["ids_identical"] == out["parity"]["queries_checked"] > 0
+    assert out["host_us_per_query"] > 0
+    one = run_bench(["--gpus", "1", "--steps", "32", "--warmup", "8", "--rows", "100000", "--settle-seconds", "0.2",
+                     "--cpu-seconds", "1"], {})
+    assert one["n_gpus"] == 1 and one["config"]["mode"] == "single"
+    assert one["roofline"]["bound"] == "hbm" and one["cpu_baseline"]["kind"] == "port"
+    assert one["batched"]["mfma_TFLOPs"] > 0 and one["batched"]["ids_identical_to_single_query_path"]
+    assert one["parity"]["ids_identical"] == one["parity"]["queries_checked"]

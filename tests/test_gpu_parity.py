@@ -242,3 +242,95 @@ def test_shape_specialised_kernels_match_any_shape(dim, metric):
             rr, dd = ix.search_radius(queries[0], radius)
             o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, queries[0], radius=radius)
             assert_same(rr, dd, o_rows, o_dist)
+
+
+def _check_all(ix, rows, dim, bits, metric, queries, k, allow=None):
+    r, d, c = ix.search_topk(queries, k, allow=allow)
+    for qi in range(queries.shape[0]):
+        o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, queries[qi], k=k,
+                                             allow=None if allow is None else allow[qi].astype(np.uint8))
+        assert c[qi] == len(o_rows), (qi, c[qi], len(o_rows))
+        assert_same(r[qi, : c[qi]], d[qi, : c[qi]], o_rows, o_dist)
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+@pytest.mark.parametrize("mq", [0, 1])
+def test_nan_among_the_first_k_rows_poisons_the_heap_like_the_reference(bits, mq):
+    """consider() pushes the first k eligible rows whatever their distance (collection.go:608).
+    A row antipodal (or parallel) to the query can come out of the unclamped acos (:831) as NaN;
+    its scan key is the WORST possible, so it is nowhere near the candidates -- but sitting in
+    the reference's heap it decides everything that follows.  Same for NaN / Inf elements.  The
+    library must notice (exact distances of the first k eligible rows) and take the exact replay."""
+    dim, n, k = 24, 4000, 6
+    rng = np.random.default_rng(bits + mq)
+    vecs = rng.uniform(-1, 1, (n, dim))
+    queries = rng.uniform(-1, 1, (5, dim))
+    # find a query scale whose antipode really yields NaN under the reference's arithmetic
+    nan_q = None
+    for t in range(400):
+        q = rng.uniform(-1, 1, dim)
+        row = orc.encode_rows(-q[None, :] * 0.5, bits)
+        if np.isnan(orc.all_distances(row, dim, bits, SZG_COSINE, q)[0]):
+            nan_q = q
+            break
+    assert nan_q is not None, "no antipodal NaN found (acos argument never left [-1, 1])"
+    queries[0] = nan_q
+    for where in (0, k - 1, k, 1500):       # inside the first k rows, at the edge, outside
+        v = vecs.copy()
+        v[where] = -nan_q * 0.5
+        rows = orc.encode_rows(v, bits)
+        with ScanIndex(dim, bits, SZG_COSINE) as ix:
+            ix.load(rows)
+            ix.set_option("multi_query", mq)
+            _check_all(ix, rows, dim, bits, SZG_COSINE, queries, k)
+            st = ix.stats()
+            if where < k:
+                assert st["full_replays"] >= 1
+            # with a filter the "first k eligible" rows move: row `where` is the first allowed one
+            allow = np.ones((queries.shape[0], n), dtype=bool)
+            allow[:, :where] = False
+            _check_all(ix, rows, dim, bits, SZG_COSINE, queries, k, allow=allow)
+            # ... and a tombstone takes it out of the heap's history again
+            ix.tombstone(where)
+            alive = np.ones((queries.shape[0], n), dtype=bool)
+            alive[:, where] = False
+            r, d, c = ix.search_topk(queries, k)
+            for qi in range(queries.shape[0]):
+                o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, SZG_COSINE, queries[qi], k=k,
+                                                     allow=alive[qi].astype(np.uint8))
+                assert_same(r[qi, : c[qi]], d[qi, : c[qi]], o_rows, o_dist)
+
+
+@pytest.mark.parametrize("metric", [SZG_EUCLIDEAN, SZG_COSINE])
+@pytest.mark.parametrize("bits", [32, 64])
+def test_nan_and_inf_elements_in_stored_rows(bits, metric):
+    dim, n, k = 16, 3000, 5
+    rng = np.random.default_rng(3)
+    vecs = rng.uniform(-1, 1, (n, dim))
+    queries = rng.uniform(-1, 1, (4, dim))
+    for where, val in ((2, np.nan), (0, np.inf), (k - 1, -np.inf), (700, np.nan)):
+        v = vecs.copy()
+        v[where, 3] = val
+        rows = orc.encode_rows(v, bits)
+        for devs in (None, [0, 0]):
+            with ScanIndex(dim, bits, metric, devices=devs) as ix:
+                ix.load(rows)
+                for mq in (0, 1):
+                    ix.set_option("multi_query", mq)
+                    _check_all(ix, rows, dim, bits, metric, queries, k)
+
+
+@pytest.mark.parametrize("bits,metric", [(8, 1), (32, 0)])
+def test_k_beyond_the_fused_selection(bits, metric):
+    """The reference bounds K by nothing (collection.go:606-619): k past the LDS-resident lists
+    is answered by the exact replay, not refused."""
+    dim, n = 12, 9000
+    rows = orc.synth_rows(SEED + 900 + bits, 0, n, dim, bits)
+    queries = orc.synth_vectors(SEED + 901, 0, 2, dim)
+    with ScanIndex(dim, bits, metric) as ix:
+        ix.load(rows)
+        for k in (5000, 8999, 12000):
+            _check_all(ix, rows, dim, bits, metric, queries, k)
+        assert ix.stats()["full_replays"] >= 6
+        allow = (np.arange(n) % 3 != 0)[None, :].repeat(2, axis=0)
+        _check_all(ix, rows, dim, bits, metric, queries, 5000, allow=allow)

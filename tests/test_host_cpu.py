@@ -60,7 +60,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libsyzgy_scan.so does not export %s" % name
     assert sorted(_lib.EXPORTS) == declared
-    assert L.szg_abi_version() == 1
+    assert L.szg_abi_version() == 2
     pager = _declared_symbols("syzgy_pager.h")
     assert sorted(_lib.PAGER_EXPORTS) == pager
     for name in pager:
@@ -128,6 +128,29 @@ def test_merge_topk_flags_ties_and_short_lists():
     assert list(r[0]) == [0, 1] and list(d[0]) == [1.0, 2.0] and hist[0]  # 2.0 == 2.0 at the boundary
     r, d, c, hist = merge_topk(5, R, D, C)
     assert c[0] == 4 and r[0, 4] == np.iinfo(np.uint64).max
+
+
+def test_merge_topk_records_is_the_same_merge():
+    """The records form (what the ranks all-gather: rows | distance bits | count per query)
+    gives exactly szg_merge_topk's answer, NaN distances and short lists included."""
+    from syzgydb_amd.sharded import merge_topk, merge_topk_records
+    rng = np.random.default_rng(5)
+    for case in range(40):
+        G, nq, kk = int(rng.integers(1, 9)), int(rng.integers(1, 7)), int(rng.integers(1, 12))
+        k = max(1, kk - 1)
+        R = rng.integers(0, 1 << 40, (G, nq, kk)).astype(np.uint64)
+        D = np.round(rng.uniform(0, 2, (G, nq, kk)), 1 if case % 2 else 6)
+        if case % 5 == 0:
+            D[0, 0, 0] = np.nan
+        D.sort(axis=2)
+        C = rng.integers(0, kk + 1, (G, nq)).astype(np.int32)
+        rec = np.zeros((G, nq, 2 * kk + 1), np.int64)
+        rec[:, :, :kk] = R.view(np.int64)
+        rec[:, :, kk:2 * kk] = D.view(np.int64)
+        rec[:, :, 2 * kk] = C
+        a = merge_topk(k, R, D, C)
+        b = merge_topk_records(k, rec, kk)
+        assert (a[0] == b[0]).all() and same_f64(a[1], b[1]) and (a[2] == b[2]).all() and (a[3] == b[3]).all()
 
 
 def test_shard_ranges_cover_everything():
