@@ -415,7 +415,7 @@ def main():
         mine = roofline_of(stats, hi - lo, ix.row_bytes, bits, metric, "")
         row = {"rank": rank, "device": devices[0], "rows": hi - lo, "elapsed_s": round(my_elapsed, 6),
                "scan_GBps": mine["achieved"], "avg_launch_ms": mine["avg_launch_ms"],
-               "host_us_per_query": round((stats["host_prep_us"] + stats["host_finish_us"]) / max(args.steps, 1) +
+               "host_us_per_query": round((stats["host_prep_us"] + stats["host_finish_us"] + stats["host_enqueue_us"]) / max(args.steps, 1) +
                                           1e6 * searcher.exchange_host_s / max(args.steps, 1), 2),
                "exchange_ms_per_batch": round(1e3 * searcher.exchange_s / max(searcher.exchanges, 1), 3)}
         per_rank = [None] * world
@@ -431,7 +431,7 @@ def main():
             rf["traffic"], src = recorded_traffic(args.workload, args.rows, rf["sweeps_per_launch"])
             if src:
                 rf["traffic_source"] = src
-        host_us = (stats["host_prep_us"] + stats["host_finish_us"]) / max(args.steps, 1)
+        host_us = (stats["host_prep_us"] + stats["host_finish_us"] + stats["host_enqueue_us"]) / max(args.steps, 1)
         if searcher is not None:
             host_us += 1e6 * searcher.exchange_host_s / max(args.steps, 1)
         out = {
@@ -464,7 +464,8 @@ def main():
             },
             "roofline": rf,
             "host_us_per_query": round(host_us, 2),
-            "host_us_breakdown": {"prepare_enqueue": round(stats["host_prep_us"] / max(args.steps, 1), 2),
+            "host_us_breakdown": {"prepare": round(stats["host_prep_us"] / max(args.steps, 1), 2),
+                                  "enqueue_hip_calls": round(stats["host_enqueue_us"] / max(args.steps, 1), 2),
                                   "assemble": round(stats["host_finish_us"] / max(args.steps, 1), 2),
                                   "exchange_pack_merge": round(1e6 * searcher.exchange_host_s / max(args.steps, 1), 2)
                                   if searcher is not None else 0.0},

@@ -24,6 +24,7 @@ import (
 	"fmt"
 	"sort"
 	"strconv"
+	"sync"
 	"unsafe"
 )
 
@@ -35,13 +36,26 @@ type gpuMirror struct {
 	ids   []uint64          // row -> document id
 	rowOf map[uint64]uint64 // document id -> row
 	dirty bool              // set by mutators that could not be applied incrementally
+	// Search runs under the collection's RLock only, so searches are concurrent with each
+	// other; a reload (which rewrites ids / rowOf and calls szg_index_load, both of which
+	// need exclusive access) takes mu for writing, every search takes it for reading.
+	mu      sync.RWMutex
+	lastID  string // greatest decimal id string among the loaded rows (visit order = sort.Strings)
+	version uint64 // bumped by add / remove: filter verdicts are cached per (key, version)
+	masks   map[string]cachedMask
+}
+
+// cachedMask is one filter's verdicts, one bit per row, valid for one collection version.
+type cachedMask struct {
+	version uint64
+	bits    []C.uint64_t
 }
 
 // newGPUMirror pages every record's stream 1 (the packed vector, exactly the
 // bytes encodeDocument wrote, collection.go:713-743) into HBM.  Called from
 // NewCollection where the LSH tree is rebuilt (collection.go:297-311).
 func newGPUMirror(c *Collection, devices []int) (*gpuMirror, error) {
-	m := &gpuMirror{rowOf: map[uint64]uint64{}}
+	m := &gpuMirror{rowOf: map[uint64]uint64{}, masks: map[string]cachedMask{}}
 	var devp *C.int
 	cdev := make([]C.int, len(devices))
 	for i, d := range devices {
@@ -76,6 +90,8 @@ func (m *gpuMirror) reload(c *Collection) error {
 	buf := make([]byte, 0, len(recordIDs)*rowBytes)
 	m.ids = m.ids[:0]
 	m.rowOf = map[uint64]uint64{}
+	m.lastID = ""
+	m.version++ // rows are renumbered: cached filter masks no longer apply
 	for _, rid := range recordIDs {
 		id, err := strconv.ParseUint(rid, 10, 64)
 		if err != nil {
@@ -87,6 +103,7 @@ func (m *gpuMirror) reload(c *Collection) error {
 		}
 		m.rowOf[id] = uint64(len(m.ids))
 		m.ids = append(m.ids, id)
+		m.lastID = rid
 		buf = append(buf, span.DataStreams[1].Data...)
 	}
 	var p *C.uint8_t
@@ -100,13 +117,23 @@ func (m *gpuMirror) reload(c *Collection) error {
 	return nil
 }
 
-// add mirrors AddDocument (collection.go:427-457); called under c.mutex.Lock.
+// add mirrors AddDocument (collection.go:427-457); called under c.mutex.Lock, so no search
+// is in flight.  Rows are kept in IterateSortedRecords order (sort.Strings of the decimal ids,
+// spanfile.go:540-560) because that order decides ties at the k boundary ("first visited
+// wins", collection.go:608): a new id that sorts after every loaded one is appended in place;
+// any other new id marks the mirror dirty and the next search reloads it in order.
 func (m *gpuMirror) add(id uint64, encoded []byte) {
+	m.version++
 	p := (*C.uint8_t)(unsafe.Pointer(&encoded[0]))
 	if row, ok := m.rowOf[id]; ok {
 		if C.szg_index_overwrite(m.h, C.uint64_t(row), p) != C.SZG_OK {
 			m.dirty = true
 		}
+		return
+	}
+	rid := strconv.FormatUint(id, 10)
+	if m.dirty || rid < m.lastID {
+		m.dirty = true // out of visit order: reload before the next exact search
 		return
 	}
 	if C.szg_index_append(m.h, p, 1) != C.SZG_OK {
@@ -115,10 +142,12 @@ func (m *gpuMirror) add(id uint64, encoded []byte) {
 	}
 	m.rowOf[id] = uint64(len(m.ids))
 	m.ids = append(m.ids, id)
+	m.lastID = rid
 }
 
 // remove mirrors removeDocument (collection.go:511-521); called under c.mutex.Lock.
 func (m *gpuMirror) remove(id uint64) {
+	m.version++
 	if row, ok := m.rowOf[id]; ok {
 		if C.szg_index_tombstone(m.h, C.uint64_t(row)) != C.SZG_OK {
 			m.dirty = true
@@ -151,22 +180,69 @@ func (m *gpuMirror) allowBits(c *Collection, filter FilterFn) []C.uint64_t {
 	return bits
 }
 
+// allowBitsKeyed is allowBits behind a cache: a filter's verdicts only change when the
+// collection does, so they are kept per (key, version) -- the REST layer's natural key is the
+// filter text it compiled (rest.go:429-436).  key == "" evaluates every time (a bare closure
+// has no identity to cache by).  Called with m.mu read-locked; the cache has its own lock.
+var maskCacheMu sync.Mutex
+
+func (m *gpuMirror) allowBitsKeyed(c *Collection, filter FilterFn, key string) []C.uint64_t {
+	if key == "" {
+		return m.allowBits(c, filter)
+	}
+	maskCacheMu.Lock()
+	if hit, ok := m.masks[key]; ok && hit.version == m.version {
+		maskCacheMu.Unlock()
+		return hit.bits
+	}
+	maskCacheMu.Unlock()
+	bits := m.allowBits(c, filter)
+	maskCacheMu.Lock()
+	if len(m.masks) > 32 {
+		m.masks = map[string]cachedMask{}
+	}
+	m.masks[key] = cachedMask{version: m.version, bits: bits}
+	maskCacheMu.Unlock()
+	return bits
+}
+
 // searchExact replaces the hot loop of Collection.Search (collection.go:672-684
 // plus the pop loop :694-697).  ok == false tells the caller to run the
 // reference's own CPU loop (keeps Search's no-error signature).
 func (m *gpuMirror) searchExact(c *Collection, args SearchArgs) (results []SearchResult, ok bool) {
-	if m.dirty {
-		if err := m.reload(c); err != nil {
+	return m.searchExactKeyed(c, args, "")
+}
+
+// searchExactKeyed: filterKey names args.Filter for the bitmask cache ("" = do not cache).
+func (m *gpuMirror) searchExactKeyed(c *Collection, args SearchArgs, filterKey string) (results []SearchResult, ok bool) {
+	m.mu.RLock()
+	stale := m.dirty
+	m.mu.RUnlock()
+	if stale {
+		// the caller holds only c.mutex.RLock: other searches may be inside the library right
+		// now.  The mirror's own lock makes the reload exclusive; whoever gets it first reloads.
+		m.mu.Lock()
+		var err error
+		if m.dirty {
+			err = m.reload(c)
+		}
+		m.mu.Unlock()
+		if err != nil {
 			return nil, false
 		}
 	}
-	if len(args.Vector) != c.DimensionCount || len(m.ids) == 0 {
-		return nil, len(m.ids) == 0 // empty collection: no results (collection_test.go:294-309)
+	m.mu.RLock()
+	defer m.mu.RUnlock()
+	if len(m.ids) == 0 {
+		return make([]SearchResult, 0), true // empty collection: no results, [] not null (collection_test.go:294-309)
+	}
+	if len(args.Vector) != c.DimensionCount {
+		return nil, false
 	}
 	var allow *C.uint64_t
 	var keep []C.uint64_t
 	if args.Filter != nil {
-		keep = m.allowBits(c, args.Filter)
+		keep = m.allowBitsKeyed(c, args.Filter, filterKey)
 		allow = &keep[0]
 	}
 	q := (*C.double)(unsafe.Pointer(&args.Vector[0]))

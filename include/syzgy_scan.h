@@ -188,10 +188,13 @@ typedef struct szg_stats {
     uint64_t mq_launches;      /* shared (multi-query) sweeps; each is also one scan launch */
     uint64_t mq_queries;       /* queries answered through shared sweeps */
     uint64_t mq_fallbacks;     /* shared-sweep batches redone through the score matrix (candidate buffer overflow) */
-    /* host CPU time of szg_search_topk outside any wait for the device (always measured):
-     * query preparation + enqueueing, and result assembly (gather, certification, heap replay) */
+    /* host time of szg_search_topk outside the waits for results (always measured): query
+     * preparation (swizzle / digit planes, first-k rows), the HIP calls that enqueue a batch
+     * (copies, launches, events: these can block on a full queue), and result assembly
+     * (gather, certification, heap replay) */
     double host_prep_us;
     double host_finish_us;
+    double host_enqueue_us;
 } szg_stats;
 
 /* Per-kernel HIP-event timing on the library's own streams (off by default). */

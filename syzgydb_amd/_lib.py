@@ -56,6 +56,7 @@ class SzgStats(ctypes.Structure):
         ("mq_fallbacks", ctypes.c_uint64),
         ("host_prep_us", ctypes.c_double),
         ("host_finish_us", ctypes.c_double),
+        ("host_enqueue_us", ctypes.c_double),
     ]
 
 

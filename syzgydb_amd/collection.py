@@ -86,6 +86,13 @@ class Collection:
         # collection does, so they are kept per (filter key, collection version)
         self._version = 0
         self._mask_cache = {}
+        # Rows are kept in the reference's deterministic visit order -- sort.Strings of the
+        # decimal ids (spanfile.go:540-560) -- because that order decides ties at the k boundary
+        # (collection.go:608).  A new id that sorts after every loaded one is appended in place;
+        # any other marks the mirror dirty and the next Search re-pages it in order (the same
+        # rule as go/syzgy_gpu.go).
+        self._last_idstr = ""
+        self._dirty = False
 
     @classmethod
     def from_spanfile(cls, path, devices=None):
@@ -102,7 +109,30 @@ class Collection:
                 c._row_of[int(id)] = row
                 c._id_of.append(int(id))
                 c._meta.append(pg.metadata(row))
+                c._last_idstr = str(int(id))
         return c
+
+    def _note_appended(self, id):
+        """Row order bookkeeping for a new id appended at the end of the mirror."""
+        s = str(id)
+        if s < self._last_idstr:
+            self._dirty = True
+        else:
+            self._last_idstr = s
+
+    def _resort(self):
+        """Re-page the live rows in sorted decimal-string id order (reload of the mirror)."""
+        live = sorted((str(id), id, row) for id, row in self._row_of.items())
+        data = self._index.read_rows(0, self._index.rows) if self._index.rows else None
+        rows = [row for _, _, row in live]
+        new_meta = [self._meta[r] for r in rows]
+        self._index.load(data[rows] if rows else np.zeros((0, self._index.row_bytes), np.uint8))
+        self._id_of = [id for _, id, _ in live]
+        self._meta = new_meta
+        self._row_of = {id: i for i, id in enumerate(self._id_of)}
+        self._last_idstr = live[-1][0] if live else ""
+        self._dirty = False
+        self._version += 1  # rows are renumbered: cached filter masks no longer apply
 
     # -- CRUD (host bookkeeping + mirror maintenance) ---------------------------
     def AddDocument(self, id: int, vector, metadata: bytes = b""):
@@ -123,6 +153,7 @@ class Collection:
             self._row_of[id] = len(self._id_of)
             self._id_of.append(id)
             self._meta.append(bytes(metadata))
+            self._note_appended(id)
 
     def AddDocuments(self, ids, vectors, metadatas=None):
         """Bulk ingest (not in the reference; same effect as AddDocument in a loop for new ids)."""
@@ -140,6 +171,7 @@ class Collection:
             self._row_of[i] = len(self._id_of)
             self._id_of.append(i)
             self._meta.append(bytes(metadatas[j]) if metadatas else b"")
+            self._note_appended(i)
 
     def GetDocument(self, id: int) -> Document:
         row = self._row_of.get(int(id))
@@ -244,6 +276,8 @@ class Collection:
                 if args.Limit > 0 and len(results) >= args.Limit:
                     break
         else:
+            if self._dirty:
+                self._resort()
             q = np.asarray(args.Vector, dtype=np.float64).reshape(-1)
             if q.size != self.DimensionCount:
                 # undefined in the reference (collection.go:814, :823); rejected here

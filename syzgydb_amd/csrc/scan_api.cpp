@@ -58,6 +58,29 @@ int fail(int code, const char *what, hipError_t e = hipSuccess)
     catch (const std::bad_alloc &) { return fail(SZG_E_NOMEM, "out of memory (host)"); } \
     catch (...) { return fail(SZG_E_DEVICE, "unexpected exception"); }
 
+// SZG_DEBUG_TIMERS=1: host time per call site of the enqueue path, printed when a handle is
+// destroyed (development aid: which HIP call blocks)
+struct SiteTimers {
+    static constexpr int N = 12;
+    double us[N] = {0};
+    uint64_t n[N] = {0};
+    const char *name[N] = {"h2d queries", "ev_up+wait", "ev_scan0", "scan launches", "ev_scan1", "ev_done+wait",
+                           "merges", "rerank", "d2h", "sentinels", "ev_all", "other"};
+    bool on = getenv("SZG_DEBUG_TIMERS") != nullptr;
+};
+SiteTimers g_sites;
+struct SiteScope {
+    int i;
+    std::chrono::steady_clock::time_point t0;
+    explicit SiteScope(int i_) : i(i_) { if (g_sites.on) t0 = std::chrono::steady_clock::now(); }
+    ~SiteScope()
+    {
+        if (!g_sites.on) return;
+        g_sites.us[i] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        g_sites.n[i]++;
+    }
+};
+
 int64_t row_bytes_of(int bits, int dim)
 {   // getVectorSize, collection.go:796-811
     switch (bits) {
@@ -622,10 +645,16 @@ int enqueue_queries(szg_index *ix, Shard *sh, Ctx *c, const double *q, int nq, c
 {
     HIPCHK(hipSetDevice(sh->device));
     memcpy(c->h_q64, q, sizeof(double) * ix->dim * nq);
-    if (ix->timing) HIPCHK(hipEventRecord(c->ev_all0, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_qsw, c->h_qsw, ix->qsw_bytes * nq, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_q64, c->h_q64, sizeof(double) * ix->dim * nq, hipMemcpyHostToDevice,
-                          c->stream));
+    if (ix->timing) {
+        SiteScope t_(10);
+        HIPCHK(hipEventRecord(c->ev_all0, c->stream));
+    }
+    {
+        SiteScope t_(0);
+        HIPCHK(hipMemcpyAsync(c->d_qsw, c->h_qsw, ix->qsw_bytes * nq, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_q64, c->h_q64, sizeof(double) * ix->dim * nq, hipMemcpyHostToDevice,
+                              c->stream));
+    }
     if (masks) {
         const size_t words = shard_words(sh);
         int rc = ensure_dev(&c->d_allow, &c->allow_cap, words * nq);
@@ -681,18 +710,27 @@ int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg
         std::lock_guard<std::mutex> lk(sh->chain_mu);
         hipStream_t st = ix->serialize_scans ? sh->scan_stream : c->stream;
         if (st != c->stream) {
+            SiteScope t_(1);
             HIPCHK(hipEventRecord(c->ev_up, c->stream));
             HIPCHK(hipStreamWaitEvent(st, c->ev_up, 0));
         }
-        if (ix->timing) HIPCHK(hipEventRecord(c->ev_scan0, st));
-        for (int j = 0; j < n; j++)
-            HIPCHK(szg::launch_scan(ix->bits, ix->metric, a[j], g.grid, g.block, st));
         if (ix->timing) {
+            SiteScope t_(2);
+            HIPCHK(hipEventRecord(c->ev_scan0, st));
+        }
+        {
+            SiteScope t_(3);
+            for (int j = 0; j < n; j++)
+                HIPCHK(szg::launch_scan(ix->bits, ix->metric, a[j], g.grid, g.block, st));
+        }
+        if (ix->timing) {
+            SiteScope t_(4);
             HIPCHK(hipEventRecord(c->ev_scan1, st));
             c->timed_scan = true;
             c->timed_n = n;
         }
         if (st != c->stream) {
+            SiteScope t_(5);
             HIPCHK(hipEventRecord(c->ev_scan_done, st));
             HIPCHK(hipStreamWaitEvent(c->stream, c->ev_scan_done, 0));
         }
@@ -762,16 +800,28 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
     int n_lists = g.grid;
     uint64_t *src = c->d_lists_a, *dst = c->d_lists_b;
     const int fan = szg::merge_fan(kp);
-    while (n_lists > 1) {
-        HIPCHK(szg::launch_merge(src, n_lists, kp, nq, dst, c->stream));
-        n_lists = (n_lists + fan - 1) / fan;
-        std::swap(src, dst);
+    {
+        SiteScope t_(6);
+        while (n_lists > 1) {
+            HIPCHK(szg::launch_merge(src, n_lists, kp, nq, dst, c->stream));
+            n_lists = (n_lists + fan - 1) / fan;
+            std::swap(src, dst);
+        }
     }
-    HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, src,
-                              nullptr, (uint32_t)kp, nq, c->d_out, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp * nq,
-                          hipMemcpyDeviceToHost, c->stream));
-    if (ix->timing) HIPCHK(hipEventRecord(c->ev_all1, c->stream));
+    {
+        SiteScope t_(7);
+        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, src,
+                                  nullptr, (uint32_t)kp, nq, c->d_out, c->stream));
+    }
+    {
+        SiteScope t_(8);
+        HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp * nq,
+                              hipMemcpyDeviceToHost, c->stream));
+    }
+    if (ix->timing) {
+        SiteScope t_(10);
+        HIPCHK(hipEventRecord(c->ev_all1, c->stream));
+    }
     return SZG_OK;
 }
 
@@ -1259,6 +1309,7 @@ int enqueue_sentinels(szg_index *ix, Shard *sh, Ctx *c, const std::vector<std::v
         most = std::max(most, n);
     }
     if (most == 0) return SZG_OK;
+    SiteScope t_(9);
     HIPCHK(hipSetDevice(sh->device));
     const size_t total = most * (size_t)nq;
     int rc = ensure_host(&c->h_sent, &c->h_sent_cap, total);
@@ -1587,6 +1638,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 else first_eligible_rows(ix, masks[j], k, &sent[j]);
             }
         }
+        const double t_enq0 = now_us();
         for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
             Shard *sh = ix->shards[s];
             if (sh->n_rows == 0) continue;
@@ -1603,7 +1655,9 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
         }
         {
             std::lock_guard<std::mutex> lk(ix->stats_mu);
-            ix->stats.host_prep_us += now_us() - t_prep0;
+            const double t_end = now_us();
+            ix->stats.host_prep_us += t_enq0 - t_prep0;
+            ix->stats.host_enqueue_us += t_end - t_enq0;
         }
         t.failed = rc != SZG_OK;  // nothing to gather: finish() only drains and releases
         inflight.push_back(std::move(t));
@@ -1914,6 +1968,13 @@ int szg_index_create(szg_index **out, int dim, int quant_bits, int metric, const
 void szg_index_destroy(szg_index *ix)
 {
     if (!ix) return;
+    if (g_sites.on) {
+        for (int i = 0; i < SiteTimers::N; i++)
+            if (g_sites.n[i])
+                fprintf(stderr, "[szg sites] %-14s %10.1f us / %8llu calls = %7.2f us\n", g_sites.name[i], g_sites.us[i],
+                        (unsigned long long)g_sites.n[i], g_sites.us[i] / (double)g_sites.n[i]);
+        g_sites = SiteTimers{};
+    }
     for (Shard *sh : ix->shards) {
         (void)hipSetDevice(sh->device);
         (void)hipDeviceSynchronize();

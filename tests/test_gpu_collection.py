@@ -415,3 +415,41 @@ def test_concurrent_single_queries_are_coalesced():
         st = ix.stats()
         assert not bad and st["queries"] == 320
         assert st["mq_queries"] > 0          # some callers shared a sweep
+
+
+def test_tie_order_follows_sorted_string_ids_after_appends():
+    """The reference's deterministic exact scan visits records in sort.Strings order of their
+    decimal ids (spanfile.go:540-560) and the first visited wins a tie at the k boundary
+    (collection.go:608).  Documents added later, in any id order, must not change that: the
+    mirror appends an id that sorts last and re-pages itself in order otherwise (the rule
+    go/syzgy_gpu.go follows too)."""
+    dim, bits = 4, 8
+    rng = np.random.default_rng(11)
+    base = rng.uniform(-1, 1, (3, dim))
+    ids = [5, 40, 100, 2, 31, 7, 1000, 12, 3, 64, 9, 77, 8, 200, 30, 6]     # "100" < "2" < "31" ...
+    vec = {id: base[i % 3] for i, id in enumerate(ids)}                      # many exactly equal rows
+    q = base[1] + 0.01
+    for metric in (Euclidean, Cosine):
+        c = Collection(CollectionOptions(Name="ties", DistanceMethod=metric, DimensionCount=dim,
+                                         Quantization=bits))
+        loaded = []
+        for step, id in enumerate(ids):
+            c.AddDocument(id, vec[id], b"m%d" % id)
+            loaded.append(id)
+            if step in (2, 7, len(ids) - 1):
+                order = sorted(loaded, key=str)                                # the reference's visit order
+                rows = orc.encode_rows(np.stack([vec[i] for i in order]), bits)
+                for k in (1, 2, 4, 5):
+                    want_rows, want_d, _ = orc.search_exact(rows, dim, bits, metric, q, k=k)
+                    got = c.Search(SearchArgs(Vector=q, K=k, Precision="exact"))
+                    assert [r.ID for r in got.Results] == [order[int(r)] for r in want_rows], (metric, step, k)
+                    assert [r.Distance for r in got.Results] == list(want_d)
+        # removal keeps the order of the rest; a re-add of the removed id lands in its sorted place
+        c.removeDocument(31)
+        c.AddDocument(31, vec[31], b"again")
+        order = sorted(loaded, key=str)
+        rows = orc.encode_rows(np.stack([vec[i] for i in order]), bits)
+        want_rows, want_d, _ = orc.search_exact(rows, dim, bits, metric, q, k=6)
+        got = c.Search(SearchArgs(Vector=q, K=6, Precision="exact"))
+        assert [r.ID for r in got.Results] == [order[int(r)] for r in want_rows]
+        c.Close()
