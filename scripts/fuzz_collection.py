@@ -49,7 +49,7 @@ while time.time() < t_end:
                 c.UpdateDocument(id, meta)
                 model[id] = (model[id][0], meta)
             else:
-                live = [i for i in order if i is not None]
+                live = sorted(model, key=str)   # the reference's deterministic visit order (spanfile.go:540-560)
                 rows = np.stack([model[i][0] for i in live]) if live else np.zeros((0, 1), np.uint8)
                 flt = None
                 if rng.random() < 0.4:

@@ -40,6 +40,9 @@ struct WaveList {
     uint64_t *lds;    // this wave's kp entries in LDS (always allocated: the block merge reads it)
     uint64_t mine;    // register form: entry `lane` (kp <= 64)
     uint64_t worst;   // current kp-th best (wave-uniform)
+    float worst_key;  // its key as a float (+inf while the list is not full): the scan's cheap pre-filter --
+                      // a row whose key is above it cannot enter the list; anything else (NaN included)
+                      // takes the exact 64-bit path
     int kp;
     bool in_regs;
 
@@ -50,6 +53,7 @@ struct WaveList {
         in_regs = kp_ <= 64;
         mine = kInvalidCand;
         worst = kInvalidCand;
+        worst_key = __builtin_inff();
         if (!in_regs)
             for (int i = lane; i < kp; i += 64) lds[i] = kInvalidCand;
     }
@@ -90,12 +94,14 @@ struct WaveList {
     __device__ __forceinline__ void offer(bool have, uint64_t c, int lane)
     {
         uint64_t m = __ballot(have && c < worst);
+        if (!m) return;
         while (m) {
             const int src = __ffsll((long long)m) - 1;
             m &= m - 1;
             const uint64_t cc = shfl_u64(c, src);
             if (cc < worst) insert(cc, lane);
         }
+        worst_key = worst == kInvalidCand ? __builtin_inff() : key_from_ordered((uint32_t)(worst >> 32));
     }
 
     // make the LDS copy current (before the block-wide merge)

@@ -102,6 +102,7 @@ struct ScanArgs {
     float qscale[kMaxSweepsPerLaunch], qconst[kMaxSweepsPerLaunch], qnorm2[kMaxSweepsPerLaunch];
     double norm_bias;
     int no_shape_kernels;       // tuning hook: always take the any-shape kernel
+    int ring;                   // tuning hook: >= 8 forces the deep ring (0 = chosen from kp)
     int mask_dense;             // masked sweep that reads every row and applies the masks at the row finish
                                 // (most rows pass); 0 = rows are tested before their loads are issued
     int kp;                     // candidates kept per list (top-k mode)

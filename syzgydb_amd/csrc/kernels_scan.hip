@@ -28,13 +28,14 @@ namespace szg {
 namespace {
 
 constexpr int kWave = 64;
-#ifndef SZG_RING
-#define SZG_RING 8
-#endif
 #ifndef SZG_MIN_BLOCKS
-#define SZG_MIN_BLOCKS 4  // 256-thread blocks per CU the register budget allows
+#define SZG_MIN_BLOCKS 3  // 256-thread blocks per CU the register budget allows: the sweeps run 2-3 per CU
+                          // (scan_geometry), and 168 registers keep every variant free of spills (at 128
+                          // the deep-ring and row-unrolled kernels spilled 2-59 registers)
 #endif
-[[maybe_unused]] constexpr int kRing = SZG_RING;
+#ifndef SZG_QPF
+#define SZG_QPF 0  // integer paths: fetch the query's digit planes of the NEXT piece from LDS before this piece's dots
+#endif
 [[maybe_unused]] constexpr int kStepList = 256;  // row steps a wave compacts at a time (selective masks)  // 16-byte loads each lane keeps in flight
 
 template <int QBITS>
@@ -136,8 +137,11 @@ __device__ __forceinline__ uint32_t grp_or(uint32_t v, const Grp &g)
 template <int QBITS, int METRIC>
 struct RowAcc {
     using acc_t = typename Traits<QBITS>::acc_t;
+    static constexpr bool kPrefetch = false;
     acc_t a0, a1;
     uint32_t nz;
+    __device__ __forceinline__ void fetch(const uint8_t *, int, int) {}
+    __device__ __forceinline__ void piece_pf(const uint4, const uint8_t *, int, int) {}
     __device__ __forceinline__ void reset()
     {
         a0 = 0;
@@ -234,12 +238,25 @@ struct RowAcc {
 // the query's quantization (bounded on the host, key_eps).
 template <int METRIC>
 struct RowAcc<8, METRIC> {
+    static constexpr bool kPrefetch = SZG_QPF != 0;
     int H, M, L, SQ, SV;
+    uint4 ph, pm, pl;  // digit planes of the piece about to be multiplied (dense phase, fetched one piece ahead)
     __device__ __forceinline__ void reset() { H = M = L = SQ = SV = 0; }
-    __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const int r16, const int dim)
+    __device__ __forceinline__ void fetch(const uint8_t *q, int j, int r16)
     {
         const uint4 *q4 = reinterpret_cast<const uint4 *>(q);
-        const uint4 qh = q4[j], qm = q4[r16 + j], ql = q4[2 * r16 + j];
+        ph = q4[j];
+        pm = q4[r16 + j];
+        pl = q4[2 * r16 + j];
+    }
+    __device__ __forceinline__ void piece_pf(const uint4 raw, const uint8_t *q, int jnext, const int r16)
+    {
+        const uint4 qh = ph, qm = pm, ql = pl;
+        fetch(q, jnext, r16);
+        mul(raw, qh, qm, ql);
+    }
+    __device__ __forceinline__ void mul(const uint4 raw, const uint4 qh, const uint4 qm, const uint4 ql)
+    {
         const uint32_t w[4] = {raw.x ^ 0x80808080u, raw.y ^ 0x80808080u, raw.z ^ 0x80808080u,
                                raw.w ^ 0x80808080u};
         const uint32_t h[4] = {qh.x, qh.y, qh.z, qh.w};
@@ -253,6 +270,11 @@ struct RowAcc<8, METRIC> {
             SQ = __builtin_amdgcn_sdot4((int)w[d], (int)w[d], SQ, false);
             SV = __builtin_amdgcn_sdot4((int)w[d], 0x01010101, SV, false);
         }
+    }
+    __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const int r16, const int dim)
+    {
+        const uint4 *q4 = reinterpret_cast<const uint4 *>(q);
+        mul(raw, q4[j], q4[r16 + j], q4[2 * r16 + j]);
     }
     __device__ __forceinline__ float finish(const QConst &a, const Grp &g, bool lead)
     {
@@ -274,13 +296,28 @@ struct RowAcc<8, METRIC> {
 // seven VALU ops per eight elements, no nibble unpacking.
 template <int METRIC>
 struct RowAcc<4, METRIC> {
+    static constexpr bool kPrefetch = SZG_QPF != 0;
     int D0, D1, D2, D3, D4, SQ, SV;
+    uint4 pp0, pp1, pp2, pp3, pp4;  // digit planes fetched one piece ahead (dense phase)
     __device__ __forceinline__ void reset() { D0 = D1 = D2 = D3 = D4 = SQ = SV = 0; }
-    __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const int r16, const int dim)
+    __device__ __forceinline__ void fetch(const uint8_t *q, int j, int r16)
     {
         const uint4 *q4 = reinterpret_cast<const uint4 *>(q);
-        const uint4 p0 = q4[j], p1 = q4[r16 + j], p2 = q4[2 * r16 + j], p3 = q4[3 * r16 + j],
-                    p4 = q4[4 * r16 + j];
+        pp0 = q4[j];
+        pp1 = q4[r16 + j];
+        pp2 = q4[2 * r16 + j];
+        pp3 = q4[3 * r16 + j];
+        pp4 = q4[4 * r16 + j];
+    }
+    __device__ __forceinline__ void piece_pf(const uint4 raw, const uint8_t *q, int jnext, const int r16)
+    {
+        const uint4 a0 = pp0, a1 = pp1, a2 = pp2, a3 = pp3, a4 = pp4;
+        fetch(q, jnext, r16);
+        mul(raw, a0, a1, a2, a3, a4);
+    }
+    __device__ __forceinline__ void mul(const uint4 raw, const uint4 p0, const uint4 p1, const uint4 p2,
+                                        const uint4 p3, const uint4 p4)
+    {
         const uint32_t w[4] = {raw.x ^ 0x88888888u, raw.y ^ 0x88888888u, raw.z ^ 0x88888888u,
                                raw.w ^ 0x88888888u};
         const uint32_t q0[4] = {p0.x, p0.y, p0.z, p0.w}, q1[4] = {p1.x, p1.y, p1.z, p1.w},
@@ -297,10 +334,23 @@ struct RowAcc<4, METRIC> {
             SV = __builtin_amdgcn_sdot8((int)w[d], 0x11111111, SV, false);
         }
     }
+    __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const int r16, const int dim)
+    {
+        const uint4 *q4 = reinterpret_cast<const uint4 *>(q);
+        mul(raw, q4[j], q4[r16 + j], q4[2 * r16 + j], q4[3 * r16 + j], q4[4 * r16 + j]);
+    }
+    // INT_OK: a lane's share of the row is short enough (<= 12 pieces) for the weighted plane sum
+    // to stay inside int32 (|digit| <= 8, |v''| <= 8, 32 elements per piece): combine the planes
+    // exactly with four shift-adds and convert once.
+    template <bool INT_OK = false>
     __device__ __forceinline__ float finish(const QConst &a, const Grp &g, bool lead)
     {
-        float dot = fmaf(65536.0f, (float)D4,
-                         fmaf(4096.0f, (float)D3, fmaf(256.0f, (float)D2, fmaf(16.0f, (float)D1, (float)D0))));
+        float dot;
+        if (INT_OK)
+            dot = (float)(D0 + (D1 << 4) + (D2 << 8) + (D3 << 12) + (D4 << 16));
+        else
+            dot = fmaf(65536.0f, (float)D4,
+                       fmaf(4096.0f, (float)D3, fmaf(256.0f, (float)D2, fmaf(16.0f, (float)D1, (float)D0))));
         int nrm = 4 * (SQ + SV);
         dot = grp_sum(dot, g);
         nrm = grp_sum(nrm, g);
@@ -385,16 +435,27 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
 
     // One row is done: reduce the group's L lanes, form the key, select.
     const Grp grp_info{L, lig, LL ? true : a.map.pow2 != 0};
+    // The common case after warm-up -- no row of the step can enter the list -- costs one float
+    // compare and one wave-uniform branch; clamping, the ordered 64-bit candidate and the exact
+    // comparison happen only behind it.
+    [[maybe_unused]] const float thr_key = COLLECT ? key_from_ordered(a.thr_ukey) : 0.0f;
     auto finish_row = [&](uint64_t row0, bool valid, RowAcc<QBITS, METRIC> &acc) {
-        float key = acc.finish(qc, grp_info, valid && lig == 0);
+        float key;
+        if constexpr (QBITS == 4 && LL != 0 && PP <= 12)
+            key = acc.template finish<true>(qc, grp_info, valid && lig == 0);
+        else
+            key = acc.finish(qc, grp_info, valid && lig == 0);
+        const bool leader = valid && lig == 0;
+        // !(key > t): at or below the threshold, or NaN (which the slow path turns into the worst finite key)
+        const bool maybe = leader && !(key > (COLLECT ? thr_key : wl.worst_key));
+        if (!__ballot(maybe)) return;
         if (!(key == key)) key = 3.0e38f;       // NaN: worst finite
         if (key > 3.0e38f) key = 3.0e38f;       // +inf (overflow): worst finite
         const uint32_t row = (uint32_t)(row0 + grp);
         const uint64_t c = ((uint64_t)ordered_key(key) << 32) | row;
-        const bool leader = valid && lig == 0;
 
         if (COLLECT) {
-            const bool hit = leader && (uint32_t)(c >> 32) <= a.thr_ukey;
+            const bool hit = maybe && (uint32_t)(c >> 32) <= a.thr_ukey;
             const uint64_t m = __ballot(hit);
             if (m) {
                 const int first = __ffsll((long long)m) - 1;
@@ -407,7 +468,7 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
                 }
             }
         } else {
-            wl.offer(leader, c, lane);
+            wl.offer(maybe, c, lane);
         }
     };
 
@@ -497,6 +558,45 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
         }                                                                               \
     }
 
+// Row-shape kernels whose ring depth divides the pieces per lane: the steady state is unrolled
+// over one whole ROW (P pieces, slot = piece % D), so every slot sits at a fixed piece of the
+// row -- the row-finish test, the row jump of the issue cursor and the query offsets are
+// compile-time facts and no per-piece branch is left.  The rows left over (< D + P pieces
+// from the end) drain through the guarded tail loop.
+#define SZG_RUN_RING_ROWS(NPX, ISSUE, CONSUME)                                          \
+    {                                                                                   \
+        const uint64_t np_ = (NPX);                                                     \
+        uint64_t issued_ = D, consumed_ = 0;                                            \
+        _Pragma("unroll") for (int u = 0; u < D; u++)                                   \
+        {                                                                               \
+            ISSUE(u)                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                          \
+        }                                                                               \
+        while (consumed_ + D + PP <= np_) {                                             \
+            _Pragma("unroll") for (int p_ = 0; p_ < PP; p_++)                           \
+            {                                                                           \
+                CONSUME(p_ % D)                                                         \
+                ISSUE(p_ % D)                                                           \
+                __builtin_amdgcn_sched_barrier(0);                                      \
+            }                                                                           \
+            consumed_ += PP;                                                            \
+            issued_ += PP;                                                              \
+        }                                                                               \
+        while (consumed_ < np_) {                                                       \
+            _Pragma("unroll") for (int u = 0; u < D; u++)                               \
+            {                                                                           \
+                if (consumed_ < np_) {                                                  \
+                    CONSUME(u)                                                          \
+                    consumed_++;                                                        \
+                    if (issued_ < np_) {                                                \
+                        ISSUE(u)                                                        \
+                        issued_++;                                                      \
+                    }                                                                   \
+                }                                                                       \
+            }                                                                           \
+        }                                                                               \
+    }
+
     // ---- dense phase: no masks, L*P == r16, gpw*L == 64, every group's row in
     // range.  No predicates at all: pointer-increment addressing, unconditional
     // accumulation.  Covers all but (at most) the wave's last row step.
@@ -514,6 +614,7 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
         const uint64_t row_jump = (a.tiled ? (stride >> 4) * ((uint64_t)a.steps * 1024) : stride * (uint64_t)a.pitch) -
                                   (uint64_t)(P - 1) * piece_step;
         int ip = 0, cp = 0, jc = lig;
+        acc.fetch(smem, lig, r16);
 #define SZG_DN_ISSUE(u)                                                                 \
     {                                                                                   \
         ring[u] = load_piece<NT>(iptr);                                                     \
@@ -527,7 +628,10 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
 #define SZG_DN_CONSUME(u)                                                               \
     {                                                                                   \
         const u32x4 v_ = ring[u];                                                       \
-        acc.piece(make_uint4(v_.x, v_.y, v_.z, v_.w), smem, jc, r16, a.dim);                     \
+        if constexpr (RowAcc<QBITS, METRIC>::kPrefetch)                                 \
+            acc.piece_pf(make_uint4(v_.x, v_.y, v_.z, v_.w), smem, cp + 1 == P ? lig : jc + L, r16); \
+        else                                                                            \
+            acc.piece(make_uint4(v_.x, v_.y, v_.z, v_.w), smem, jc, r16, a.dim);        \
         if (++cp == P) {                                                                \
             finish_row(crow0, dense_valid(crow0), acc);                                 \
             acc.reset();                                                                \
@@ -538,7 +642,10 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
             jc += L;                                                                    \
         }                                                                               \
     }
-        SZG_RUN_RING_DENSE(it_dense * (uint64_t)P, SZG_DN_ISSUE, SZG_DN_CONSUME)
+        if constexpr (LL != 0 && PP % D == 0)
+            SZG_RUN_RING_ROWS(it_dense * (uint64_t)P, SZG_DN_ISSUE, SZG_DN_CONSUME)
+        else
+            SZG_RUN_RING_DENSE(it_dense * (uint64_t)P, SZG_DN_ISSUE, SZG_DN_CONSUME)
 #undef SZG_DN_ISSUE
 #undef SZG_DN_CONSUME
     }
@@ -649,6 +756,7 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
     }
 #undef SZG_RUN_RING
 #undef SZG_RUN_RING_DENSE
+#undef SZG_RUN_RING_ROWS
 
     if (COLLECT) continue;
 
@@ -767,49 +875,68 @@ __global__ __launch_bounds__(1024) void merge_kernel(const uint64_t *in, int n_l
 #endif  // SZG_QBITS == 0
 
 #if SZG_QBITS != 0
-// Row shapes (lanes per row, pieces per lane) that get their own kernels.  Only the 4-bit
-// rows gain from it: their rows are short (3 pieces per lane at 384 and 768 dims, choose_map
-// in scan_api.cpp), so the shape-dependent bookkeeping around each row finish weighs 5-11 %.
-// The shapes of 8/16/32-bit rows at those widths, (8,3) (8,6) (8,12) (8,24), measured no gain
-// (scripts/dev_shape.sh) and stay on the any-shape kernel.
-template <int QBITS> struct Shapes {
-    [[maybe_unused]] static constexpr int LA = 0, PA = 0, LB = 0, PB = 0;
-};
-template <> struct Shapes<4> {  // tiled 4-bit rows: L = 4, P = r16 / 4 (384 and 768 dims)
-    [[maybe_unused]] static constexpr int LA = 4, PA = 3, LB = 4, PB = 6;
-};
+// Ring depth.  HBM streams fastest with about 6-9 MB of reads in flight on the chip
+// (scripts/readbw; deeper queues only lengthen the DRAM queues), so the ring is kept SHORT:
+// 4 loads per lane for the any-shape kernels (8 when the candidate lists live in LDS, kp > 64,
+// whose inserts stall longer).  Measured on one box, ring 8 -> 4: 1M x 768 f32 7.04 -> 7.12 TB/s,
+// 4M x 768 8-bit 6.75 -> 6.97, 12.5M x 384 4-bit 6.31 -> 6.57.
+//
+// Row-shape kernels: lanes per row L, pieces per lane P and a ring depth D that DIVIDES P are
+// compile-time constants, so after unrolling the ring every slot sits at a fixed position of
+// the row: the row-finish test, the query offsets and the row jump are folded, no per-piece
+// branch is left (12.5M x 384 4-bit with D = P = 3: 6.31 -> 6.77 TB/s).
+#ifdef SZG_RING
+constexpr int kRingShort = SZG_RING, kRingDeep = SZG_RING;
+#define SZG_SHAPE_RING(d) SZG_RING
+#else
+constexpr int kRingShort = 4, kRingDeep = 8;
+#define SZG_SHAPE_RING(d) d
+#endif
 
-template <int QBITS, int METRIC, bool COLLECT, int LL, int PP>
-void launch_shaped(const ScanArgs &a, dim3 g, dim3 b, size_t lds, hipStream_t stream)
+template <int QBITS, int METRIC, bool COLLECT, int LL, int PP, int D>
+hipError_t launch_shaped(const ScanArgs &a, dim3 g, dim3 b, size_t lds, hipStream_t stream)
 {
     if (LL >= 8 || a.tiled)
-        hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, COLLECT, false, true, LL, PP>), g, b, lds, stream, a);
+        hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, D, COLLECT, false, true, LL, PP>), g, b, lds, stream, a);
     else
-        hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, COLLECT, false, false, LL, PP>), g, b, lds, stream, a);
+        hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, D, COLLECT, false, false, LL, PP>), g, b, lds, stream, a);
+    return hipGetLastError();
+}
+
+template <int QBITS, int METRIC, bool COLLECT, bool MASKED, int D>
+hipError_t launch_any_shape(const ScanArgs &a, dim3 g, dim3 b, size_t lds, hipStream_t stream)
+{
+    if (a.map.L >= 8 || a.tiled)  // whole lines per load instruction: stream past the caches
+        hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, D, COLLECT, MASKED, true>), g, b, lds, stream, a);
+    else
+        hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, D, COLLECT, MASKED, false>), g, b, lds, stream, a);
+    return hipGetLastError();
 }
 
 template <int QBITS, int METRIC, bool COLLECT, bool MASKED>
 hipError_t launch_scan_qmcm(const ScanArgs &a, int grid, int block, size_t lds, hipStream_t stream)
 {
     const dim3 g(grid), b(block);
-    if constexpr (!MASKED && Shapes<QBITS>::LA != 0) {
-        using S = Shapes<QBITS>;
-        if (a.map.dense && a.map.L * a.map.gpw == kWave && !a.no_shape_kernels) {
-            if (a.map.L == S::LA && a.map.P == S::PA) {
-                launch_shaped<QBITS, METRIC, COLLECT, S::LA, S::PA>(a, g, b, lds, stream);
-                return hipGetLastError();
+    const bool deep = (!COLLECT && a.kp > 64) || a.ring >= 8;
+    if constexpr (!MASKED) {
+        if (a.map.dense && a.map.L * a.map.gpw == kWave && !a.no_shape_kernels && !deep) {
+            const int L = a.map.L, P = a.map.P;
+#define SZG_TRY_SHAPE(l, p, d)                                                                 \
+    if (L == l && P == p) return launch_shaped<QBITS, METRIC, COLLECT, l, p, SZG_SHAPE_RING(d)>(a, g, b, lds, stream);
+            if constexpr (QBITS == 4) {   // tiled rows walk 4 lanes per row: 384 / 768 dims
+                SZG_TRY_SHAPE(4, 3, 3)
+                SZG_TRY_SHAPE(4, 6, 6)
+            } else if constexpr (QBITS == 8) {
+                SZG_TRY_SHAPE(4, 6, 6)
+                SZG_TRY_SHAPE(4, 12, 4)
+            } else if constexpr (QBITS == 32) {   // linear rows, 8 lanes per row; (8, 24) unrolled over a whole
+                SZG_TRY_SHAPE(8, 12, 4)           // row spills registers and measured slower than any-shape
             }
-            if (a.map.L == S::LB && a.map.P == S::PB) {
-                launch_shaped<QBITS, METRIC, COLLECT, S::LB, S::PB>(a, g, b, lds, stream);
-                return hipGetLastError();
-            }
+#undef SZG_TRY_SHAPE
         }
     }
-    if (a.map.L >= 8 || a.tiled)  // whole lines per load instruction: stream past the caches
-        hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, COLLECT, MASKED, true>), g, b, lds, stream, a);
-    else
-        hipLaunchKernelGGL((scan_kernel<QBITS, METRIC, kRing, COLLECT, MASKED, false>), g, b, lds, stream, a);
-    return hipGetLastError();
+    if (deep) return launch_any_shape<QBITS, METRIC, COLLECT, MASKED, kRingDeep>(a, g, b, lds, stream);
+    return launch_any_shape<QBITS, METRIC, COLLECT, MASKED, kRingShort>(a, g, b, lds, stream);
 }
 
 template <int QBITS, int METRIC>

@@ -290,6 +290,7 @@ struct szg_index {
     int block_threads = 256;
     int query_batch = 16;     // queries per scan launch
     int shape_kernels = 1;    // use the row-shape-specialised scan kernels where they exist
+    int ring = 0;             // tuning hook: 8 = always the deep piece ring
     int queries_per_launch = 16;  // sweeps one scan launch walks back to back (query-major)
     int force_escalate = 0;   // test hook: treat every first pass as uncertified
     int tie_mode = 0;         // 0: exact full replay on ties/NaN, 1: keep the fast answer
@@ -698,6 +699,7 @@ void fill_scan_args(const szg_index *ix, const Shard *sh, const Ctx *c, bool has
     }
     a->norm_bias = ix->norm_bias;
     a->no_shape_kernels = ix->shape_kernels ? 0 : 1;
+    a->ring = ix->ring;
 }
 
 // Launch the fused scan for each of the batch's queries (n = a->size()) as the
@@ -2591,6 +2593,9 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
         ix->block_threads = (int)value;
     } else if (n == "shape_kernels") {
         ix->shape_kernels = value != 0;
+    } else if (n == "ring") {
+        if (value != 0 && value != 8) return fail(SZG_E_INVALID, "ring must be 0 (auto) or 8 (deep)");
+        ix->ring = (int)value;
     } else if (n == "queries_per_launch") {
         if (value < 1 || value > szg::kMaxSweepsPerLaunch)
             return fail(SZG_E_INVALID, "queries_per_launch out of range");
