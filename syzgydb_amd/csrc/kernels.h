@@ -63,13 +63,24 @@ struct RowMap {
     int dense; // L*P == r16 and gpw*L == 64: every lane always has a piece of a row
 };
 
+// 4-bit rows, single-query scan: the query is quantized to balanced int4 digit planes of radix
+// 16.  kPlanes4 digits carry |Q| < 16^kPlanes4 / 2; every plane costs one v_dot8_i32_i4 per
+// dword of the row and one 16-byte LDS read per piece.  The quantization step enters the
+// certification bound (key_eps) -- 4 planes (15 bits) still certify: the bound grows to
+// ~4e-5 in cosine units against gaps of ~1e-2 between the k-th and the kp-th best key.
+#ifndef SZG_PLANES4
+#define SZG_PLANES4 4
+#endif
+constexpr int kPlanes4 = SZG_PLANES4;
+constexpr double kQmax4 = kPlanes4 == 5 ? 480000.0 : 30000.0;
+
 // Bytes of one prepared query as the scan stages it in LDS: float32 (float64 for
 // 64-bit rows) per element, or integer digit planes of 16 bytes per piece for the
 // exact-integer paths (3 int8 planes for 8-bit rows, 5 int4 planes for 4-bit rows).
 __host__ __device__ inline size_t query_lds_bytes(int qbits, int r16)
 {
     switch (qbits) {
-    case 4: return (size_t)r16 * 16 * 5;
+    case 4: return (size_t)r16 * 16 * kPlanes4;
     case 8: return (size_t)r16 * 16 * 3;
     case 16: return (size_t)r16 * 8 * 4;
     case 32: return (size_t)r16 * 4 * 4;

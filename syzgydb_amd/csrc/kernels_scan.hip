@@ -297,39 +297,39 @@ struct RowAcc<8, METRIC> {
 template <int METRIC>
 struct RowAcc<4, METRIC> {
     static constexpr bool kPrefetch = SZG_QPF != 0;
-    int D0, D1, D2, D3, D4, SQ, SV;
-    uint4 pp0, pp1, pp2, pp3, pp4;  // digit planes fetched one piece ahead (dense phase)
-    __device__ __forceinline__ void reset() { D0 = D1 = D2 = D3 = D4 = SQ = SV = 0; }
+    int D[kPlanes4], SQ, SV;
+    uint4 pp[kPlanes4];  // digit planes fetched one piece ahead (dense phase, SZG_QPF)
+    __device__ __forceinline__ void reset()
+    {
+#pragma unroll
+        for (int x = 0; x < kPlanes4; x++) D[x] = 0;
+        SQ = SV = 0;
+    }
     __device__ __forceinline__ void fetch(const uint8_t *q, int j, int r16)
     {
         const uint4 *q4 = reinterpret_cast<const uint4 *>(q);
-        pp0 = q4[j];
-        pp1 = q4[r16 + j];
-        pp2 = q4[2 * r16 + j];
-        pp3 = q4[3 * r16 + j];
-        pp4 = q4[4 * r16 + j];
+#pragma unroll
+        for (int x = 0; x < kPlanes4; x++) pp[x] = q4[x * r16 + j];
     }
     __device__ __forceinline__ void piece_pf(const uint4 raw, const uint8_t *q, int jnext, const int r16)
     {
-        const uint4 a0 = pp0, a1 = pp1, a2 = pp2, a3 = pp3, a4 = pp4;
+        uint4 cur[kPlanes4];
+#pragma unroll
+        for (int x = 0; x < kPlanes4; x++) cur[x] = pp[x];
         fetch(q, jnext, r16);
-        mul(raw, a0, a1, a2, a3, a4);
+        mul(raw, cur);
     }
-    __device__ __forceinline__ void mul(const uint4 raw, const uint4 p0, const uint4 p1, const uint4 p2,
-                                        const uint4 p3, const uint4 p4)
+    __device__ __forceinline__ void mul(const uint4 raw, const uint4 (&p)[kPlanes4])
     {
         const uint32_t w[4] = {raw.x ^ 0x88888888u, raw.y ^ 0x88888888u, raw.z ^ 0x88888888u,
                                raw.w ^ 0x88888888u};
-        const uint32_t q0[4] = {p0.x, p0.y, p0.z, p0.w}, q1[4] = {p1.x, p1.y, p1.z, p1.w},
-                       q2[4] = {p2.x, p2.y, p2.z, p2.w}, q3[4] = {p3.x, p3.y, p3.z, p3.w},
-                       q4w[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
         for (int d = 0; d < 4; d++) {
-            D0 = __builtin_amdgcn_sdot8((int)q0[d], (int)w[d], D0, false);
-            D1 = __builtin_amdgcn_sdot8((int)q1[d], (int)w[d], D1, false);
-            D2 = __builtin_amdgcn_sdot8((int)q2[d], (int)w[d], D2, false);
-            D3 = __builtin_amdgcn_sdot8((int)q3[d], (int)w[d], D3, false);
-            D4 = __builtin_amdgcn_sdot8((int)q4w[d], (int)w[d], D4, false);
+#pragma unroll
+            for (int x = 0; x < kPlanes4; x++) {
+                const uint32_t qd = d == 0 ? p[x].x : d == 1 ? p[x].y : d == 2 ? p[x].z : p[x].w;
+                D[x] = __builtin_amdgcn_sdot8((int)qd, (int)w[d], D[x], false);
+            }
             SQ = __builtin_amdgcn_sdot8((int)w[d], (int)w[d], SQ, false);
             SV = __builtin_amdgcn_sdot8((int)w[d], 0x11111111, SV, false);
         }
@@ -337,20 +337,28 @@ struct RowAcc<4, METRIC> {
     __device__ __forceinline__ void piece(const uint4 raw, const uint8_t *q, int j, const int r16, const int dim)
     {
         const uint4 *q4 = reinterpret_cast<const uint4 *>(q);
-        mul(raw, q4[j], q4[r16 + j], q4[2 * r16 + j], q4[3 * r16 + j], q4[4 * r16 + j]);
+        uint4 p[kPlanes4];
+#pragma unroll
+        for (int x = 0; x < kPlanes4; x++) p[x] = q4[x * r16 + j];
+        mul(raw, p);
     }
     // INT_OK: a lane's share of the row is short enough (<= 12 pieces) for the weighted plane sum
     // to stay inside int32 (|digit| <= 8, |v''| <= 8, 32 elements per piece): combine the planes
-    // exactly with four shift-adds and convert once.
+    // exactly with shift-adds and convert once.
     template <bool INT_OK = false>
     __device__ __forceinline__ float finish(const QConst &a, const Grp &g, bool lead)
     {
         float dot;
-        if (INT_OK)
-            dot = (float)(D0 + (D1 << 4) + (D2 << 8) + (D3 << 12) + (D4 << 16));
-        else
-            dot = fmaf(65536.0f, (float)D4,
-                       fmaf(4096.0f, (float)D3, fmaf(256.0f, (float)D2, fmaf(16.0f, (float)D1, (float)D0))));
+        if (INT_OK) {
+            int t = D[kPlanes4 - 1];
+#pragma unroll
+            for (int x = kPlanes4 - 2; x >= 0; x--) t = (t << 4) + D[x];
+            dot = (float)t;
+        } else {
+            dot = (float)D[kPlanes4 - 1];
+#pragma unroll
+            for (int x = kPlanes4 - 2; x >= 0; x--) dot = fmaf(16.0f, dot, (float)D[x]);
+        }
         int nrm = 4 * (SQ + SV);
         dot = grp_sum(dot, g);
         nrm = grp_sum(nrm, g);

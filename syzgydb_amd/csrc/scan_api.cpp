@@ -392,7 +392,7 @@ void prep_query(const szg_index *ix, const double *q, uint8_t *out_sw, QMeta *me
     meta->qnorm = std::sqrt(nrm);
     meta->qnorm2 = nrm;
     if (bits == 8 || bits == 4) {
-        const double Qmax = bits == 8 ? 1000000.0 : 480000.0;
+        const double Qmax = bits == 8 ? 1000000.0 : szg::kQmax4;
         const double qs = (vmax > 0 && std::isfinite(vmax)) ? vmax / Qmax : 1.0;
         meta->qscale = qs;
         double sumQ = 0.0;
@@ -417,9 +417,9 @@ void prep_query(const szg_index *ix, const double *q, uint8_t *out_sw, QMeta *me
                 // byte b of the piece holds element 2b in its high nibble, 2b+1 in the low one
                 const int bb = i / 2, d = bb / 4, kb = bb % 4;
                 const int t4 = 2 * kb + ((i % 2 == 0) ? 1 : 0);
-                for (int x = 0; x < 5; x++) {  // plane x carries the digit of weight 16^x
+                for (int x = 0; x < szg::kPlanes4; x++) {  // plane x carries the digit of weight 16^x
                     long long dig;
-                    if (x < 4) {
+                    if (x < szg::kPlanes4 - 1) {
                         dig = ((Q + 8) & 15) - 8;
                         Q = (Q - dig) >> 4;
                     } else {
@@ -477,7 +477,7 @@ double key_eps(const szg_index *ix, double key, const QMeta &m)
         // absolute error <= 16*2^-24 * qscale*Qmax*V*dim in units of sum v n.
         const double M = (double)((1u << ix->bits) - 1u);
         const double V = ix->bits == 8 ? 128.0 : 8.0;
-        const double Qmax = ix->bits == 8 ? 1000000.0 : 480000.0;
+        const double Qmax = ix->bits == 8 ? 1000000.0 : szg::kQmax4;
         const double fl = 16.0 * 0x1p-24 * m.qscale * Qmax * V * (double)ix->dim;
         if (ix->metric == SZG_COSINE)  // divided by |n| >= sqrt(dim) (every n is odd)
             return 0.5 * m.qscale * std::sqrt((double)ix->dim) + fl / std::sqrt((double)ix->dim) + 0x1p-21;
