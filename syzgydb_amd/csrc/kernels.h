@@ -90,6 +90,16 @@ __host__ __device__ inline size_t query_lds_bytes(int qbits, int r16)
 
 constexpr int kMaxSweepsPerLaunch = 16;
 
+// Exact integer shared sweep (mq_score_i8_kernel): the query as kMqPlanes balanced int8 digit
+// planes of radix 128.  Every plane costs one MFMA and one 16-byte LDS read per query block
+// and 64-byte row step; 2 planes (|Q| <= 16000, ~14 bits) keep the certification bound at
+// ~2e-4 in cosine units, still far inside the gap between the k-th and the kp-th best key.
+#ifndef SZG_MQ_PLANES
+#define SZG_MQ_PLANES 2
+#endif
+constexpr int kMqPlanes = SZG_MQ_PLANES;
+constexpr double kMqQmax = kMqPlanes == 2 ? 16000.0 : 1000000.0;
+
 // per-query constants of the integer paths, as the row finish consumes them
 struct QConst {
     float qscale, qconst, qnorm2, norm_bias;
@@ -157,12 +167,16 @@ struct MqArgs {
     int collect;
     const float *thr;            // [n_queries]
     uint64_t *cand_buf;          // [n_queries][cand_cap]  (ordered key << 32 | row)
-    uint32_t *cand_count;        // [n_queries]; may exceed cand_cap (then the batch is redone)
+    uint32_t *cand_count;        // [n_queries * kCandCountStride]; may exceed cand_cap (then the batch is redone)
     uint32_t cand_cap;
     const uint64_t *live_bits;   // nullable
     const uint64_t *allow_bits;  // nullable, per query
     uint32_t allow_stride;
 };
+// Hit counters of the fused selection sit one per 128-byte line: the waves claim their slots
+// with returning atomics, mostly at the end of the sweep, and atomics on one line serialise
+// (~12 ns each) -- 48 counters in two lines made a 46 us tail on a 190 us sweep.
+constexpr int kCandCountStride = 32;  // 32-bit words
 // thr[q] = key of the kp-th entry of query q's sorted list (3.0e38 if the list is shorter)
 hipError_t launch_mq_thr(const uint64_t *lists, int kp, int n_queries, float *thr, hipStream_t stream);
 // per query: the kp best of its candidate buffer, sorted, as one list [n_queries][kp]

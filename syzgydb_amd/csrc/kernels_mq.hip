@@ -38,7 +38,14 @@ namespace szg {
 
 namespace {
 
-[[maybe_unused]] constexpr int kRingMq = 6;
+#ifndef SZG_MQ_RING
+#define SZG_MQ_RING 4  // 16-byte loads per lane in flight (4 vs 6: -1.5 % on the int8 sweeps, no change on f32)
+#endif
+#ifndef SZG_MQ8_WAVES
+#define SZG_MQ8_WAVES 12  // waves per block (one block per CU) of the int8 sweep
+#endif
+[[maybe_unused]] constexpr int kRingMq = SZG_MQ_RING;
+[[maybe_unused]] constexpr int kMq8Threads = 64 * SZG_MQ8_WAVES;
 
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -48,6 +55,13 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // later -- a non-temporal hint evicts it first (measured 1.22x HBM over-fetch)
 __device__ __forceinline__ u32x4 load_nt(const uint8_t *p)
 {
+    return *reinterpret_cast<const u32x4 *>(p);
+}
+// tiled rows (4- and 8-bit): a wave instruction reads one whole KiB that is used once per
+// sweep -- stream it past the caches (measured on the 8-bit sweep: 199 -> 182 us)
+__device__ __forceinline__ u32x4 load_stream(const uint8_t *p, bool nt)
+{
+    if (nt) return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
     return *reinterpret_cast<const u32x4 *>(p);
 }
 
@@ -105,7 +119,7 @@ __device__ __forceinline__ void hit_flush(const MqArgs &a, HitBuf &hb, int lane)
         if (a.live_bits) ok = (a.live_bits[r >> 6] >> (r & 63)) & 1;
         if (ok && a.allow_bits) ok = (a.allow_bits[(size_t)q * a.allow_stride + (r >> 6)] >> (r & 63)) & 1;
         if (ok) {
-            const uint32_t idx = atomicAdd(a.cand_count + q, 1u);
+            const uint32_t idx = atomicAdd(a.cand_count + q * kCandCountStride, 1u);
             if (idx < a.cand_cap) a.cand_buf[(size_t)q * a.cand_cap + idx] = c;
         }
     }
@@ -128,6 +142,37 @@ __device__ __forceinline__ void hit_offer(const MqArgs &a, HitBuf &hb, int lane,
         hb.query[pos] = (uint8_t)q;
     }
     hb.n += cnt;
+}
+
+// OR of a 32-bit value over the wave (uniform result): four DPP steps inside each row of 16
+// lanes, then the four rows through scalar registers
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);  // row_mirror
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+// The tile finish of the fused-selection sweeps.  A tile yields NB x 4 (query, row) keys per lane;
+// almost none of them is at or below its query's threshold.  All keys are formed first (pure
+// VALU work), the lanes' hit bits are OR-ed over the wave, and only the (query block, register)
+// slots that hold a hit somewhere go through hit_offer: one wave-uniform branch per tile in the
+// common case instead of one ballot and branch per slot.
+template <int NB>
+__device__ __forceinline__ void offer_tile_hits(const MqArgs &a, HitBuf &hb, int lane, int c, uint32_t hm,
+                                                const float (&keys)[NB][4], uint64_t row)
+{
+    if (!__ballot(hm != 0)) return;
+    const uint32_t un = wave_or_u32(hm);
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (un & (1u << (b * 4 + r)))
+                hit_offer(a, hb, lane, (hm >> (b * 4 + r)) & 1u, b * 16 + c * 4 + r, row, keys[b][r]);
 }
 
 #if SZG_MQ_PART >= 4
@@ -328,8 +373,15 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
         // D layout of the 16x16 product: column = lane & 15 (the tile's row),
         // row = (lane >> 4) * 4 + reg (the query inside its block of 16)
         if (COLLECT || row < a.n_rows) {
+            float keys[NB][4];
+            uint32_t hm = 0;
+            const bool row_ok = row < a.n_rows;
 #pragma unroll
             for (int b = 0; b < NB; b++) {
+                // the four queries of this lane in block b are consecutive: one 16-byte LDS read
+                const float4 th = COLLECT ? *reinterpret_cast<const float4 *>(thr_lds + b * 16 + c * 4)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float thv[4] = {th.x, th.y, th.z, th.w};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int q = b * 16 + c * 4 + r;
@@ -342,12 +394,14 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
                     }
                     if (!(key == key)) key = 3.0e38f;
                     if (key > 3.0e38f) key = 3.0e38f;
+                    keys[b][r] = key;
                     if (COLLECT)
-                        hit_offer(a, hb, lane, row < a.n_rows && q < a.n_queries && key <= thr_lds[q], q, row, key);
+                        hm |= (row_ok && q < a.n_queries && key <= thv[r]) ? (1u << (b * 4 + r)) : 0u;
                     else if (q < a.n_queries)
                         a.keys[(size_t)q * a.key_stride + row] = key;
                 }
             }
+            if (COLLECT) offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row);
         }
         // gfx9 counts loads and stores in ONE vmcnt and they retire out of order with
         // respect to each other, so with a key store possibly pending the compiler can only
@@ -424,16 +478,20 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 // comes from two v_dot4_i32_i8 per dword.  The finish is RowAcc<8>::finish's, so the key
 // and its error bound (key_eps, integer branch) are the single-query path's.
 typedef int v4i32 __attribute__((ext_vector_type(4)));
+#ifndef SZG_ABL
+#define SZG_ABL 0  // timing experiments (answers become wrong): bit 0 no tile finish, bit 1 no norm dots, bit 2 no MFMA
+#endif
 
 template <int NB, int METRIC, bool COLLECT, bool FAST = false, int RB = 8>
-__global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
+__global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a)
 {
     // RB = 8: one B operand per 16-byte piece (the bytes, xor 0x80).  RB = 4: two -- the
     // high nibbles (even elements) and the low nibbles (odd elements) as unsigned bytes
     // 0..15, against the digit planes of the even / odd elements; n = 2x - 15 turns
     // sum Q x into sum Q n on the host side of the constants table.
     constexpr int T = RB == 4 ? 2 : 1;
-    constexpr bool PF = RB == 8;  // prefetch the A operands one step ahead (register budget)
+    constexpr int NPL = kMqPlanes;  // digit planes of the query (radix 128)
+    constexpr bool PF = RB == 8 || NPL <= 2;  // prefetch the A operands one step ahead (register budget)
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -443,7 +501,7 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
     const int steps = (r16 + 3) / 4;  // 64-byte steps per row
     const RowLayout mlay{a.pitch, a.tiled, a.steps};
     const uint32_t istep = a.tiled ? 1024u : 64u;  // bytes from one 64-byte step of a row to the next
-    const int n16 = steps * 3 * T * NB * 64;  // image, 16-byte words
+    const int n16 = steps * NPL * T * NB * 64;  // image, 16-byte words
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -452,7 +510,8 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
         if (COLLECT && tid < 48)
             reinterpret_cast<float *>(smem + (size_t)n * 16)[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
     }
-    __syncthreads();
+    // (the barrier that publishes the image comes after the ring's first loads have been issued:
+    // the rows do not depend on it, and a 140 us sweep notices a 5 us start-up)
     const v4i32 *qimg = reinterpret_cast<const v4i32 *>(smem);
     const float *qtab = reinterpret_cast<const float *>(smem + (size_t)n16 * 16);
     const float *thr_lds = qtab + 3 * 48;
@@ -478,23 +537,15 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
     int cs = 0;
 
     u32x4 ring[kRingMq];
-    v4i32 acc[3][NB];
+    v4i32 acc[NPL][NB];
 #pragma unroll
-    for (int p = 0; p < 3; p++)
+    for (int p = 0; p < NPL; p++)
 #pragma unroll
         for (int b = 0; b < NB; b++) acc[p][b] = v4i32{0, 0, 0, 0};
     int SQ = 0, SV = 0;
-    const int qstep8 = 3 * T * NB * 64;  // 16-byte words of the image per 64-byte step
+    const int qstep8 = NPL * T * NB * 64;  // 16-byte words of the image per 64-byte step
     // A operands of the step about to be multiplied (fetched one step ahead when PF)
-    v4i32 qn[3][T][NB];
-    if (PF) {
-#pragma unroll
-        for (int p = 0; p < 3; p++)
-#pragma unroll
-            for (int t = 0; t < T; t++)
-#pragma unroll
-                for (int b = 0; b < NB; b++) qn[p][t][b] = qimg[((p * T + t) * NB + b) * 64 + lane];
-    }
+    v4i32 qn[NPL][T][NB];
 
     // FAST (r16 % 4 == 0): no range predicates, addresses advance by constants
     auto row_ptr = [&](uint64_t tile) -> const uint8_t * {
@@ -505,7 +556,7 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
 
 #define MQ8F_ISSUE(u)                                                                    \
     {                                                                                    \
-        ring[u] = load_nt(iptr);                                                         \
+        ring[u] = load_stream(iptr, a.tiled != 0);                                       \
         if (++is == steps) {                                                             \
             is = 0;                                                                      \
             itile += tile_stride;                                                        \
@@ -546,10 +597,10 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
                 bop_[T - 1][d] = in_ ? (int)(raw_[d] & 0x0F0F0F0Fu) : 0;                 \
             }                                                                            \
         }                                                                                \
-        v4i32 qc_[3][T][NB];                                                             \
+        v4i32 qc_[NPL][T][NB];                                                            \
         const int qcur_ = lane + cs * qstep8;                                            \
         const int qnext_ = lane + (cs + 1 == steps ? 0 : cs + 1) * qstep8;               \
-        _Pragma("unroll") for (int p = 0; p < 3; p++)                                    \
+        _Pragma("unroll") for (int p = 0; p < NPL; p++)                                   \
             _Pragma("unroll") for (int t = 0; t < T; t++)                                \
                 _Pragma("unroll") for (int b = 0; b < NB; b++)                           \
                 {                                                                        \
@@ -561,9 +612,13 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
                     }                                                                    \
                 }                                                                        \
         _Pragma("unroll") for (int t = 0; t < T; t++)                                    \
-            _Pragma("unroll") for (int p = 0; p < 3; p++)                                \
+            _Pragma("unroll") for (int p = 0; p < NPL; p++)                               \
                 _Pragma("unroll") for (int b = 0; b < NB; b++)                           \
-                    acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qc_[p][t][b], bop_[t], acc[p][b], 0, 0, 0); \
+                {                                                                        \
+                    if (SZG_ABL & 4) { asm volatile("" :: "v"(qc_[p][t][b]), "v"(bop_[t])); }          \
+                    else acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qc_[p][t][b], bop_[t], acc[p][b], 0, 0, 0); \
+                }                                                                        \
+        if (!(SZG_ABL & 2))                                                              \
         _Pragma("unroll") for (int d = 0; d < 4; d++)                                    \
         {                                                                                \
             if (RB == 8) {                                                               \
@@ -575,7 +630,8 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
             }                                                                            \
         }                                                                                \
         if (++cs == steps) {                                                             \
-            finish_tile8(ctile);                                                         \
+            if (SZG_ABL & 1) { asm volatile("" :: "v"(acc[0][0]), "v"(SQ), "v"(SV)); }  \
+            else finish_tile8(ctile);                                                    \
             cs = 0;                                                                      \
             ctile += tile_stride;                                                        \
         }                                                                                \
@@ -591,31 +647,47 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
         const float inv = __frsqrt_rn(norm);
         const uint64_t row = tile * 16 + trow;
         if (COLLECT || row < a.n_rows) {
+            float keys[NB][4];
+            uint32_t hm = 0;
+            const bool row_ok = row < a.n_rows;
 #pragma unroll
             for (int b = 0; b < NB; b++) {
+                // this lane's four queries of block b are consecutive: 16-byte reads of the tables
+                const int q0 = b * 16 + c * 4;
+                const float4 qs4 = *reinterpret_cast<const float4 *>(qtab + q0);
+                const float4 qc4 = *reinterpret_cast<const float4 *>(qtab + 48 + q0);
+                const float4 qn4 = METRIC == kCosine ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                                     : *reinterpret_cast<const float4 *>(qtab + 96 + q0);
+                const float4 th4 = COLLECT ? *reinterpret_cast<const float4 *>(thr_lds + q0)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float qsv[4] = {qs4.x, qs4.y, qs4.z, qs4.w}, qcv[4] = {qc4.x, qc4.y, qc4.z, qc4.w};
+                const float qnv[4] = {qn4.x, qn4.y, qn4.z, qn4.w}, thv[4] = {th4.x, th4.y, th4.z, th4.w};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int q = b * 16 + c * 4 + r;
-                    const float dot = fmaf(16384.0f, (float)acc[0][b][r],
-                                           fmaf(128.0f, (float)acc[1][b][r], (float)acc[2][b][r]));
-                    const float d2 = fmaf(2.0f, dot, qtab[48 + q]);  // sum Q n
+                    const int q = q0 + r;
+                    float dot = (float)acc[0][b][r];  // plane 0 = the top digit
+#pragma unroll
+                    for (int p = 1; p < NPL; p++) dot = fmaf(128.0f, dot, (float)acc[p][b][r]);
+                    const float d2 = fmaf(2.0f, dot, qcv[r]);  // sum Q n
                     float key;
                     if (METRIC == kCosine)
-                        key = -(d2 * qtab[q]) * inv;
+                        key = -(d2 * qsv[r]) * inv;
                     else
-                        key = fmaf(-2.0f * qtab[q], d2, qtab[96 + q] + norm);
-                    if (!(key == key)) key = 3.0e38f;
-                    if (key > 3.0e38f) key = 3.0e38f;
+                        key = fmaf(-2.0f * qsv[r], d2, qnv[r] + norm);
+                    // (finite by construction: integer sums, norm >= dim > 0 -- no NaN / inf clamps)
+                    keys[b][r] = key;
                     if (COLLECT)
-                        hit_offer(a, hb, lane, row < a.n_rows && q < a.n_queries && key <= thr_lds[q], q, row, key);
+                        hm |= (row_ok && key <= thv[r]) ? (1u << (b * 4 + r)) : 0u;  // unused queries: thr = -3e38
                     else if (q < a.n_queries)
                         a.keys[(size_t)q * a.key_stride + row] = key;
                 }
             }
+            if (SZG_ABL & 8) { asm volatile("" :: "v"(hm), "v"(keys[0][0])); }  // timing experiment: keys formed, hits dropped
+            else if (COLLECT) offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row);
         }
         if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores (see mq_score_kernel)
 #pragma unroll
-        for (int p = 0; p < 3; p++)
+        for (int p = 0; p < NPL; p++)
 #pragma unroll
             for (int b = 0; b < NB; b++) acc[p][b] = v4i32{0, 0, 0, 0};
         SQ = 0;
@@ -629,6 +701,13 @@ __global__ __launch_bounds__(768) void mq_score_i8_kernel(const MqArgs a)
         {                                                                                \
             ISSUE(u)                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                           \
+        }                                                                                \
+        __syncthreads(); /* the query image is complete */                               \
+        if (PF) {                                                                        \
+            _Pragma("unroll") for (int p = 0; p < NPL; p++)                              \
+                _Pragma("unroll") for (int t = 0; t < T; t++)                            \
+                    _Pragma("unroll") for (int b = 0; b < NB; b++)                       \
+                        qn[p][t][b] = qimg[((p * T + t) * NB + b) * 64 + lane];          \
         }                                                                                \
         while (consumed + 2 * kRingMq <= NP) {                                           \
             _Pragma("unroll") for (int u = 0; u < kRingMq; u++)                          \
@@ -715,7 +794,7 @@ __global__ __launch_bounds__(256) void mq_select_kernel(const float *keys, size_
         if (tid == 0) {
             const uint64_t c = out[kp - 1];
             thr_out[q] = c == kInvalidCand ? 3.0e38f : key_from_ordered((uint32_t)(c >> 32));
-            count_zero[q] = 0;
+            count_zero[q * kCandCountStride] = 0;
         }
     }
 }
@@ -740,7 +819,7 @@ __global__ __launch_bounds__(256) void cand_select_kernel(const uint64_t *cand_b
     WaveList wl;
     wl.init(wl_lds + (size_t)wave * kp, kp, lane);
     __syncthreads();
-    const uint32_t n = min(cand_count[q], cand_cap);
+    const uint32_t n = min(cand_count[q * kCandCountStride], cand_cap);
     const uint64_t *src = cand_buf + (size_t)q * cand_cap;
     for (uint32_t i = tid; i < ((n + blockDim.x - 1) / blockDim.x) * blockDim.x; i += blockDim.x) {
         const bool ok = i < n;
@@ -844,11 +923,11 @@ hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStre
 
 size_t mq_i8_image_bytes(int row_bits, int r16, int nb)
 {
-    return (size_t)((r16 + 3) / 4) * 3 * (row_bits == 4 ? 2 : 1) * nb * 1024;
+    return (size_t)((r16 + 3) / 4) * kMqPlanes * (row_bits == 4 ? 2 : 1) * nb * 1024;
 }
 size_t mq_i8_lds_bytes(int row_bits, int r16, int nb)
 {   // + constants, thresholds, the 12 waves' hit buffers
-    return mq_i8_image_bytes(row_bits, r16, nb) + 4 * 48 * sizeof(float) + (size_t)12 * 64 * 9;
+    return mq_i8_image_bytes(row_bits, r16, nb) + 4 * 48 * sizeof(float) + (size_t)SZG_MQ8_WAVES * 64 * 9;
 }
 hipError_t launch_mq_score_i8_rows8(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
 hipError_t launch_mq_score_i8_rows4(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
@@ -871,7 +950,7 @@ hipError_t launch_mq_score_i8_t(const MqArgs &a, int grid, size_t lds, hipStream
         reinterpret_cast<const void *>(&mq_score_i8_kernel<NB, METRIC, COLLECT, FAST, kRowBits>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mq_score_i8_kernel<NB, METRIC, COLLECT, FAST, kRowBits>), dim3(grid), dim3(768), lds,
+    hipLaunchKernelGGL((mq_score_i8_kernel<NB, METRIC, COLLECT, FAST, kRowBits>), dim3(grid), dim3(kMq8Threads), lds,
                        stream, a);
     return hipGetLastError();
 }

@@ -165,10 +165,10 @@ struct QMeta {
     double qconst = 0;  // integer paths: sum Q_i
     double qnorm2 = 0;  // euclid: sum g_i^2 of the prepared query g
     bool mq = false;    // answered by the shared float32 MFMA sweep (its own error bound)
-    // 4-bit rows through the int8 shared sweep: the query as int8 digit planes of
-    // Q_i = round(v_i / mq_qscale), |Q| <= 1e6 (the single-query path's int4 planes stay
+    // the int8 shared sweep (8- and 4-bit rows): the query as kMqPlanes int8 digit planes of
+    // Q_i = round(v_i / mq_qscale), |Q| <= kMqQmax (the single-query path's own planes stay
     // in qscale / qconst for the escalation sweep)
-    bool mq_int4 = false;
+    bool mq_int = false;
     double mq_qscale = 0, mq_qconst = 0;
 };
 
@@ -460,9 +460,11 @@ double key_eps(const szg_index *ix, double key, const QMeta &m)
         const double s = 2.0 * m.qnorm + std::sqrt(k);
         return 1.5 * n * u * s * s + 1e-30;
     }
-    if (m.mq_int4) {
-        // as the integer branch below with Qmax = 1e6 and the row operand x = nibble in 0..15
-        const double M = 15.0, V = 16.0, Qmax = 1000000.0;
+    if (m.mq_int) {
+        // as the integer branch below with the sweep's own quantization step; the row operand is
+        // v' = v - 128 (8-bit rows) or the nibble x in 0..15 (4-bit rows)
+        const double M = (double)((1u << ix->bits) - 1u);
+        const double V = ix->bits == 8 ? 128.0 : 16.0, Qmax = szg::kMqQmax;
         const double fl = 16.0 * 0x1p-24 * m.mq_qscale * Qmax * V * (double)ix->dim;
         if (ix->metric == SZG_COSINE)
             return 0.5 * m.mq_qscale * std::sqrt((double)ix->dim) + fl / std::sqrt((double)ix->dim) + 0x1p-21;
@@ -838,13 +840,13 @@ double mq_int_scale(const szg_index *ix, double m1)
     return (double)((1u << ix->bits) - 1u);
 }
 
-// 4-bit rows, int8 sweep: quantization step, the integer query Q (dim values) and its digit sum
-void prep_mq_int4(const szg_index *ix, const double *q, QMeta *meta, int32_t *Qout)
+// int8 sweep: quantization step, the integer query Q (dim values) and its digit sum
+void prep_mq_int(const szg_index *ix, const double *q, QMeta *meta, int32_t *Qout)
 {
     const double scale = mq_int_scale(ix, meta->m1);
     double vmax = 0.0;
     for (int e = 0; e < ix->dim; e++) vmax = std::max(vmax, std::fabs(q[e] * scale));
-    const double Qmax = 1000000.0;
+    const double Qmax = szg::kMqQmax;
     const double qs = (vmax > 0 && std::isfinite(vmax)) ? vmax / Qmax : 1.0;
     const double inv = scale / qs;
     long long sumQ = 0;
@@ -853,7 +855,7 @@ void prep_mq_int4(const szg_index *ix, const double *q, QMeta *meta, int32_t *Qo
         Qout[e] = (int32_t)Q;
         sumQ += Q;
     }
-    meta->mq_int4 = true;
+    meta->mq_int = true;
     meta->mq_qscale = qs;
     meta->mq_qconst = (double)sumQ;
 }
@@ -884,56 +886,38 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     rc = ensure_dev(&c->d_mq, &c->d_mq_cap, img);
     if (rc) return rc;
     memset(c->h_mq, 0, img);
-    if (i8 && ix->bits == 8) {
-        // [64-byte step][digit plane][query block][lane = chunk*16 + query][16 bytes] from the
-        // planes prep_query wrote ([plane][piece][16 bytes]), then [qscale | qconst | qnorm2][48]
-        const int steps = (r16 + 3) / 4;
+    if (i8) {
+        // [64-byte step][digit plane h..l][T halves][query block][lane = chunk*16 + query][16 bytes] of the
+        // int8 digits of Q = round(v / mq_qscale), then the table [qscale | qconst | qnorm2][48].
+        // 8-bit rows (T = 1): byte i of a lane's word belongs to element 16*piece + i; the row
+        // operand is v' = v - 128 and n = 2v' + 1, so sum Q n = 2 sum Q v' + sum Q.
+        // 4-bit rows (T = 2: even | odd elements): byte bi belongs to element 32*piece + 2*bi
+        // (+1 for the odd half); the operand is the nibble x and n = 2x - 15.
+        const int NP = szg::kMqPlanes, T = ix->bits == 4 ? 2 : 1;
+        const int epp = ix->bits == 4 ? 32 : 16;  // elements per 16-byte piece
         uint8_t *im8 = c->h_mq;
-        for (int q = 0; q < nq; q++) {
-            const uint8_t *pl = c->h_qsw + (size_t)q * ix->qsw_bytes;
-            const int b = q / 16, qi = q % 16;
-            for (int s = 0; s < steps; s++)
-                for (int p = 0; p < 3; p++)
-                    for (int ch = 0; ch < 4; ch++) {
-                        const int j = s * 4 + ch;
-                        if (j >= r16) continue;
-                        memcpy(im8 + ((((size_t)s * 3 + p) * nb + b) * 64 + ch * 16 + qi) * 16,
-                               pl + ((size_t)p * r16 + j) * 16, 16);
-                    }
-        }
-        float *tab = reinterpret_cast<float *>(c->h_mq + szg::mq_i8_image_bytes(8, r16, nb));
-        for (int q = 0; q < nq && q < 48; q++) {
-            tab[q] = (float)c->meta[q].qscale;
-            tab[48 + q] = (float)c->meta[q].qconst;
-            tab[96 + q] = (float)c->meta[q].qnorm2;
-        }
-    } else if (i8) {
-        // 4-bit rows: [step][plane][even | odd elements][query block][lane][16 bytes] of the int8
-        // digits of Q = round(v / mq_qscale); byte bi of a lane's word belongs to element
-        // 32*piece + 2*bi (+1 for the odd half).  n = 2x - 15: sum Q n = 2 sum Q x - 15 sum Q.
-        uint8_t *im8 = c->h_mq;
+        const size_t plane = (size_t)T * nb * 64 * 16;  // bytes between digit planes of a step
         for (int q = 0; q < nq; q++) {
             const int32_t *Qv = c->h_mqQ + (size_t)q * ix->dim;
             const int b = q / 16, qi = q % 16;
             for (int e = 0; e < ix->dim; e++) {
                 int Q = Qv[e];
-                const int j = e >> 5, i = e & 31, bi = i >> 1, half = i & 1;
+                const int j = e / epp, i = e % epp;
+                const int bi = T == 2 ? i >> 1 : i, half = T == 2 ? i & 1 : 0;
                 const int s = j >> 2, ch = j & 3;
-                uint8_t *dst = im8 + ((((size_t)s * 3 * 2 + half) * nb + b) * 64 + ch * 16 + qi) * 16 + bi;
-                const size_t plane = (size_t)2 * nb * 64 * 16;  // bytes between digit planes of a step
-                const int l = ((Q + 64) & 127) - 64;
-                Q = (Q - l) >> 7;
-                const int mdig = ((Q + 64) & 127) - 64;
-                Q = (Q - mdig) >> 7;
-                dst[0] = (uint8_t)(int8_t)Q;          // plane 0 = h (x16384)
-                dst[plane] = (uint8_t)(int8_t)mdig;   // plane 1 = m (x128)
-                dst[2 * plane] = (uint8_t)(int8_t)l;  // plane 2 = l
+                uint8_t *dst = im8 + ((((size_t)s * NP * T + half) * nb + b) * 64 + ch * 16 + qi) * 16 + bi;
+                for (int p = NP - 1; p > 0; p--) {   // low digits first, balanced in [-64, 63]
+                    const int dig = ((Q + 64) & 127) - 64;
+                    Q = (Q - dig) >> 7;
+                    dst[(size_t)p * plane] = (uint8_t)(int8_t)dig;
+                }
+                dst[0] = (uint8_t)(int8_t)Q;         // plane 0 = the top digit
             }
         }
-        float *tab = reinterpret_cast<float *>(c->h_mq + szg::mq_i8_image_bytes(4, r16, nb));
+        float *tab = reinterpret_cast<float *>(c->h_mq + szg::mq_i8_image_bytes(ix->bits, r16, nb));
         for (int q = 0; q < nq && q < 48; q++) {
             tab[q] = (float)c->meta[q].mq_qscale;
-            tab[48 + q] = (float)(-15.0 * c->meta[q].mq_qconst);
+            tab[48 + q] = (float)((ix->bits == 4 ? -15.0 : 1.0) * c->meta[q].mq_qconst);
             tab[96 + q] = (float)c->meta[q].qnorm2;
         }
     } else {
@@ -988,9 +972,9 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     if (rc) return rc;
     if (fused) {
         if (!c->d_thr) HIPCHK(hipMalloc((void **)&c->d_thr, 64 * sizeof(float)));
-        if (!c->d_cand_count) HIPCHK(hipMalloc((void **)&c->d_cand_count, 64 * sizeof(uint32_t)));
+        if (!c->d_cand_count) HIPCHK(hipMalloc((void **)&c->d_cand_count, 64 * szg::kCandCountStride * sizeof(uint32_t)));
         if (!c->h_cand_count)
-            HIPCHK(hipHostMalloc((void **)&c->h_cand_count, 64 * sizeof(uint32_t), hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void **)&c->h_cand_count, 64 * szg::kCandCountStride * sizeof(uint32_t), hipHostMallocDefault));
         rc = ensure_dev(&c->d_cand, &c->cand_cap_total, (size_t)cand_cap * nq);
         if (rc) return rc;
     }
@@ -1086,7 +1070,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
         if (fused) {
             HIPCHK(szg::launch_cand_select(c->d_cand, c->d_cand_count, cand_cap, kp, nq, c->d_lists_a, tail));
             src = c->d_lists_a;
-            HIPCHK(hipMemcpyAsync(c->h_cand_count, c->d_cand_count, 64 * sizeof(uint32_t),
+            HIPCHK(hipMemcpyAsync(c->h_cand_count, c->d_cand_count, 64 * szg::kCandCountStride * sizeof(uint32_t),
                                   hipMemcpyDeviceToHost, tail));
         } else {
             HIPCHK(select_chain((uint32_t)sh->n_rows, key_stride, tail, &src));
@@ -1422,7 +1406,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
             Ctx *c = t.ctx[s];
             if (rc == SZG_OK && c->mq_fused_used) {
                 bool overflow = false;
-                for (int j = 0; j < t.nq; j++) overflow |= c->h_cand_count[j] > c->mq_cand_cap;
+                for (int j = 0; j < t.nq; j++) overflow |= c->h_cand_count[j * szg::kCandCountStride] > c->mq_cand_cap;
                 c->mq_fused_used = false;
                 if (overflow) {
                     {
@@ -1509,7 +1493,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                     // (always the single-query kernel) adds its own on the rows it tests
                     QMeta single = t.meta[j];
                     single.mq = false;
-                    single.mq_int4 = false;
+                    single.mq_int = false;
                     const double e1 = key_eps(ix, (double)kmax + key_eps(ix, kmax, t.meta[j]), t.meta[j]);
                     const double e2 = key_eps(ix, (double)kmax + e1, single);
                     thr = (double)kmax + 1.05 * (e1 + e2);
@@ -1605,11 +1589,11 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
         // the batch is prepared ONCE (swizzled / digit-plane forms, constants) into the first
         // shard's staging buffers; the other shards get copies
         Ctx *c0 = nullptr;
-        const bool int4_planes = nb > 0 && mq_uses_i8(ix) && ix->bits == 4;
+        const bool int_planes = nb > 0 && mq_uses_i8(ix);
         for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
             if (ix->shards[s]->n_rows == 0) continue;
             Ctx *cx = t.ctx[s];
-            if (int4_planes && !cx->h_mqQ) {
+            if (int_planes && !cx->h_mqQ) {
                 cx->h_mqQ = (int32_t *)malloc(sizeof(int32_t) * (size_t)kMaxBatch * ix->dim);
                 if (!cx->h_mqQ) {
                     rc = fail(SZG_E_NOMEM, "host scratch");  // the ticket is still finished below
@@ -1621,13 +1605,13 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 for (int j = 0; j < t.nq; j++) {
                     prep_query(ix, q + (size_t)j * ix->dim, cx->h_qsw + (size_t)j * ix->qsw_bytes, &t.meta[j]);
                     t.meta[j].mq = nb > 0 && !mq_uses_i8(ix);  // the integer sweeps keep the integer bound
-                    if (int4_planes)
-                        prep_mq_int4(ix, q + (size_t)j * ix->dim, &t.meta[j], cx->h_mqQ + (size_t)j * ix->dim);
+                    if (int_planes)
+                        prep_mq_int(ix, q + (size_t)j * ix->dim, &t.meta[j], cx->h_mqQ + (size_t)j * ix->dim);
                     cx->meta[j] = t.meta[j];
                 }
             } else {
                 memcpy(cx->h_qsw, c0->h_qsw, ix->qsw_bytes * (size_t)t.nq);
-                if (int4_planes) memcpy(cx->h_mqQ, c0->h_mqQ, sizeof(int32_t) * (size_t)t.nq * ix->dim);
+                if (int_planes) memcpy(cx->h_mqQ, c0->h_mqQ, sizeof(int32_t) * (size_t)t.nq * ix->dim);
                 for (int j = 0; j < t.nq; j++) cx->meta[j] = t.meta[j];
             }
         }
