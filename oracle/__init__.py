@@ -87,6 +87,21 @@ def lib():
         L.orc_bench_topk_faithful.restype = ctypes.c_double
         L.orc_bench_topk_faithful.argtypes = [u8p, u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, f64p, ctypes.c_int, ctypes.c_int, u64p]
+        vp = ctypes.c_void_p
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        L.orc_lsh_build.restype = vp
+        L.orc_lsh_build.argtypes = [u8p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_uint64]
+        L.orc_lsh_free.restype = None
+        L.orc_lsh_free.argtypes = [vp]
+        L.orc_lsh_sizes.restype = None
+        L.orc_lsh_sizes.argtypes = [vp, i64p, i64p]
+        L.orc_lsh_export.restype = None
+        L.orc_lsh_export.argtypes = [vp, i32p, i32p, i32p, f64p, f64p, i64p, i32p, u64p]
+        L.orc_lsh_search.restype = ctypes.c_int64
+        L.orc_lsh_search.argtypes = [vp, ctypes.c_uint64, f64p, ctypes.c_int, ctypes.c_double, u8p, u64p, f64p,
+                                     ctypes.c_uint64, u64p, u64p]
         _lib = L
     return _lib
 
@@ -250,3 +265,55 @@ def bench_topk_faithful(rows, dim, bits, metric, queries, k, meta_len=16):
     if secs < 0:
         raise RuntimeError("faithful baseline: span failed to parse")
     return float(secs), out
+
+
+class LshForest:
+    """The reference's LSH forest (lshtree.go:102-251 insert / split rules) over packed rows,
+    built from a documented splitmix64 stream in place of Go's math/rand."""
+
+    def __init__(self, rows, dim, bits, metric, threshold=100, num_trees=5, seed=1):
+        self._rows = np.ascontiguousarray(rows, dtype=np.uint8)   # borrowed by the C side
+        self.n_rows = self._rows.size // vector_size(bits, dim)
+        self.dim, self.bits, self.metric, self.num_trees = dim, bits, metric, num_trees
+        self._h = lib().orc_lsh_build(_p(self._rows, ctypes.c_uint8), self.n_rows, dim, bits, metric, threshold,
+                                      num_trees, seed)
+        if not self._h:
+            raise ValueError("orc_lsh_build failed")
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_lsh_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def export(self):
+        """Flat arrays: dict(roots, left, right, normals, b, ids_off, ids_cnt, ids)."""
+        nn, ni = ctypes.c_int64(0), ctypes.c_int64(0)
+        lib().orc_lsh_sizes(self._h, ctypes.byref(nn), ctypes.byref(ni))
+        nn, ni = nn.value, ni.value
+        out = dict(roots=np.zeros(self.num_trees, np.int32), left=np.zeros(nn, np.int32), right=np.zeros(nn, np.int32),
+                   normals=np.zeros((nn, self.dim)), b=np.zeros(nn), ids_off=np.zeros(nn, np.int64),
+                   ids_cnt=np.zeros(nn, np.int32), ids=np.zeros(max(ni, 1), np.uint64))
+        lib().orc_lsh_export(self._h, _p(out["roots"], ctypes.c_int32), _p(out["left"], ctypes.c_int32),
+                             _p(out["right"], ctypes.c_int32), _p(out["normals"], ctypes.c_double),
+                             _p(out["b"], ctypes.c_double), _p(out["ids_off"], ctypes.c_int64),
+                             _p(out["ids_cnt"], ctypes.c_int32), _p(out["ids"], ctypes.c_uint64))
+        out["ids"] = out["ids"][:ni]
+        return out
+
+    def search(self, query, k=0, radius=0.0, allow=None):
+        """lshTree.search + consider(): (rows, dist, points_searched, visit_order)."""
+        q = _f64(query).reshape(-1)
+        cap = self.n_rows
+        out_rows = np.zeros(max(cap, 1), np.uint64)
+        out_dist = np.zeros(max(cap, 1), np.float64)
+        order = np.zeros(max(cap, 1), np.uint64)
+        searched = ctypes.c_uint64(0)
+        al = None if allow is None else np.ascontiguousarray(allow, dtype=np.uint8)
+        n = lib().orc_lsh_search(self._h, self.n_rows, _p(q, ctypes.c_double), int(k), float(radius),
+                                 _p(al, ctypes.c_uint8) if al is not None else None,
+                                 _p(out_rows, ctypes.c_uint64), _p(out_dist, ctypes.c_double), cap,
+                                 ctypes.byref(searched), _p(order, ctypes.c_uint64))
+        return out_rows[:n], out_dist[:n], int(searched.value), order[:int(searched.value)]

@@ -9,6 +9,7 @@
  */
 #include "syzgy_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
@@ -629,4 +630,343 @@ double orc_bench_topk_faithful(const uint8_t *spans, const uint64_t *offsets, ui
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* ------------------------------------------------------------- LSH path (f3) */
+/*
+ * Restatement of the reference's default ("medium") search path: the random-hyperplane
+ * forest of lshtree.go and the traversal lshTree.search (lshtree.go:283-351) driving
+ * consider() (collection.go:583-629) per candidate.  Test infrastructure, like the rest of
+ * this file.  The forest itself is an INPUT of the search: the reference builds it with Go's
+ * math/rand (rand.Intn / NormFloat64, lshtree.go:39-45, :173-180), a stream that cannot be
+ * reproduced here, so orc_lsh_build follows the reference's insert / split rules
+ * (lshtree.go:102-251) with its own documented generator -- any forest those rules can
+ * produce is a valid one, and parity of the SEARCH is defined on a given forest.
+ * Documents are identified by their row in `rows` (the caller keeps row <-> id).
+ */
+typedef struct lsh_node {
+    double *normal; /* dim, interior nodes (lshtree.go:48) */
+    double b;
+    double radius;
+    struct lsh_node *left, *right;
+    uint64_t *ids;
+    int64_t n_ids, cap_ids;
+} lsh_node;
+
+struct orc_lsh {
+    lsh_node **roots;
+    int n_roots, threshold, dim, bits, metric;
+    const uint8_t *rows; /* borrowed */
+    uint64_t rng;
+};
+
+static uint64_t lsh_next(orc_lsh *t) { return orc_splitmix64(t->rng++); }
+static int64_t lsh_intn(orc_lsh *t, int64_t n) { return (int64_t)(lsh_next(t) % (uint64_t)n); } /* stands in for rand.Intn */
+static double lsh_norm(orc_lsh *t)
+{   /* stands in for rand.NormFloat64: Box-Muller on two uniforms of the splitmix stream */
+    double u1 = ((double)(lsh_next(t) >> 11) + 1.0) * (1.0 / 9007199254740993.0);
+    double u2 = (double)(lsh_next(t) >> 11) * (1.0 / 9007199254740992.0);
+    return sqrt(-2.0 * log(u1)) * cos(2.0 * M_PI * u2);
+}
+
+/* lshtree.go:30-36 */
+static double vector_length(const double *v, int n)
+{
+    double sum = 0.0;
+    for (int i = 0; i < n; i++) sum += v[i] * v[i];
+    return sqrt(sum);
+}
+
+/* lshtree.go:135-144 */
+static double dot_product(const double *a, const double *b, int n)
+{
+    double dot = 0.0;
+    for (int i = 0; i < n; i++) dot += a[i] * b[i];
+    return dot;
+}
+
+/* lshtree.go:55-74 */
+static double distance_to_hyperplane(int method, const double *vector, double length, const double *normal,
+                                     double b, int dim, int *right)
+{
+    double dist = dot_product(vector, normal, dim) - b;
+    *right = 0;
+    if (method == ORC_EUCLIDEAN) {
+        if (dist > 0) *right = 1; else dist = -dist;
+        return dist;
+    }
+    dist = orc_go_acos(dist / length) / M_PI; /* angular distance of two already-normalized vectors */
+    if (dist > 0.5) {
+        *right = 1;
+        dist = 1 - dist;
+    }
+    return dist;
+}
+
+static lsh_node *lsh_leaf(void) { return (lsh_node *)calloc(1, sizeof(lsh_node)); }
+
+static void lsh_push_id(lsh_node *n, uint64_t id)
+{
+    if (n->n_ids == n->cap_ids) {
+        n->cap_ids = n->cap_ids ? n->cap_ids * 2 : 16;
+        n->ids = (uint64_t *)realloc(n->ids, sizeof(uint64_t) * (size_t)n->cap_ids);
+    }
+    n->ids[n->n_ids++] = id;
+}
+
+static void lsh_doc(const orc_lsh *t, uint64_t id, double *out)
+{
+    orc_decode_vector(t->rows + id * (uint64_t)orc_vector_size(t->bits, t->dim), t->dim, t->bits, out);
+}
+
+/* lshtree.go:171-251 */
+static lsh_node *lsh_split(orc_lsh *t, lsh_node *node)
+{
+    const int dim = t->dim;
+    int64_t i1 = lsh_intn(t, node->n_ids), i2;
+    do { i2 = lsh_intn(t, node->n_ids); } while (i2 == i1);
+    double *d1 = (double *)malloc(sizeof(double) * (size_t)dim * 3), *d2 = d1 + dim, *v = d2 + dim;
+    lsh_doc(t, node->ids[i1], d1);
+    lsh_doc(t, node->ids[i2], d2);
+    int same = 1; /* aboutEqual, :160-169 */
+    for (int i = 0; i < dim; i++) if (fabs(d1[i] - d2[i]) > 1e-9) { same = 0; break; }
+    if (same) { free(d1); return node; }
+    double *normal = (double *)malloc(sizeof(double) * (size_t)dim);
+    double b = 0.0;
+    for (int i = 0; i < dim; i++) normal[i] = lsh_norm(t);       /* randomNormalizedVector :39-45 */
+    {
+        double norm = 0.0;
+        for (int i = 0; i < dim; i++) norm += normal[i] * normal[i];
+        if (norm != 0) { norm = sqrt(norm); for (int i = 0; i < dim; i++) normal[i] = normal[i] / norm; }
+    }
+    if (t->metric == ORC_EUCLIDEAN) {                              /* :205-207 */
+        for (int i = 0; i < dim; i++) v[i] = (d1[i] + d2[i]) / 2;  /* midpoint :146-155 */
+        b = sqrt(dot_product(v, v, dim));
+    }
+    lsh_node *l = lsh_leaf(), *r = lsh_leaf();
+    double radius = 0.0;
+    for (int64_t i = 0; i < node->n_ids; i++) {                    /* :217-232 */
+        lsh_doc(t, node->ids[i], v);
+        int right;
+        double distance = distance_to_hyperplane(t->metric, v, vector_length(v, dim), normal, b, dim, &right);
+        radius = fmax(radius, distance);
+        lsh_push_id(right ? r : l, node->ids[i]);
+    }
+    free(d1);
+    if (l->n_ids == 0 || r->n_ids == 0) {                          /* :236-238 */
+        free(l->ids); free(r->ids); free(l); free(r); free(normal);
+        return node;
+    }
+    lsh_node *n = lsh_leaf();
+    n->normal = normal; n->b = b; n->radius = radius; n->left = l; n->right = r;
+    free(node->ids); free(node);
+    return n;
+}
+
+/* lshtree.go:118-133 */
+static lsh_node *lsh_insert(orc_lsh *t, lsh_node *node, uint64_t id, const double *vector, double length)
+{
+    if (node->left == NULL) {
+        lsh_push_id(node, id);
+        if (node->n_ids > t->threshold) node = lsh_split(t, node);
+        return node;
+    }
+    int right;
+    double distance = distance_to_hyperplane(t->metric, vector, length, node->normal, node->b, t->dim, &right);
+    node->radius = fmax(node->radius, distance);
+    if (!right) node->left = lsh_insert(t, node->left, id, vector, length);
+    else node->right = lsh_insert(t, node->right, id, vector, length);
+    return node;
+}
+
+orc_lsh *orc_lsh_build(const uint8_t *rows, uint64_t n_rows, int dim, int bits, int metric, int threshold,
+                       int num_trees, uint64_t seed)
+{
+    if (orc_vector_size(bits, dim) < 0 || threshold < 1 || num_trees < 1) return NULL;
+    orc_lsh *t = (orc_lsh *)calloc(1, sizeof(orc_lsh));
+    t->roots = (lsh_node **)calloc((size_t)num_trees, sizeof(lsh_node *));
+    t->n_roots = num_trees; t->threshold = threshold; t->dim = dim; t->bits = bits; t->metric = metric;
+    t->rows = rows; t->rng = seed;
+    for (int i = 0; i < num_trees; i++) t->roots[i] = lsh_leaf();  /* newLSHTree :84-96 */
+    double *v = (double *)malloc(sizeof(double) * (size_t)dim);
+    for (uint64_t id = 0; id < n_rows; id++) {                     /* addPoint :98-116, one tree after the other */
+        lsh_doc(t, id, v);
+        double length = vector_length(v, dim);
+        for (int i = 0; i < num_trees; i++) t->roots[i] = lsh_insert(t, t->roots[i], id, v, length);
+    }
+    free(v);
+    return t;
+}
+
+static void lsh_free_node(lsh_node *n)
+{
+    if (!n) return;
+    lsh_free_node(n->left); lsh_free_node(n->right);
+    free(n->normal); free(n->ids); free(n);
+}
+
+void orc_lsh_free(orc_lsh *t)
+{
+    if (!t) return;
+    for (int i = 0; i < t->n_roots; i++) lsh_free_node(t->roots[i]);
+    free(t->roots); free(t);
+}
+
+static void lsh_count(const lsh_node *n, int64_t *nodes, int64_t *ids)
+{
+    (*nodes)++; *ids += n->n_ids;
+    if (n->left) { lsh_count(n->left, nodes, ids); lsh_count(n->right, nodes, ids); }
+}
+
+void orc_lsh_sizes(const orc_lsh *t, int64_t *n_nodes, int64_t *n_ids)
+{
+    *n_nodes = 0; *n_ids = 0;
+    for (int i = 0; i < t->n_roots; i++) lsh_count(t->roots[i], n_nodes, n_ids);
+}
+
+static int32_t lsh_flatten(const orc_lsh *t, const lsh_node *n, int32_t *next, int64_t *ids_at, int32_t *left,
+                           int32_t *right, double *normals, double *b, int64_t *ids_off, int32_t *ids_cnt,
+                           uint64_t *ids)
+{
+    int32_t me = (*next)++;
+    b[me] = n->b;
+    ids_off[me] = *ids_at; ids_cnt[me] = (int32_t)n->n_ids;
+    for (int64_t i = 0; i < n->n_ids; i++) ids[(*ids_at)++] = n->ids[i];
+    for (int i = 0; i < t->dim; i++) normals[(size_t)me * (size_t)t->dim + (size_t)i] = n->normal ? n->normal[i] : 0.0;
+    left[me] = right[me] = -1;
+    if (n->left) {
+        left[me] = lsh_flatten(t, n->left, next, ids_at, left, right, normals, b, ids_off, ids_cnt, ids);
+        right[me] = lsh_flatten(t, n->right, next, ids_at, left, right, normals, b, ids_off, ids_cnt, ids);
+    }
+    return me;
+}
+
+/* the forest as flat arrays (what the host mirror of the product traverses) */
+void orc_lsh_export(const orc_lsh *t, int32_t *roots, int32_t *left, int32_t *right, double *normals, double *b,
+                    int64_t *ids_off, int32_t *ids_cnt, uint64_t *ids)
+{
+    int32_t next = 0;
+    int64_t at = 0;
+    for (int i = 0; i < t->n_roots; i++)
+        roots[i] = lsh_flatten(t, t->roots[i], &next, &at, left, right, normals, b, ids_off, ids_cnt, ids);
+}
+
+/* nodePriorityQueue, lshtree.go:353-381: container/heap, Less = priority > (max-heap) */
+typedef struct { const lsh_node *node; double priority; } npq_item;
+typedef struct { npq_item *a; int64_t len, cap; } npq;
+static int npq_less(const npq *h, int64_t i, int64_t j) { return h->a[i].priority > h->a[j].priority; }
+static void npq_swap(npq *h, int64_t i, int64_t j) { npq_item t = h->a[i]; h->a[i] = h->a[j]; h->a[j] = t; }
+static void npq_push(npq *h, npq_item it)
+{
+    if (h->len == h->cap) { h->cap = h->cap ? h->cap * 2 : 64; h->a = (npq_item *)realloc(h->a, (size_t)h->cap * sizeof(npq_item)); }
+    h->a[h->len++] = it;
+    for (int64_t j = h->len - 1;;) { /* up */
+        int64_t i = (j - 1) / 2;
+        if (i == j || !npq_less(h, j, i)) break;
+        npq_swap(h, i, j);
+        j = i;
+    }
+}
+static npq_item npq_pop(npq *h)
+{
+    int64_t n = h->len - 1;
+    npq_swap(h, 0, n);
+    for (int64_t i = 0;;) { /* down(0, n) */
+        int64_t j1 = 2 * i + 1;
+        if (j1 >= n || j1 < 0) break;
+        int64_t j = j1, j2 = j1 + 1;
+        if (j2 < n && npq_less(h, j2, j1)) j = j2;
+        if (!npq_less(h, j, i)) break;
+        npq_swap(h, i, j);
+        i = j;
+    }
+    h->len = n;
+    return h->a[n];
+}
+
+enum { STOP_SEARCH = 0, POINT_ACCEPTED, POINT_CHECKED, POINT_IGNORED }; /* collection.go:19-24 */
+
+/*
+ * Search{Precision: "medium"} (collection.go:685-691 -> lshTree.search, lshtree.go:283-351) with
+ * consider() (collection.go:583-629) as the callback.  visit_order (nullable, capacity n_rows)
+ * receives the rows in the order consider() saw them.
+ */
+int64_t orc_lsh_search(const orc_lsh *t, uint64_t n_rows, const double *query, int k, double radius_arg,
+                       const uint8_t *allow, uint64_t *out_rows, double *out_dist, uint64_t capacity,
+                       uint64_t *points_searched, uint64_t *visit_order)
+{
+    const int dim = t->dim;
+    double radius = radius_arg > 0 ? radius_arg : DBL_MAX;   /* collection.go:686-689, math.MaxFloat64 */
+    double length = vector_length(query, dim);
+    uint8_t *visited = (uint8_t *)calloc((size_t)(n_rows ? n_rows : 1), 1);
+    double *vec = (double *)malloc(sizeof(double) * (size_t)dim);
+    const int search_k = 200;
+    int k_counter = 0, point_accepted = 0;
+    uint64_t searched = 0;
+    orc_pq results = {0, 0, 0};
+    npq pq = {0, 0, 0};
+    for (int i = 0; i < t->n_roots; i++) { npq_item it = {t->roots[i], 0}; npq_push(&pq, it); }
+    while (pq.len > 0) {
+        npq_item item = npq_pop(&pq);
+        const lsh_node *node = item.node;
+        const int leaf = node->left == NULL;
+        if (item.priority < 0 && -item.priority > radius && leaf) continue;   /* :305-310 */
+        if (k_counter >= search_k) break;                                     /* :312-314 */
+        if (leaf) {
+            for (int64_t ii = 0; ii < node->n_ids; ii++) {
+                uint64_t id = node->ids[ii];
+                if (visited[id]) continue;
+                visited[id] = 1;
+                /* consider(), collection.go:583-629 */
+                int signal = POINT_CHECKED;
+                lsh_doc(t, id, vec);
+                if (visit_order) visit_order[searched] = id;
+                searched++;
+                if (allow && !allow[id]) {
+                    signal = POINT_IGNORED;
+                } else {
+                    double distance = distance_fn(t->metric, query, vec, dim);
+                    if (radius_arg > 0 && distance <= radius_arg) {
+                        orc_item it = {id, distance};
+                        heap_push(&results, it);
+                        signal = POINT_ACCEPTED;
+                    } else if (radius_arg > 0) {
+                        signal = POINT_CHECKED;
+                    } else if (k > 0) {
+                        if (results.len <= k && (results.len < k || results.a[0].priority > distance)) {
+                            orc_item it = {id, distance};
+                            heap_push(&results, it);
+                            if (results.len > k) heap_pop(&results);
+                            radius = results.a[0].priority;                   /* :616 */
+                            signal = POINT_ACCEPTED;
+                        }
+                    }
+                }
+                switch (signal) {                                             /* lshtree.go:323-334 */
+                case POINT_ACCEPTED: k_counter = 0; point_accepted = 1; break;
+                case POINT_CHECKED: if (point_accepted) k_counter++; break;
+                default: break;
+                }
+            }
+        } else {
+            int right;
+            double dist = distance_to_hyperplane(t->metric, query, length, node->normal, node->b, dim, &right);
+            npq_item a, b;
+            if (right) { a.node = node->right; a.priority = dist; b.node = node->left; b.priority = -dist; }
+            else { a.node = node->left; a.priority = dist; b.node = node->right; b.priority = -dist; }
+            npq_push(&pq, a);
+            npq_push(&pq, b);
+        }
+    }
+    int64_t n = results.len;
+    for (int64_t i = n - 1; i >= 0; i--) {                                    /* collection.go:694-697 */
+        orc_item it = heap_pop(&results);
+        if ((uint64_t)i < capacity) {
+            if (out_rows) out_rows[i] = it.row;
+            if (out_dist) out_dist[i] = it.priority;
+        }
+    }
+    if (points_searched) *points_searched = searched;
+    free(visited); free(vec); free(results.a); free(pq.a);
+    return n;
 }

@@ -120,6 +120,28 @@ double orc_bench_topk_faithful(const uint8_t *spans, const uint64_t *offsets, ui
                                int bits, int metric, const double *queries, int n_queries, int k,
                                uint64_t *out_rows /* n_queries*k */);
 
+/*
+ * LSH path: the reference's default search, Search{Precision:"medium"} ->
+ * lshTree.search (lshtree.go:283-351) with consider() (collection.go:583-629) per candidate.
+ * The forest is built by the reference's insert / split rules (lshtree.go:102-251) from a
+ * documented splitmix64 stream in place of Go's math/rand (which cannot be reproduced here):
+ * the forest is an input of the search, and parity of the search is defined on a given forest.
+ * Documents are identified by their row.  PARITY UNPINNED beyond the restatement: the
+ * reference's tests hold no known answers for this path (lshtree_test.go checks recall only).
+ */
+typedef struct orc_lsh orc_lsh;
+orc_lsh *orc_lsh_build(const uint8_t *rows /* borrowed until orc_lsh_free */, uint64_t n_rows, int dim, int bits,
+                       int metric, int threshold /* 100, collection.go:292 */, int num_trees /* 5 */, uint64_t seed);
+void orc_lsh_free(orc_lsh *t);
+void orc_lsh_sizes(const orc_lsh *t, int64_t *n_nodes, int64_t *n_ids);
+/* flat arrays: roots[num_trees], left/right[n_nodes] (-1 = leaf), normals[n_nodes*dim], b[n_nodes],
+ * ids_off/ids_cnt[n_nodes] into ids[n_ids] */
+void orc_lsh_export(const orc_lsh *t, int32_t *roots, int32_t *left, int32_t *right, double *normals, double *b,
+                    int64_t *ids_off, int32_t *ids_cnt, uint64_t *ids);
+int64_t orc_lsh_search(const orc_lsh *t, uint64_t n_rows, const double *query, int k, double radius,
+                       const uint8_t *allow, uint64_t *out_rows, double *out_dist, uint64_t capacity,
+                       uint64_t *points_searched, uint64_t *visit_order /* nullable, n_rows */);
+
 #ifdef __cplusplus
 }
 #endif

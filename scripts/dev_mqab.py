@@ -17,6 +17,7 @@ with ScanIndex(dim, bits, metric, devices=[0]) as ix:
         ix.set_timing(True); ix.reset_stats(); ix.search_topk(q, k); s = ix.stats()
         ms = s["scan_ms"] / max(s["timed_launches"], 1)
         per = s["mq_queries"] / max(s["mq_launches"], 1)
-        print("%s %s bits=%d metric=%d: %.0f QPS  sweep %.3f ms  %.1f TFLOP/s  (%.1f q/pass)  esc %d fb %d" % (
+        print("%s %s bits=%d metric=%d: %.0f QPS  sweep %.3f ms  %.1f TFLOP/s  (%.1f q/pass)  esc %d fb %d  host us/query: prep %.2f enq %.2f fin %.2f" % (
             os.path.basename(os.environ.get("SZG_LIB_PATH", "default")), os.environ.get("SZG_OPTS", ""), bits, metric, nq / wall, ms,
-            2.0 * n * dim * per / (ms * 1e-3) / 1e12, per, s["escalations"], s["mq_fallbacks"]), flush=True)
+            2.0 * n * dim * per / (ms * 1e-3) / 1e12, per, s["escalations"], s["mq_fallbacks"],
+            s["host_prep_us"] / nq, s["host_enqueue_us"] / nq, s["host_finish_us"] / nq), flush=True)

@@ -1,0 +1,38 @@
+"""SURVEY.md 8f-3 on the GPU: the default ("medium") search path with its candidates scored in
+bulk by szg_distances.  The host walk of syzgydb_amd/lsh.py (the reference's forest and queue,
+windows of leaves scored in one device call each) must return exactly what lshTree.search +
+consider() return on the same forest: rows, order, float64 distances, pointsSearched."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from syzgydb_amd import ScanIndex, lsh
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("bits,metric,dim", [(32, 1, 96), (8, 0, 48), (4, 1, 64), (64, 0, 16), (16, 1, 32)])
+def test_lsh_bulk_rerank_equals_reference_walk(bits, metric, dim):
+    n = 20000
+    rows = orc.synth_rows(700 + bits, 0, n, dim, bits)
+    forest_o = orc.LshForest(rows, dim, bits, metric, threshold=100, num_trees=5, seed=11)   # collection.go:292
+    forest = lsh.LshForest(metric=metric, **forest_o.export())
+    Q = orc.synth_vectors(701, 0, 8, dim)
+    Q[1] = orc.decode_vector(rows[1234], dim, bits)          # a stored vector as the query
+    rng = np.random.default_rng(5)
+    allow = rng.random(n) < 0.5
+    with ScanIndex(dim, bits, metric) as ix:
+        ix.load(rows)
+        for qi in range(Q.shape[0]):
+            for k, radius, flt in ((10, 0.0, None), (100, 0.0, allow), (0, 0.46 if metric else 0.9 * np.sqrt(dim / 6), None)):
+                er, ed, es, _ = forest_o.search(Q[qi], k=k, radius=radius, allow=flt)
+                r, d, s = lsh.search(forest, ix, Q[qi], k=k, radius=radius, allow=flt)
+                assert list(map(int, r)) == list(map(int, er)), (qi, k, radius)
+                assert ((d == ed) | (np.isnan(d) & np.isnan(ed))).all()
+                assert s == es and s < n
+        # few device calls per search: windows of ~2048 candidates, not one call per candidate or leaf
+        calls = []
+        real = ix.distances
+        ix.distances = lambda q, ids: (calls.append(len(ids)), real(q, ids))[1]
+        _, _, s = lsh.search(forest, ix, Q[0], k=10)
+        assert len(calls) <= 1 + s // 1024 and sum(calls) >= s
