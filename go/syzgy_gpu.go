@@ -21,6 +21,7 @@ package syzgydb
 import "C"
 
 import (
+	"container/heap"
 	"fmt"
 	"sort"
 	"strconv"
@@ -334,4 +335,112 @@ func (m *gpuMirror) pairDistances(a, b []uint64) ([]float64, bool) {
 	out := make([]float64, len(a))
 	rc := C.szg_pair_distances(m.h, &ra[0], &rb[0], C.uint64_t(len(a)), (*C.double)(unsafe.Pointer(&out[0])))
 	return out, rc == C.SZG_OK
+}
+
+
+// searchIndexBulk is the default ("medium") path of Collection.Search -- c.index.search(args.Vector,
+// radius, consider), collection.go:685-691 -- with the candidates' distances computed in bulk on
+// the GPU.  The forest, its queue and consider() are the reference's, unchanged; only c.distance
+// moves.  lshTree.search (lshtree.go:283-351) reads the candidates' distances back through two
+// scalars only, `radius` (when a far-side leaf is popped, :305-310) and k_counter (:312-314);
+// neither changes the ORDER in which nodes leave the queue, they only skip leaves and stop the
+// walk.  So this function (1) pops the queue exactly as lshTree.search does but without pruning
+// or stopping, buffering the next `window` candidates' leaves, (2) scores all their unvisited
+// ids in ONE szg_distances call, and (3) replays the reference's loop body over the buffered
+// leaves -- pruning test, stop test, visited marks, consider -- with those distances.  The
+// result, its order and pointsSearched are the reference's on the same forest
+// (tests/test_gpu_lsh.py drives the same algorithm, syzgydb_amd/lsh.py, against a C
+// restatement of lshTree.search).  consider is Search's closure with its c.distance call
+// replaced by the supplied value: considerWith(docid, distance, radius) (signal, radius).
+func (m *gpuMirror) searchIndexBulk(c *Collection, tree *lshTree, vector []float64, radius float64,
+	considerWith func(docid uint64, distance float64, radius float64) (int, float64)) bool {
+	const window = 2048
+	const search_k = 200
+	m.mu.RLock()
+	defer m.mu.RUnlock()
+	if m.dirty {
+		return false // the caller runs the reference's own walk
+	}
+	length := vectorLength(vector)
+	visited := make(map[uint64]bool)
+	k_counter := 0
+	pointAccepted := false
+	pq := &nodePriorityQueue{}
+	heap.Init(pq)
+	for _, root := range tree.roots {
+		heap.Push(pq, &nodePriorityItem{node: root, priority: 0})
+	}
+	type pending struct {
+		node     *lshNode
+		priority float64
+	}
+	for pq.Len() > 0 {
+		// (1) the next leaves of the unpruned walk
+		var leaves []pending
+		var want []uint64
+		queued := make(map[uint64]bool)
+		for pq.Len() > 0 && len(want) < window {
+			item := heap.Pop(pq).(*nodePriorityItem)
+			node := item.node
+			if !node.isLeaf() {
+				dist, right := distanceToHyperplane(tree.c.DistanceMethod, vector, length, node.normal, node.b)
+				if right {
+					heap.Push(pq, &nodePriorityItem{node: node.right, priority: dist})
+					heap.Push(pq, &nodePriorityItem{node: node.left, priority: -dist})
+				} else {
+					heap.Push(pq, &nodePriorityItem{node: node.left, priority: dist})
+					heap.Push(pq, &nodePriorityItem{node: node.right, priority: -dist})
+				}
+				continue
+			}
+			leaves = append(leaves, pending{node, item.priority})
+			for _, id := range node.ids {
+				if !visited[id] && !queued[id] {
+					queued[id] = true
+					want = append(want, id)
+				}
+			}
+		}
+		// (2) one device call for the window
+		distOf := make(map[uint64]float64, len(want))
+		if len(want) > 0 {
+			d, ok := m.distancesTo(vector, want)
+			if !ok {
+				return false
+			}
+			for i, id := range want {
+				distOf[id] = d[i]
+			}
+		}
+		// (3) the reference's loop body over the buffered leaves
+		for _, lf := range leaves {
+			if lf.priority < 0 && -lf.priority > radius {
+				continue // lshtree.go:305-310
+			}
+			if k_counter >= search_k {
+				return true // :312-314
+			}
+			for _, id := range lf.node.ids {
+				if visited[id] {
+					continue
+				}
+				visited[id] = true
+				var signal int
+				signal, radius = considerWith(id, distOf[id], radius)
+				switch signal {
+				case StopSearch:
+					return true
+				case PointAccepted:
+					k_counter = 0
+					pointAccepted = true
+				case PointChecked:
+					if pointAccepted {
+						k_counter++
+					}
+				case PointIgnored:
+				}
+			}
+		}
+	}
+	return true
 }

@@ -8,8 +8,9 @@ from .index import ScanIndex, pack_allow_bits, f64_probe  # noqa: F401
 from .collection import (Collection, CollectionOptions, Document, SearchArgs, SearchResult,  # noqa: F401
                          SearchResults, Euclidean, Cosine)
 from . import codec  # noqa: F401
+from . import lsh  # noqa: F401
 from .pager import SpanfilePager  # noqa: F401
 
 __all__ = ["ScanIndex", "Collection", "CollectionOptions", "Document", "SearchArgs",
            "SearchResult", "SearchResults", "Euclidean", "Cosine", "codec", "SzgError",
-           "pack_allow_bits", "f64_probe", "SpanfilePager", "SZG_COSINE", "SZG_EUCLIDEAN", "LIB_PATH"]
+           "pack_allow_bits", "f64_probe", "SpanfilePager", "lsh", "SZG_COSINE", "SZG_EUCLIDEAN", "LIB_PATH"]
