@@ -89,15 +89,16 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def recorded_traffic(workload, rows_override, sweeps_per_launch):
+def recorded_traffic(workload, rows, sweeps_per_launch):
     """HBM bytes per scan launch as RECORDED by the PMC passes under profiles/ (FETCH_SIZE with
     the gfx950 x2 correction + WRITE_SIZE; separate rocprofv3 runs, not this run), scaled from
-    the sweeps per launch of the PMC run to this run's.  (None, None) when no pass exists."""
-    if rows_override:
-        return None, None
+    the sweeps per launch of the PMC run to this run's.  (None, None) when no pass exists for
+    this workload at this row count."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             e = json.load(f)[workload]
+        if int(e.get("rows", WORKLOADS[workload][0])) != int(rows):
+            return None, None
         return (int(e["hbm_bytes_per_launch"] / float(e.get("sweeps_per_launch", 1)) * sweeps_per_launch),
                 "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
                 "not measured in this run)")
@@ -175,25 +176,31 @@ def calibrated_radius(ix, queries, radius, target_hits=500):
     return rad, len(r)
 
 
+def radius_searches(ix, queries, radius, threads=3):
+    """Radius searches as the reference issues them -- one Search per caller, several callers at
+    once under RLock (collection.go:570): a few threads keep the sweeps back to back while the
+    other callers' hits are re-ranked and copied."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        return list(ex.map(lambda q: ix.search_radius(q, radius), queries))
+
+
 def timed_leg(ix, queries, k, radius, n_settle=16):
     """Side workloads (one card, one query per sweep): a short settle, then the queries with HIP
     events on; returns (queries/s, stats, hits per query or None)."""
     ix.set_option("multi_query", 0)
-    if radius > 0:
-        for q in queries[:2]:
-            ix.search_radius(q, radius)
-    else:
-        ix.search_topk(queries[:n_settle], k)
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < 0.4:   # clocks / TLBs settle (untimed)
+        if radius > 0:
+            radius_searches(ix, queries[:6], radius)
+        else:
+            ix.search_topk(queries[:n_settle], k)
     ix.set_timing(True)
     ix.reset_stats()
     t0 = time.perf_counter()
     hits = None
     if radius > 0:
-        tot = 0
-        for q in queries:
-            r, _ = ix.search_radius(q, radius)
-            tot += len(r)
-        hits = tot / float(len(queries))
+        hits = sum(len(r) for r, _ in radius_searches(ix, queries, radius)) / float(len(queries))
     else:
         ix.search_topk(queries, k)
     el = time.perf_counter() - t0
@@ -219,6 +226,10 @@ def side_workload(name, n_queries, devices):
             radius, _ = calibrated_radius(ix, q, radius)
         qps, st, hits = timed_leg(ix, q[:n_queries], k, radius)
         rf = roofline_of(st, rows, ix.row_bytes, bits, metric, "collect" if radius > 0 else "topk")
+        if radius == 0:
+            rf["traffic"], src = recorded_traffic(name, rows, rf["sweeps_per_launch"])
+            if src:
+                rf["traffic_source"] = src
         out = {
             "workload": "%s%s: %d x %d, %d-bit, %s, %s, 1 query per sweep" % (
                 name, " (per-GPU shard of %d rows / 8)" % n_rows if name in SHARD_ROWS else "", rows, dim, bits,
@@ -369,7 +380,7 @@ def main():
             if dist_path:
                 outs = searcher.search_radius_stream(local_radius, q, radius)
             else:
-                outs = [ix.search_radius(x, radius) for x in q]
+                outs = radius_searches(ix, q, radius)
             return [o[0] for o in outs], [o[1] for o in outs]
         if dist_path:
             r, d, _, _ = searcher.search_stream(q, k, chunk)
@@ -428,7 +439,7 @@ def main():
                          bits, metric, "collect" if radius > 0 else "topk")
         n_dev = args.gpus
         if world == 1 and not inproc:
-            rf["traffic"], src = recorded_traffic(args.workload, args.rows, rf["sweeps_per_launch"])
+            rf["traffic"], src = recorded_traffic(args.workload, n_rows, rf["sweeps_per_launch"])
             if src:
                 rf["traffic_source"] = src
         host_us = (stats["host_prep_us"] + stats["host_finish_us"] + stats["host_enqueue_us"]) / max(args.steps, 1)

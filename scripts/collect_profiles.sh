@@ -1,7 +1,8 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence behind bench.py's roofline object into
-# gpurun_out/profiles/ (copy what is to be judged into profiles/).  Run on the GPU box
-# from the repo root:  bash scripts/collect_profiles.sh r01
+# Collects the rocprofv3 evidence behind bench.py's roofline objects into gpurun_out/profiles/
+# (copy what is to be judged into profiles/).  Run on the GPU box from the repo root:
+#     bash scripts/collect_profiles.sh r02
+# Counters are collected in their own runs (--kernel-trace --pmc only, one counter set per run).
 set -e
 tag=${1:-rXX}
 out=$GRAFT_REPO_ROOT/gpurun_out/profiles
@@ -9,22 +10,36 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 one() { f=$(find "$1" -name "$2" | head -1); if [ -n "$f" ]; then cp "$f" "$3"; else echo "missing $2 under $1" >&2; fi; }
 
-echo "[1/5] unprofiled bench" | tee -a $out/progress.log
+echo "[1] unprofiled bench" | tee -a $out/progress.log
 python3 $GRAFT_REPO_ROOT/bench.py > $out/${tag}_bench_n1_unprofiled_stdout.json 2> $out/bench_unprofiled.err
 
-echo "[2/5] kernel trace + stats over bench.py" | tee -a $out/progress.log
+echo "[2] kernel trace + stats over bench.py" | tee -a $out/progress.log
+rm -rf /tmp/prof_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py > $out/${tag}_bench_n1_stdout.json 2> $out/bench_profiled.err
 one /tmp/prof_stats "*kernel_stats.csv" $out/${tag}_bench_n1_kernel_stats.csv
 
 i=2
-for cfg in "headline 1000000 768 32 1 10 16" "cfg3 1000000 768 8 1 10 16"; do
+# name rows dim bits metric k queries (one query-major launch of 16 sweeps)
+for cfg in "headline 1000000 768 32 1 10 16" "cfg2 1000000 384 32 1 10 16" "cfg3 1000000 768 8 1 10 16" \
+           "cfg4shard 1250000 768 32 0 100 16" "cfg5shard 12500000 384 4 1 10 16"; do
   set -- $cfg; name=$1; shift
   for ctr in FETCH_SIZE WRITE_SIZE; do
     i=$((i+1))
     echo "[$i] pmc $ctr $name" | tee -a $out/progress.log
+    rm -rf /tmp/prof_${name}_$ctr
     rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/prof_${name}_$ctr -- python3 $GRAFT_REPO_ROOT/scripts/dev_one.py "$@" > /tmp/pmc.log 2>&1
     lc=$(echo $ctr | tr A-Z a-z)
     one /tmp/prof_${name}_$ctr "*counter_collection.csv" $out/${tag}_pmc_${name}_$lc.csv
   done
 done
+
+echo "[mq] shared sweeps: kernel stats + counters" | tee -a $out/progress.log
+for b in 32 8 4; do
+  rm -rf /tmp/prof_mq$b
+  SZG_BITS=$b rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mq$b -- python3 $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /tmp/mq.log 2>&1
+  one /tmp/prof_mq$b "*kernel_stats.csv" $out/${tag}_mq_${b}bit_kernel_stats.csv
+done
+SZG_BITS=8 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_i8_kernel<3, 1, true" $out/${tag}_pmc_mq_i8_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
+SZG_BITS=32 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_kernel<3, 32, 1, true" $out/${tag}_pmc_mq_f32_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
+python3 $GRAFT_REPO_ROOT/scripts/make_traffic.py $out $tag > $out/traffic.json || true
 echo done | tee -a $out/progress.log

@@ -40,8 +40,8 @@ while time.time() < t_end:
     if dim * n > 4_000_000:
         n = max(1, 4_000_000 // dim)
     nq = int(rng.choice([1, 2, 7, 8, 9, 16, 17, 33, 50]))
-    k = int(rng.choice([1, 2, 10, 11, 50, 100, 300]))
-    kind = int(rng.integers(0, 5))
+    k = int(rng.choice([1, 2, 10, 11, 50, 100, 300, 5000]))
+    kind = int(rng.integers(0, 7))
     vec = rng.uniform(-1, 1, (n, dim))
     if kind == 1:          # duplicates
         vec[rng.integers(0, n, n // 2)] = vec[0]
@@ -51,8 +51,14 @@ while time.time() < t_end:
         vec = vec * 1e3 + 5e3
     elif kind == 4:        # some zero rows
         vec[rng.integers(0, n, max(1, n // 10))] = 0.0
-    rows = orc.encode_rows(vec, bits)
     Q = rng.uniform(-1, 1, (nq, dim))
+    if kind == 5:          # rows antipodal / parallel to a query among the first rows: the unclamped acos
+        for r0 in rng.integers(0, min(n, max(k, 4)), 3):   # (collection.go:831) can return NaN for them, and the
+            vec[r0] = Q[0] * float(rng.choice([-0.5, -1.0, 0.5, 1.0]))   # first k rows enter the heap regardless
+    elif kind == 6 and bits >= 32:   # NaN / Inf elements in stored rows
+        for r0 in rng.integers(0, n, 3):
+            vec[r0, int(rng.integers(0, dim))] = float(rng.choice([np.nan, np.inf, -np.inf]))
+    rows = orc.encode_rows(vec, bits)
     if kind == 3 and bits >= 32:
         Q = Q * 1e3 + 5e3
     if rng.random() < 0.2:

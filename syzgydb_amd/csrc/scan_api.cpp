@@ -303,6 +303,8 @@ struct szg_index {
     int mq_tail_overlap = 0;  // shared sweep: post-processing of a batch beside the next batch's sweep
     int mq_min = 2;           // smallest batch worth a shared sweep (measured: 2 queries already break even)
     int mq_blocks_max = 3;    // query blocks of 16 per shared sweep (LDS image permitting)
+    int mq_hits = 1024;       // fused selection: candidates per query the full sweep is expected to collect
+                              // (sets the prefix: n_rows * kp / mq_hits rows)
     bool timing = false;
     std::mutex stats_mu;
     // coalescing of concurrent single-query searches (szg_search_topk, n_queries == 1)
@@ -962,7 +964,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     // (query, row) pairs at or below their threshold -- about `hits` per query -- instead of
     // writing and re-reading n_rows x batch keys.  Every row outside a query's buffer has a
     // key above the threshold, which is >= the kp-th kept key: certification is unchanged.
-    const uint64_t hits = std::max<uint64_t>(1024, 16ull * kp);
+    const uint64_t hits = std::max<uint64_t>((uint64_t)ix->mq_hits, 16ull * kp);
     uint64_t prefix = ((sh->n_rows * (uint64_t)kp + hits - 1) / hits + 15) & ~15ull;
     prefix = std::max<uint64_t>(prefix, 16ull * kp);
     const bool fused = ix->mq_fused && !force_matrix && prefix * 4 <= sh->n_rows;
@@ -2622,6 +2624,9 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
         ix->mq_i8 = value != 0;
     } else if (n == "mq_tail_overlap") {
         ix->mq_tail_overlap = value != 0;
+    } else if (n == "mq_hits") {
+        if (value < 64 || value > 65536) return fail(SZG_E_INVALID, "mq_hits out of range");
+        ix->mq_hits = (int)value;
     } else if (n == "mq_min") {
         if (value < 1 || value > 32) return fail(SZG_E_INVALID, "mq_min out of range");
         ix->mq_min = (int)value;
