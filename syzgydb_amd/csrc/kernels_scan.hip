@@ -454,11 +454,9 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
         else
             key = acc.finish(qc, grp_info, valid && lig == 0);
         const bool leader = valid && lig == 0;
-        // !(key > t): at or below the threshold, or NaN (which the slow path turns into the worst finite key)
+        key = fminf(key, 3.0e38f);              // +inf (overflow) and NaN (minNum returns the number): worst finite
         const bool maybe = leader && !(key > (COLLECT ? thr_key : wl.worst_key));
         if (!__ballot(maybe)) return;
-        if (!(key == key)) key = 3.0e38f;       // NaN: worst finite
-        if (key > 3.0e38f) key = 3.0e38f;       // +inf (overflow): worst finite
         const uint32_t row = (uint32_t)(row0 + grp);
         const uint64_t c = ((uint64_t)ordered_key(key) << 32) | row;
 
