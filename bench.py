@@ -366,7 +366,10 @@ def main():
             dist.broadcast(rad, 0)
             radius = float(rad.item())
 
-    chunk = args.exchange_every or (256 if args.steps >= 1024 else max(16, (args.steps // 4 + 15) // 16 * 16))
+    # queries per local search call and all-gather: one call (one pipeline fill / drain, one
+    # exchange) for short runs, 256 for long ones so that exchanges overlap the next call's sweeps
+    chunk = args.exchange_every or (args.steps if args.steps <= 128 else
+                                    256 if args.steps >= 1024 else (args.steps // 4 + 15) // 16 * 16)
     searcher = None
     if dist_path:
         searcher = ShardedSearcher(lambda q, kk: ix.search_topk(q, kk),

@@ -197,7 +197,8 @@ typedef struct szg_stats {
     double host_enqueue_us;
 } szg_stats;
 
-/* Per-kernel HIP-event timing on the library's own streams (off by default). */
+/* HIP-event timing on the library's own streams (off by default): 1 = events around the scan
+ * launches (scan_ms / timed_launches), 2 = also around each batch's whole pipeline (total_ms). */
 int szg_set_timing(szg_index *ix, int enabled);
 int szg_get_stats(szg_index *ix, szg_stats *out);
 int szg_reset_stats(szg_index *ix);

@@ -305,7 +305,7 @@ struct szg_index {
     int mq_blocks_max = 3;    // query blocks of 16 per shared sweep (LDS image permitting)
     int mq_hits = 1024;       // fused selection: candidates per query the full sweep is expected to collect
                               // (sets the prefix: n_rows * kp / mq_hits rows)
-    bool timing = false;
+    int timing = 0;           // 0 off, 1 HIP events around the scan launches, 2 + around the whole per-batch pipeline
     std::mutex stats_mu;
     // coalescing of concurrent single-query searches (szg_search_topk, n_queries == 1)
     std::mutex comb_mu;
@@ -650,7 +650,7 @@ int enqueue_queries(szg_index *ix, Shard *sh, Ctx *c, const double *q, int nq, c
 {
     HIPCHK(hipSetDevice(sh->device));
     memcpy(c->h_q64, q, sizeof(double) * ix->dim * nq);
-    if (ix->timing) {
+    if (ix->timing >= 2) {
         SiteScope t_(10);
         HIPCHK(hipEventRecord(c->ev_all0, c->stream));
     }
@@ -675,6 +675,9 @@ int enqueue_queries(szg_index *ix, Shard *sh, Ctx *c, const double *q, int nq, c
         HIPCHK(hipMemcpyAsync(c->d_allow, c->h_allow, words * nq * sizeof(uint64_t),
                               hipMemcpyHostToDevice, c->stream));
     }
+    // what the sweeps wait for ends here: work enqueued on this stream afterwards (the first-k
+    // rows' distances) runs beside the sweeps
+    HIPCHK(hipEventRecord(c->ev_up, c->stream));
     return SZG_OK;
 }
 
@@ -717,8 +720,7 @@ int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg
         hipStream_t st = ix->serialize_scans ? sh->scan_stream : c->stream;
         if (st != c->stream) {
             SiteScope t_(1);
-            HIPCHK(hipEventRecord(c->ev_up, c->stream));
-            HIPCHK(hipStreamWaitEvent(st, c->ev_up, 0));
+            HIPCHK(hipStreamWaitEvent(st, c->ev_up, 0));  // recorded by enqueue_queries
         }
         if (ix->timing) {
             SiteScope t_(2);
@@ -824,7 +826,7 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
         HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp * nq,
                               hipMemcpyDeviceToHost, c->stream));
     }
-    if (ix->timing) {
+    if (ix->timing >= 2) {
         SiteScope t_(10);
         HIPCHK(hipEventRecord(c->ev_all1, c->stream));
     }
@@ -1093,7 +1095,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
         ix->stats.mq_launches += 1;
         ix->stats.mq_queries += (uint64_t)nq;
     }
-    if (ix->timing) HIPCHK(hipEventRecord(c->ev_all1, c->stream));
+    if (ix->timing >= 2) HIPCHK(hipEventRecord(c->ev_all1, c->stream));
     return SZG_OK;
 }
 
@@ -1102,7 +1104,7 @@ int finish_timing(szg_index *ix, Ctx *c)
     if (!ix->timing) return SZG_OK;
     float ms_scan = 0, ms_all = 0;
     if (c->timed_scan) HIPCHK(hipEventElapsedTime(&ms_scan, c->ev_scan0, c->ev_scan1));
-    HIPCHK(hipEventElapsedTime(&ms_all, c->ev_all0, c->ev_all1));
+    if (ix->timing >= 2) HIPCHK(hipEventElapsedTime(&ms_all, c->ev_all0, c->ev_all1));
     std::lock_guard<std::mutex> lk(ix->stats_mu);
     if (c->timed_scan) {
         ix->stats.scan_ms += ms_scan;
@@ -1143,8 +1145,9 @@ int run_collect(szg_index *ix, Shard *sh, Ctx *c, int slot, float thr_key, bool 
     for (;;) {
         int rc = ensure_dev(&c->d_collect, &c->collect_cap, want);
         if (rc) return rc;
-        if (ix->timing) HIPCHK(hipEventRecord(c->ev_all0, c->stream));
+        if (ix->timing >= 2) HIPCHK(hipEventRecord(c->ev_all0, c->stream));
         HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(uint32_t), c->stream));
+        HIPCHK(hipEventRecord(c->ev_up, c->stream));  // the sweep must see the zeroed counter
         std::vector<szg::ScanArgs> a(1);
         fill_scan_args(ix, sh, c, has_allow, slot, 1, &a[0]);
         a[0].collect = 1;
@@ -1157,7 +1160,7 @@ int run_collect(szg_index *ix, Shard *sh, Ctx *c, int slot, float thr_key, bool 
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(c->h_count, c->d_count, sizeof(uint32_t), hipMemcpyDeviceToHost,
                               c->stream));
-        if (ix->timing) HIPCHK(hipEventRecord(c->ev_all1, c->stream));
+        if (ix->timing >= 2) HIPCHK(hipEventRecord(c->ev_all1, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         rc = finish_timing(ix, c);
         if (rc) return rc;
@@ -1632,11 +1635,12 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
             if (sh->n_rows == 0) continue;
             t.ctx[s]->sent_n = 0;
             rc = enqueue_queries(ix, sh, t.ctx[s], q, t.nq, mptr);
+            // (before the sweeps: on the context's stream this runs while the scan stream sweeps)
+            if (rc == SZG_OK && !sent.empty()) rc = enqueue_sentinels(ix, sh, t.ctx[s], sent, t.nq);
             if (rc == SZG_OK && !replay_all)
                 rc = nb ? enqueue_topk_mq(ix, sh, t.ctx[s], kp, t.nq, nb, t.any_mask)
                         : enqueue_topk(ix, sh, t.ctx[s], kp, t.nq, t.any_mask);
-            if (rc == SZG_OK && !sent.empty()) rc = enqueue_sentinels(ix, sh, t.ctx[s], sent, t.nq);
-            if (rc == SZG_OK && replay_all && ix->timing) {
+            if (rc == SZG_OK && replay_all && ix->timing >= 2) {
                 const hipError_t e = hipEventRecord(t.ctx[s]->ev_all1, t.ctx[s]->stream);
                 if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "hipEventRecord", e);
             }
@@ -2542,7 +2546,7 @@ int szg_set_timing(szg_index *ix, int enabled)
         (void)hipSetDevice(sh->device);
         (void)hipDeviceSynchronize();
     }
-    ix->timing = enabled != 0;
+    ix->timing = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
     return SZG_OK;
 }
 

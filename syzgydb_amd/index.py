@@ -211,7 +211,8 @@ class ScanIndex:
 
     # -- diagnostics ----------------------------------------------------------
     def set_timing(self, enabled):
-        check(self._L.szg_set_timing(self._h, 1 if enabled else 0), "szg_set_timing")
+        """False / 0 off; True / 1 events around the scan launches; 2 also around each batch's pipeline."""
+        check(self._L.szg_set_timing(self._h, int(enabled)), "szg_set_timing")
 
     def stats(self):
         s = SzgStats()
