@@ -20,7 +20,9 @@ for spec in sys.argv[1:]:
         if radius > 0:
             _, dd, _ = ix.search_topk(q[0], 500)
             radius = float(dd[0, -1])
-            run = lambda qq: [ix.search_radius(x, radius) for x in qq[:32]]
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=3)   # concurrent callers keep the sweeps back to back
+            run = lambda qq: list(pool.map(lambda x: ix.search_radius(x, radius), qq[:96]))
         else:
             run = lambda qq: ix.search_topk(qq, k)
         run(q[:64]); run(q)
