@@ -256,6 +256,11 @@ struct Shard {
     std::mutex chain_mu;
     hipStream_t scan_stream = nullptr;
     uint8_t *zero16 = nullptr;   // 16 zero bytes idle lanes of the multi-query sweep read
+    // device staging of the mutation entry points (load / append / overwrite / read-back): kept
+    // between calls, so AddDocument in a loop pays no hipMalloc / hipFree per row
+    uint8_t *stage = nullptr;
+    size_t stage_cap = 0;
+    std::mutex stage_mu;         // szg_index_read_rows may run beside other readers (szg_pair_distances)
 };
 
 }  // namespace
@@ -1663,27 +1668,45 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
     return rc;
 }
 
+// the shard's staging buffer, at least `bytes` large (kept up to 64 MiB between calls)
+int shard_stage(Shard *sh, size_t bytes, uint8_t **out)
+{
+    if (sh->stage_cap < bytes) {
+        if (sh->stage) (void)hipFree(sh->stage);
+        sh->stage = nullptr;
+        sh->stage_cap = 0;
+        const size_t want = std::max<size_t>(bytes, 4096);
+        hipError_t e = hipMalloc((void **)&sh->stage, want);
+        if (e != hipSuccess) return fail(SZG_E_NOMEM, "hipMalloc(staging)", e);
+        sh->stage_cap = want;
+    }
+    *out = sh->stage;
+    return SZG_OK;
+}
+
 int upload_rows(szg_index *ix, Shard *sh, uint64_t dst_row, const uint8_t *rows, uint64_t n)
 {
     if (n == 0) return SZG_OK;
     HIPCHK(hipSetDevice(sh->device));
     const uint64_t chunk_rows = std::max<uint64_t>(1, (64ull << 20) / ix->row_bytes);
-    uint8_t *stage = nullptr;
     const uint64_t cr = std::min(chunk_rows, n);
-    HIPCHK(hipMalloc((void **)&stage, cr * ix->row_bytes));
-    int rc = SZG_OK;
-    for (uint64_t off = 0; off < n && rc == SZG_OK; off += cr) {
+    uint8_t *stage = nullptr;
+    std::lock_guard<std::mutex> stage_lock(sh->stage_mu);
+    int rc = shard_stage(sh, cr * ix->row_bytes, &stage);
+    if (rc) return rc;
+    // copies and the page-in kernel share the null stream: a chunk's copy waits for the previous
+    // chunk's kernel, one synchronisation at the end
+    hipError_t e = hipSuccess;
+    for (uint64_t off = 0; off < n && e == hipSuccess; off += cr) {
         const uint64_t m = std::min(cr, n - off);
-        hipError_t e = hipMemcpy(stage, rows + off * ix->row_bytes, m * ix->row_bytes,
-                                 hipMemcpyHostToDevice);
+        e = hipMemcpy(stage, rows + off * ix->row_bytes, m * ix->row_bytes, hipMemcpyHostToDevice);
         if (e == hipSuccess)
             e = szg::launch_repack(ix->bits, stage, ix->row_bytes, sh->rows, ix->layout, dst_row + off, m, 0,
                                    nullptr);
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "upload_rows", e);
     }
-    (void)hipFree(stage);
-    return rc;
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) return fail(SZG_E_DEVICE, "upload_rows", e);
+    return SZG_OK;
 }
 
 int shard_reserve(szg_index *ix, Shard *sh, uint64_t rows_needed)
@@ -1973,6 +1996,7 @@ void szg_index_destroy(szg_index *ix)
         for (Ctx *c : sh->all_ctx) ctx_free(c);
         if (sh->scan_stream) (void)hipStreamDestroy(sh->scan_stream);
         (void)hipFree(sh->zero16);
+        (void)hipFree(sh->stage);
         (void)hipFree(sh->rows);
         (void)hipFree(sh->live_bits);
         delete sh;
@@ -2085,20 +2109,22 @@ int szg_index_append_f64(szg_index *ix, const double *vectors, uint64_t n_rows)
     int rc = shard_reserve(ix, sh, sh->n_rows + n_rows);
     if (rc) return rc;
     const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / ((uint64_t)ix->dim * 8));
-    double *stage = nullptr;
-    HIPCHK(hipMalloc((void **)&stage, std::min(chunk, n_rows) * (uint64_t)ix->dim * 8));
-    for (uint64_t off = 0; off < n_rows && rc == SZG_OK; off += chunk) {
+    uint8_t *stage8 = nullptr;
+    std::unique_lock<std::mutex> stage_lock(sh->stage_mu);
+    rc = shard_stage(sh, std::min(chunk, n_rows) * (uint64_t)ix->dim * 8, &stage8);
+    if (rc) return rc;
+    double *stage = reinterpret_cast<double *>(stage8);
+    hipError_t e = hipSuccess;
+    for (uint64_t off = 0; off < n_rows && e == hipSuccess; off += chunk) {
         const uint64_t m = std::min(chunk, n_rows - off);
-        hipError_t e = hipMemcpy(stage, vectors + off * (uint64_t)ix->dim, m * (uint64_t)ix->dim * 8,
-                                 hipMemcpyHostToDevice);
+        e = hipMemcpy(stage, vectors + off * (uint64_t)ix->dim, m * (uint64_t)ix->dim * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess)
             e = szg::launch_synth(ix->bits, sh->rows, ix->layout, sh->n_rows + off, ix->dim, m, 0, 0, stage,
                                   nullptr);
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "append_f64", e);
     }
-    (void)hipFree(stage);
-    if (rc) return rc;
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    stage_lock.unlock();
+    if (e != hipSuccess) return fail(SZG_E_DEVICE, "append_f64", e);
     rc = shard_set_live(sh, sh->n_rows, sh->n_rows + n_rows);
     if (rc) return rc;
     sh->n_rows += n_rows;
@@ -2117,13 +2143,15 @@ int szg_index_overwrite_f64(szg_index *ix, uint64_t row, const double *vector)
     if (!sh) return fail(SZG_E_RANGE, "row out of range");
     HIPCHK(hipSetDevice(sh->device));
     HIPCHK(hipDeviceSynchronize());
-    double *stage = nullptr;
-    HIPCHK(hipMalloc((void **)&stage, (size_t)ix->dim * 8));
+    uint8_t *stage8 = nullptr;
+    std::lock_guard<std::mutex> stage_lock(sh->stage_mu);
+    int rc = shard_stage(sh, (size_t)ix->dim * 8, &stage8);
+    if (rc) return rc;
+    double *stage = reinterpret_cast<double *>(stage8);
     hipError_t e = hipMemcpy(stage, vector, (size_t)ix->dim * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = szg::launch_synth(ix->bits, sh->rows, ix->layout, local, ix->dim, 1, 0, 0, stage, nullptr);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    (void)hipFree(stage);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) return fail(SZG_E_DEVICE, "overwrite_f64", e);
     return SZG_OK;
     SZG_CATCH
@@ -2287,14 +2315,20 @@ int szg_index_read_rows(szg_index *ix, uint64_t first_row, uint64_t n_rows, uint
         if (hi <= lo) continue;
         HIPCHK(hipSetDevice(sh->device));
         const uint64_t m = hi - lo;
+        const uint64_t cr = std::min<uint64_t>(m, std::max<uint64_t>(1, (64ull << 20) / ix->row_bytes));
         uint8_t *stage = nullptr;
-        HIPCHK(hipMalloc((void **)&stage, m * ix->row_bytes));
-        hipError_t e = szg::launch_repack(ix->bits, stage, ix->row_bytes, sh->rows, ix->layout, lo - sh->first, m,
-                                          1, nullptr);
-        if (e == hipSuccess)
-            e = hipMemcpy(out + (lo - first_row) * ix->row_bytes, stage, m * ix->row_bytes,
-                          hipMemcpyDeviceToHost);
-        (void)hipFree(stage);
+        std::lock_guard<std::mutex> stage_lock(sh->stage_mu);
+        int rc = shard_stage(sh, cr * ix->row_bytes, &stage);
+        if (rc) return rc;
+        hipError_t e = hipSuccess;
+        for (uint64_t off = 0; off < m && e == hipSuccess; off += cr) {
+            const uint64_t mm = std::min(cr, m - off);
+            e = szg::launch_repack(ix->bits, stage, ix->row_bytes, sh->rows, ix->layout, lo - sh->first + off, mm, 1,
+                                   nullptr);
+            if (e == hipSuccess)
+                e = hipMemcpy(out + (lo - first_row + off) * ix->row_bytes, stage, mm * ix->row_bytes,
+                              hipMemcpyDeviceToHost);
+        }
         if (e != hipSuccess) return fail(SZG_E_DEVICE, "read_rows", e);
     }
     return SZG_OK;
