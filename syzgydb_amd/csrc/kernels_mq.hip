@@ -44,6 +44,9 @@ namespace {
 #ifndef SZG_MQ8_WAVES
 #define SZG_MQ8_WAVES 12  // waves per block (one block per CU) of the int8 sweep
 #endif
+#ifndef SZG_ABL
+#define SZG_ABL 0  // timing experiments (answers become wrong): bit 0 no tile finish, bit 1 no norm work, bit 2 no MFMA,
+#endif             // bit 3 keys formed but hits dropped
 [[maybe_unused]] constexpr int kRingMq = SZG_MQ_RING;
 [[maybe_unused]] constexpr int kMq8Threads = 64 * SZG_MQ8_WAVES;
 
@@ -269,7 +272,9 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
         float x_[E];                                                                     \
         _Pragma("unroll") for (int d = 0; d < 4; d++)                                    \
             decode_dword<QBITS, false>(w_[d], 0, 0, x_ + d * N);                         \
-        _Pragma("unroll") for (int i = 0; i < E; i++) nrm = fmaf(x_[i], x_[i], nrm);     \
+        if (SZG_ABL & 2) nrm = fmaf(x_[0], x_[0], nrm); /* 1 of E terms: same statistics, a quarter of the work */ \
+        else                                                                             \
+            _Pragma("unroll") for (int i = 0; i < E; i++) nrm = fmaf(x_[i], x_[i], nrm); \
         const int qcur_ = qbase + cs * qstep;                                            \
         const int qnext_ = qbase + (cs + 1 == steps ? 0 : cs + 1) * qstep;               \
         _Pragma("unroll") for (int g = 0; g < G4; g++)                                   \
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
             _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
                 acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc_[b].w, x_[4 * g + 3], acc[b], 0, 0, 0); \
         }                                                                                \
-        if (QBITS == 32) {                                                               \
+        if (QBITS == 32 && !(SZG_ABL & 2)) {                                             \
             nz |= v_.x | v_.y;                                                           \
             nz |= v_.z | v_.w;                                                           \
         }                                                                                \
@@ -478,9 +483,6 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 // comes from two v_dot4_i32_i8 per dword.  The finish is RowAcc<8>::finish's, so the key
 // and its error bound (key_eps, integer branch) are the single-query path's.
 typedef int v4i32 __attribute__((ext_vector_type(4)));
-#ifndef SZG_ABL
-#define SZG_ABL 0  // timing experiments (answers become wrong): bit 0 no tile finish, bit 1 no norm dots, bit 2 no MFMA
-#endif
 
 template <int NB, int METRIC, bool COLLECT, bool FAST = false, int RB = 8>
 __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a)
