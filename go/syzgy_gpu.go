@@ -157,6 +157,10 @@ func (m *gpuMirror) remove(id uint64) {
 	}
 }
 
+// touch mirrors UpdateDocument (collection.go:490-509): the vectors do not change, but filters
+// see metadata, so cached filter masks no longer apply.  Called under c.mutex.Lock.
+func (m *gpuMirror) touch() { m.version++ }
+
 func (m *gpuMirror) close() {
 	if m.h != nil {
 		C.szg_index_destroy(m.h)
