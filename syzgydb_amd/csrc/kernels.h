@@ -218,6 +218,12 @@ hipError_t launch_rerank(int qbits, int metric, const uint8_t *rows, RowLayout l
                          const double *query_f64, const uint64_t *cands, const uint32_t *n_cands_dev,
                          uint32_t n_cands_max, int n_queries, RerankOut *out, hipStream_t stream);
 
+// The same for pairs of STORED rows (computeAverageDistance, collection.go:372-398): out[i] =
+// c.distance(row left_rows[i], row (uint32)right_cands[i]), both decoded exactly on the device.
+hipError_t launch_rerank_pairs(int qbits, int metric, const uint8_t *rows, RowLayout layout, int dim,
+                               const uint32_t *left_rows, const uint64_t *right_cands, uint32_t n_pairs,
+                               RerankOut *out, hipStream_t stream);
+
 // Page-in transform: n_rows rows in the reference encoding at `ref` (big-endian 16/32/64-bit,
 // row_bytes apart) <-> rows [first_row, first_row + n_rows) of the resident mirror `rows`.
 hipError_t launch_repack(int qbits, uint8_t *ref, uint32_t row_bytes, uint8_t *rows, RowLayout layout,

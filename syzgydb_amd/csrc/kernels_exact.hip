@@ -148,7 +148,7 @@ template <int QBITS, int METRIC>
 __global__ __launch_bounds__(64) void rerank_kernel(const uint8_t *rows, RowLayout lay, int dim,
                                                     const double *query, const uint64_t *cands,
                                                     const uint32_t *n_dev, uint32_t n_max,
-                                                    RerankOut *out)
+                                                    RerankOut *out, const uint32_t *left_rows)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int CH = 1024;                        // elements per LDS chunk
@@ -175,12 +175,16 @@ __global__ __launch_bounds__(64) void rerank_kernel(const uint8_t *rows, RowLayo
             continue;
         }
         const uint32_t row = (uint32_t)c;
+        // left_rows: the "query" of candidate ci is the stored row left_rows[ci], decoded exactly --
+        // c.distance(doc1.Vector, doc2.Vector) of computeAverageDistance (collection.go:372-398)
+        const bool pair = left_rows != nullptr;
+        const uint32_t lrow = pair ? left_rows[ci] : 0u;
         double s = 0.0;
         for (int base = 0; base < dim; base += CH) {
             const int m = min(CH, dim - base);
             __syncthreads();
             for (int i = lane; i < m; i += 64) {
-                const double x = query[base + i];
+                const double x = pair ? decode_elem<QBITS>(rows, lay, lrow, base + i) : query[base + i];
                 const double y = decode_elem<QBITS>(rows, lay, row, base + i);
                 if (METRIC == kEuclidean) {
                     const double diff = __dsub_rn(x, y);
@@ -368,17 +372,18 @@ __global__ void f64_probe_kernel(int op, const double *a, const double *b, doubl
 template <int QBITS>
 hipError_t launch_rerank_q(int metric, const uint8_t *rows, RowLayout lay, int dim,
                            const double *q, const uint64_t *cands, const uint32_t *n_dev,
-                           uint32_t n_max, int n_queries, RerankOut *out, hipStream_t stream)
+                           uint32_t n_max, int n_queries, RerankOut *out, hipStream_t stream,
+                           const uint32_t *left_rows = nullptr)
 {
     if (n_max == 0 || n_queries == 0) return hipSuccess;
     const dim3 grid(n_max < 4096u ? n_max : 4096u, n_queries);
     const size_t lds = (size_t)1024 * 3 * sizeof(double);
     if (metric == kCosine)
         hipLaunchKernelGGL((rerank_kernel<QBITS, kCosine>), grid, dim3(64), lds, stream, rows,
-                           lay, dim, q, cands, n_dev, n_max, out);
+                           lay, dim, q, cands, n_dev, n_max, out, left_rows);
     else
         hipLaunchKernelGGL((rerank_kernel<QBITS, kEuclidean>), grid, dim3(64), lds, stream,
-                           rows, lay, dim, q, cands, n_dev, n_max, out);
+                           rows, lay, dim, q, cands, n_dev, n_max, out, left_rows);
     return hipGetLastError();
 }
 
@@ -394,6 +399,20 @@ hipError_t launch_rerank(int qbits, int metric, const uint8_t *rows, RowLayout p
     case 16: return launch_rerank_q<16>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream);
     case 32: return launch_rerank_q<32>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream);
     case 64: return launch_rerank_q<64>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_rerank_pairs(int qbits, int metric, const uint8_t *rows, RowLayout pitch, int dim,
+                               const uint32_t *left_rows, const uint64_t *right_cands, uint32_t n_pairs,
+                               RerankOut *out, hipStream_t stream)
+{
+    switch (qbits) {
+    case 4: return launch_rerank_q<4>(metric, rows, pitch, dim, nullptr, right_cands, nullptr, n_pairs, 1, out, stream, left_rows);
+    case 8: return launch_rerank_q<8>(metric, rows, pitch, dim, nullptr, right_cands, nullptr, n_pairs, 1, out, stream, left_rows);
+    case 16: return launch_rerank_q<16>(metric, rows, pitch, dim, nullptr, right_cands, nullptr, n_pairs, 1, out, stream, left_rows);
+    case 32: return launch_rerank_q<32>(metric, rows, pitch, dim, nullptr, right_cands, nullptr, n_pairs, 1, out, stream, left_rows);
+    case 64: return launch_rerank_q<64>(metric, rows, pitch, dim, nullptr, right_cands, nullptr, n_pairs, 1, out, stream, left_rows);
     default: return hipErrorInvalidValue;
     }
 }

@@ -2243,28 +2243,59 @@ int szg_pair_distances(szg_index *ix, const uint64_t *rows_a, const uint64_t *ro
     SZG_TRY
     if (!ix || ((!rows_a || !rows_b || !out_dist) && n_pairs)) return fail(SZG_E_INVALID, "null argument");
     if (n_pairs == 0) return SZG_OK;
-    // pairs sharing a left row go down in one szg_distances call with that row as the query
-    std::vector<uint64_t> order(n_pairs);
-    for (uint64_t i = 0; i < n_pairs; i++) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) { return rows_a[x] < rows_a[y]; });
+    const uint64_t total = szg_index_rows(ix);
+    for (uint64_t i = 0; i < n_pairs; i++)
+        if (rows_a[i] < ix->row_base || rows_a[i] - ix->row_base >= total || rows_b[i] < ix->row_base ||
+            rows_b[i] - ix->row_base >= total)
+            return fail(SZG_E_RANGE, "row out of range");
+    std::vector<uint8_t> done(n_pairs, 0);
+    // pairs whose two rows live in one shard: both decoded and compared on the device, one launch per shard
+    for (Shard *sh : ix->shards) {
+        if (sh->n_rows == 0) continue;
+        std::vector<uint32_t> left;
+        std::vector<uint64_t> right, where;
+        for (uint64_t i = 0; i < n_pairs; i++) {
+            const uint64_t a = rows_a[i] - ix->row_base, b = rows_b[i] - ix->row_base;
+            if (a >= sh->first && a < sh->first + sh->n_rows && b >= sh->first && b < sh->first + sh->n_rows) {
+                left.push_back((uint32_t)(a - sh->first));
+                right.push_back(b - sh->first);
+                where.push_back(i);
+            }
+        }
+        if (where.empty()) continue;
+        Ctx *c = ctx_acquire(sh);
+        CtxGuard guard{sh, c};
+        HIPCHK(hipSetDevice(sh->device));
+        const size_t n = where.size();
+        int rc = ensure_dev(&c->d_collect, &c->collect_cap, n + (n + 1) / 2);  // right rows (u64) + left rows (u32)
+        if (rc) return rc;
+        rc = ensure_dev(&c->d_out, &c->d_out_cap, n);
+        if (rc) return rc;
+        rc = ensure_host(&c->h_out, &c->h_out_cap, n);
+        if (rc) return rc;
+        uint32_t *d_left = reinterpret_cast<uint32_t *>(c->d_collect + n);
+        HIPCHK(hipMemcpyAsync(c->d_collect, right.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d_left, left.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(szg::launch_rerank_pairs(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, d_left, c->d_collect,
+                                        (uint32_t)n, c->d_out, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));  // also keeps `left` / `right` alive until the copies are done
+        for (size_t i = 0; i < n; i++) {
+            out_dist[where[i]] = c->h_out[i].dist;
+            done[where[i]] = 1;
+        }
+    }
+    // pairs that straddle two shards (devices): the left row is read back, decoded as the reference
+    // does and sent as the query of a szg_distances call on the right row's shard
     std::vector<uint8_t> bytes((size_t)szg_row_bytes(ix->bits, ix->dim));
-    std::vector<double> vec(ix->dim), d;
-    std::vector<uint64_t> rhs;
-    for (uint64_t s = 0; s < n_pairs;) {
-        uint64_t e = s;
-        while (e < n_pairs && rows_a[order[e]] == rows_a[order[s]]) e++;
-        const uint64_t a = rows_a[order[s]];
-        if (a < ix->row_base) return fail(SZG_E_RANGE, "row out of range");
-        int rc = szg_index_read_rows(ix, a - ix->row_base, 1, bytes.data());
+    std::vector<double> vec(ix->dim);
+    for (uint64_t i = 0; i < n_pairs; i++) {
+        if (done[i]) continue;
+        int rc = szg_index_read_rows(ix, rows_a[i] - ix->row_base, 1, bytes.data());
         if (rc) return rc;
         decode_row_host(bytes.data(), ix->dim, ix->bits, vec.data());
-        rhs.clear();
-        for (uint64_t i = s; i < e; i++) rhs.push_back(rows_b[order[i]]);
-        d.assign(rhs.size(), 0.0);
-        rc = szg_distances(ix, vec.data(), rhs.data(), rhs.size(), d.data());
+        rc = szg_distances(ix, vec.data(), &rows_b[i], 1, &out_dist[i]);
         if (rc) return rc;
-        for (uint64_t i = s; i < e; i++) out_dist[order[i]] = d[i - s];
-        s = e;
     }
     return SZG_OK;
     SZG_CATCH
