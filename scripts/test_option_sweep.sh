@@ -13,13 +13,12 @@ run() {  # $1 = label, rest = pytest arguments
   rc=$?
   if [ $rc -ne 0 ]; then failed=$((failed + 1)); echo "FAILED ($rc): $label" >> $out; fi
 }
-for opts in "serialize_scans=0" "queries_per_launch=1" "queries_per_launch=3,blocks_per_cu=1" "shape_kernels=0,block_threads=128" \
-            "mq_fused=0,mq_i8=0" "mq_tail_overlap=1,mq_blocks=2" "multi_query=0,query_batch=5" "contexts=1,blocks_per_cu=6" "mask_dense=0,coalesce=0" \
-            "mq_min=8,tie_mode=0" "tie_mode=1"; do
-  desel=""
-  # tie_mode=1 keeps the fast answer where the reference's depends on its heap history: the
-  # tests that pin that history do not apply
-  if [ "$opts" = "tie_mode=1" ]; then desel="--deselect tests/test_gpu_parity.py::test_nan_among_the_first_k_rows_poisons_the_heap_like_the_reference --deselect tests/test_gpu_parity.py::test_nan_and_inf_elements_in_stored_rows --deselect tests/test_gpu_collection.py::test_tie_order_follows_sorted_string_ids_after_appends -k not(fuzz)and(not(golden))"; fi
+# (tie_mode=1 changes the contract -- any valid top-k among equal distances -- and has its own test,
+# tests/test_gpu_parity.py::test_tie_mode_1_returns_a_valid_topk.)
+# SWEEP_SETS="a=1 b=2,c=3" restricts the first loop to those sets (re-checking a fix)
+for opts in ${SWEEP_SETS:-serialize_scans=0 queries_per_launch=1 queries_per_launch=3,blocks_per_cu=1 shape_kernels=0,block_threads=128 \
+            mq_fused=0,mq_i8=0 mq_tail_overlap=1,mq_blocks=2 multi_query=0,query_batch=5 contexts=1,blocks_per_cu=6 mask_dense=0,coalesce=0 \
+            mq_min=8,tie_mode=0 ring=8,mq_hits=256}; do
   run "$opts" tests -m gpu -q -x --ignore=tests/test_gpu_fullsize.py --ignore=tests/test_gpu_bench_launch.py \
       --deselect tests/test_gpu_multiquery.py::test_shared_sweep_matches_oracle \
       --deselect tests/test_gpu_multiquery.py::test_shared_sweep_quantized_rows \
@@ -27,10 +26,10 @@ for opts in "serialize_scans=0" "queries_per_launch=1" "queries_per_launch=3,blo
       --deselect tests/test_gpu_multiquery.py::test_shared_sweep_euclidean_far_from_origin \
       --deselect tests/test_gpu_multiquery.py::test_shared_sweep_int8_mfma \
       --deselect tests/test_gpu_multiquery.py::test_fused_selection_overflow_falls_back \
-      --deselect tests/test_gpu_collection.py::test_concurrent_single_queries_are_coalesced $desel
+      --deselect tests/test_gpu_collection.py::test_concurrent_single_queries_are_coalesced
 done
 # shared-sweep variants on the shared-sweep tests (their statistics do not depend on these)
-for opts in "mq_fused=0" "mq_i8=0" "mq_tail_overlap=1" "mq_fused=0,mq_tail_overlap=1,serialize_scans=0"; do
+for opts in ${SWEEP_MQ_SETS-mq_fused=0 mq_i8=0 mq_tail_overlap=1 mq_fused=0,mq_tail_overlap=1,serialize_scans=0}; do
   run "multiquery tests, $opts" tests/test_gpu_multiquery.py -q -x \
       --deselect tests/test_gpu_multiquery.py::test_fused_selection_overflow_falls_back
 done

@@ -1,5 +1,7 @@
 """The shared (multi-query, MFMA) sweep against the oracle: same bar as the
 single-query path -- ids identical, float64 distances bit-equal."""
+import os
+
 import numpy as np
 import pytest
 
@@ -7,6 +9,11 @@ import oracle as orc
 from syzgydb_amd import ScanIndex, SZG_COSINE, SZG_EUCLIDEAN
 
 pytestmark = pytest.mark.gpu
+
+# statistics of a particular path are asserted only under the default tunables (scripts/test_option_sweep.sh
+# re-runs this file with SZG_OPTIONS set: the ANSWERS must not change, the path taken may)
+DEFAULT_TUNABLES = not os.environ.get("SZG_OPTIONS")
+TIE_EXACT = "tie_mode=1" not in os.environ.get("SZG_OPTIONS", "")
 
 
 def check(ix, rows, dim, Q, k, allow=None, bits=32, metric=1):
@@ -61,7 +68,8 @@ def test_shared_sweep_two_shards():
     with ScanIndex(dim, 32, SZG_COSINE, devices=[0, 0]) as ix:
         ix.load(rows)
         check(ix, rows, dim, Q, 10)
-        assert ix.stats()["mq_launches"] == 2  # one shared sweep per shard
+        if DEFAULT_TUNABLES:
+            assert ix.stats()["mq_launches"] == 2  # one shared sweep per shard
 
 
 def test_shared_sweep_masks_tombstones_and_escalation():
@@ -81,7 +89,10 @@ def test_shared_sweep_masks_tombstones_and_escalation():
         ix.set_option("force_escalate", 1)
         ix.reset_stats()
         check(ix, rows, dim, Q[:16], 5, allow=allow2)
-        assert ix.stats()["escalations"] == 16 and ix.stats()["mq_queries"] == 16
+        if DEFAULT_TUNABLES:
+            assert ix.stats()["escalations"] == 16 and ix.stats()["mq_queries"] == 16
+    if not TIE_EXACT:
+        return
     # duplicates: ties across the candidate boundary -> escalation / exact replay
     base = orc.synth_vectors(5, 0, 6, 16)
     vecs = np.repeat(base, 200, axis=0)
@@ -90,7 +101,8 @@ def test_shared_sweep_masks_tombstones_and_escalation():
     with ScanIndex(16, 32, SZG_COSINE) as ix:
         ix.load(rows)
         check(ix, rows, 16, Q, 10)
-        assert ix.stats()["mq_queries"] == 16
+        if DEFAULT_TUNABLES:
+            assert ix.stats()["mq_queries"] == 16
 
 
 def test_shared_sweep_zero_rows_and_zero_query():

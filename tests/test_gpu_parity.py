@@ -334,3 +334,30 @@ def test_k_beyond_the_fused_selection(bits, metric):
         assert ix.stats()["full_replays"] >= 6
         allow = (np.arange(n) % 3 != 0)[None, :].repeat(2, axis=0)
         _check_all(ix, rows, dim, bits, metric, queries, 5000, allow=allow)
+
+
+@pytest.mark.parametrize("bits,metric,dim", [(4, 1, 3), (8, 0, 2), (32, 1, 16)])
+def test_tie_mode_1_returns_a_valid_topk(bits, metric, dim):
+    """tie_mode=1 trades the reference's heap-history order among EQUAL distances for speed (no
+    exact replay): the answer must still be a correct top-k -- ascending, every distance the
+    reference's float64 value for its row, and the same multiset of distances as the oracle's."""
+    n, k = 1500, 12
+    rng = np.random.default_rng(bits)
+    vec = np.round(rng.uniform(-1, 1, (n, dim)) * 2) / 2        # coarse grid: many exactly equal distances
+    rows = orc.encode_rows(vec, bits)
+    Q = rng.uniform(-1, 1, (6, dim))
+    with ScanIndex(dim, bits, metric) as ix:
+        ix.load(rows)
+        ix.set_option("tie_mode", 1)
+        for mq in (0, 1):
+            ix.set_option("multi_query", mq)
+            r, d, c = ix.search_topk(Q, k)
+            assert ix.stats()["full_replays"] == 0
+            for qi in range(Q.shape[0]):
+                want_all = orc.all_distances(rows, dim, bits, metric, Q[qi])
+                _, o_dist, _ = orc.search_exact(rows, dim, bits, metric, Q[qi], k=k)
+                got_r, got_d = r[qi, : c[qi]], d[qi, : c[qi]]
+                assert c[qi] == len(o_dist) and len(set(int(x) for x in got_r)) == c[qi]
+                assert (np.diff(got_d) >= 0).all()
+                assert (got_d == want_all[got_r.astype(np.int64)]).all()
+                assert (np.sort(got_d) == np.sort(np.asarray(o_dist))).all()

@@ -63,13 +63,18 @@ dist.destroy_process_group()
 '''
 
 
-def test_two_rank_gloo_sharded_search(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_sharded_search(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
     env = dict(os.environ)
     env["MASTER_ADDR"] = "127.0.0.1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)]
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+           "--master-addr", "127.0.0.1", "--master-port", str(29631 + world), str(script)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    assert "SHARDED_OK world=2" in p.stdout
+    assert "SHARDED_OK world=%d" % world in p.stdout
