@@ -414,8 +414,11 @@ def main():
     sync()
     t0 = time.perf_counter()
     res_rows, res_dist = run(qt)  # returns when every result is on the host
-    sync()
-    elapsed = time.perf_counter() - t0
+    if torch is not None and (backend == "nccl" or not dist_path) and torch.cuda.is_available():
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0   # this rank's K steps, device idle; the MAX over ranks follows the barrier
+    if dist is not None:
+        dist.barrier()
     stats = ix.stats()
     ix.set_timing(False)
     if radius > 0:

@@ -205,9 +205,11 @@ class ShardedSearcher:
         """Pipelined form for throughput: the local sweeps of chunk i+1 run in a worker
         thread (the C call releases the GIL) while this thread exchanges and merges
         chunk i.  Every rank must call it with the same chunking."""
-        from concurrent.futures import ThreadPoolExecutor
         q = np.ascontiguousarray(queries, dtype=np.float64)
         chunks = [q[i:i + chunk] for i in range(0, q.shape[0], chunk)]
+        if len(chunks) == 1:   # nothing to overlap: no worker thread
+            return self.exchange(self.local_search(chunks[0], k + 1), k)
+        from concurrent.futures import ThreadPoolExecutor
         outs = []
         with ThreadPoolExecutor(max_workers=1) as ex:
             futs = [ex.submit(self.local_search, c, k + 1) for c in chunks]
