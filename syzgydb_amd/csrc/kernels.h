@@ -183,6 +183,11 @@ hipError_t launch_mq_thr(const uint64_t *lists, int kp, int n_queries, float *th
 hipError_t launch_cand_select(const uint64_t *cand_buf, const uint32_t *cand_count, uint32_t cand_cap,
                               int kp, int n_queries, uint64_t *lists, hipStream_t stream);
 size_t mq_lds_bytes(int qbits, int r16, int nb);
+// float32 re-score of the collected candidates of a bfloat16 sweep (32-bit rows): replaces the key in every
+// candidate word; qscale[q] = 1/|q| (cosine) or 1 (euclid), the float32 query is (float)(q64 * qscale)
+hipError_t launch_cand_rescore(int metric, const uint8_t *rows, uint32_t pitch, int dim, const double *q64,
+                               const double *qscale, uint64_t *cand_buf, const uint32_t *cand_count,
+                               uint32_t cand_cap, int n_queries, hipStream_t stream);
 
 // Exact integer shared sweep for 8-bit rows (v_mfma_i32_16x16x64_i8).  MqArgs.queries is
 // the image [64-byte step][digit plane h,m,l][query block][lane = chunk*16 + query][16 bytes]
@@ -194,6 +199,13 @@ size_t mq_lds_bytes(int qbits, int r16, int nb);
 size_t mq_i8_image_bytes(int row_bits, int r16, int nb);   // digit image only
 size_t mq_i8_lds_bytes(int row_bits, int r16, int nb);     // image + constants table + hit buffers
 hipError_t launch_mq_score_i8(int row_bits, const MqArgs &a, int nb, int grid, hipStream_t stream);
+// bfloat16 shared sweep for 32-bit rows of whole 64-byte steps (v_mfma_f32_16x16x32_bf16): MqArgs.queries is the
+// image [32-element step][query block][lane = chunk*16 + query][8 bf16]: slots 0..3 = elements 4*chunk + 0..3 of the
+// step's first 16, slots 4..7 = the same of its second 16 (zeros where the row has ended)
+size_t mq_bf16_image_bytes(int r16, int nb);
+int mq_bf16_image_natural();  // 1: the built kernel wants lane (query, k-group g) = elements 8g..8g+7 of the step
+size_t mq_bf16_lds_bytes(int r16, int nb);
+hipError_t launch_mq_score_bf16(const MqArgs &a, int nb, int grid, hipStream_t stream);
 hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStream_t stream);  // a.metric picks the key
 hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_rows,
                             const uint64_t *live_bits, const uint64_t *allow_bits,

@@ -47,7 +47,15 @@ namespace {
 #ifndef SZG_ABL
 #define SZG_ABL 0  // timing experiments (answers become wrong): bit 0 no tile finish, bit 1 no norm work, bit 2 no MFMA,
 #endif             // bit 3 keys formed but hits dropped
+#ifndef SZG_MQB_STAGED
+#define SZG_MQB_STAGED 1  // bfloat16 sweep: 128-byte row segments per load, operands through LDS (0: direct, 64-byte)
+#endif
+#ifndef SZG_MQB_WAVES
+#define SZG_MQB_WAVES 8  // waves per block (one block per CU) of the bfloat16 sweep: 8 x 2 steps x 2 KiB = 32 KiB in
+#endif                    // flight per CU (16 waves or 3 steps: -3..-6 %, as on every streaming kernel here)
 [[maybe_unused]] constexpr int kRingMq = SZG_MQ_RING;
+[[maybe_unused]] constexpr int kMqbThreads = 64 * SZG_MQB_WAVES;
+typedef int v4i32b __attribute__((ext_vector_type(4)));
 [[maybe_unused]] constexpr int kMq8Threads = 64 * SZG_MQ8_WAVES;
 
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
@@ -469,6 +477,449 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 
 #endif  // SZG_MQ_PART >= 4
 
+#if SZG_MQ_PART == 3
+// ---- bfloat16 shared sweep, 32-bit rows ---------------------------------------------------------------------------
+//
+// The sweep only has to RANK: what it keeps is re-scored in float64 and certified against the
+// bound of its own arithmetic (key_eps, bf16 branch), so its products need not carry 24 bits.
+// Rows and queries are rounded to bfloat16 on the fly (v_cvt_pk_bf16_f32, round to nearest
+// even: relative error <= 2^-9 each, same exponent range as float32) and multiplied by
+// v_mfma_f32_16x16x32_bf16 -- 16 x the rate of the float32 MFMA, which turns the 48-query
+// sweep from matrix-bound (0.64 ms at 1M x 768) into a plain stream of the rows.  By
+// Cauchy-Schwarz the dot product moves by at most (2^-8 + 2^-18) |x| |q|, i.e. 0.0039 in -cos:
+// a band that holds a few dozen rows of a million, all of which the float64 re-rank sees.
+//
+// A wave owns a tile of 16 rows; lane (row = lane & 15, chunk = lane >> 4) loads 16 bytes of
+// two consecutive 64-byte steps (one 128-byte line per row, both halves requested back to
+// back), converts the 8 floats to one B operand, and multiplies with one A operand per query
+// block from LDS (image [32-element step][query block][lane = chunk*16 + query][8 bf16], the
+// same element in the same slot of both operands).  Row norms (of the float32 values) are
+// VALU side work as in mq_score_kernel.  Whole 64-byte steps only (dim % 16 == 0); other
+// shapes use mq_score_kernel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef SZG_MQB_RING
+#define SZG_MQB_RING 2  // 32-byte (two-load) steps per lane in flight
+#endif
+constexpr int kRingB = SZG_MQB_RING;
+
+template <int NB, int METRIC, bool COLLECT>
+__global__ __launch_bounds__(kMqbThreads) void mq_score_bf16_kernel(const MqArgs a)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int steps = a.r16 / 4;          // 64-byte steps per row (whole ones)
+    const int SS = (steps + 1) / 2;       // 32-element steps; an odd row ends with half a one
+    const bool odd = (steps & 1) != 0;
+    const int n16 = SS * NB * 64;         // image, 16-byte words
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (int i = tid; i < n16; i += blockDim.x) dst[i] = src[i];
+        if (COLLECT && tid < 48)
+            reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
+    }
+    const v4i32b *qimg = reinterpret_cast<const v4i32b *>(smem);
+    const float *thr_lds = reinterpret_cast<const float *>(smem + (size_t)n16 * 16);
+    HitBuf hb;
+    {
+        uint8_t *base = smem + (size_t)n16 * 16 + 48 * sizeof(float);
+        hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
+        hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
+        hb.n = 0;
+    }
+
+    const int trow = lane & 15;
+    const int c = lane >> 4;
+    const uint64_t n_tiles = ((uint64_t)a.n_rows + 15) / 16;
+    const uint64_t tile_stride = (uint64_t)gridDim.x * nwaves;
+    const uint64_t tile_first = (uint64_t)blockIdx.x * nwaves + wave;
+    const uint64_t n_it = tile_first < n_tiles ? (n_tiles - tile_first + tile_stride - 1) / tile_stride : 0;
+    const uint64_t NP = n_it * (uint64_t)SS;
+
+    uint64_t itile = tile_first;
+    int is = 0;
+    uint64_t ctile = tile_first;
+    int cs = 0;
+
+    u32x4 ring_a[kRingB], ring_b[kRingB];
+    f32x4 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float nrm = 0.f;
+    uint32_t nz = 0;
+    v4i32b qn[NB];  // A operands of the step about to be multiplied (one ahead)
+
+    auto row_ptr = [&](uint64_t tile) -> const uint8_t * {
+        const uint64_t r = min(tile * 16 + trow, (uint64_t)a.n_rows - 1);  // past the end: a valid row, discarded
+        return a.rows + (size_t)r * a.pitch + (size_t)c * 16;
+    };
+    const uint8_t *iptr = row_ptr(tile_first);
+
+    // the half step at the end of an odd row reads its one real piece twice; the image holds
+    // zeros against the second copy and the norm skips it
+#define MQB_ISSUE(u)                                                                     \
+    {                                                                                    \
+        ring_a[u] = load_nt(iptr);                                                       \
+        ring_b[u] = load_nt(iptr + ((odd && is == SS - 1) ? 0 : 64));                    \
+        if (++is == SS) {                                                                \
+            is = 0;                                                                      \
+            itile += tile_stride;                                                        \
+            iptr = row_ptr(itile);                                                       \
+        } else {                                                                         \
+            iptr += 128;                                                                 \
+        }                                                                                \
+    }
+
+#define MQB_CONSUME(u)                                                                   \
+    {                                                                                    \
+        const u32x4 va_ = ring_a[u], vb_ = ring_b[u];                                    \
+        const bool half_ = odd && cs == SS - 1;                                          \
+        const float xa_[4] = {__uint_as_float(va_.x), __uint_as_float(va_.y), __uint_as_float(va_.z),       \
+                              __uint_as_float(va_.w)};                                   \
+        const float xb_[4] = {__uint_as_float(vb_.x), __uint_as_float(vb_.y), __uint_as_float(vb_.z),       \
+                              __uint_as_float(vb_.w)};                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) nrm = fmaf(xa_[i], xa_[i], nrm);   \
+        if (!half_) {                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; i++) nrm = fmaf(xb_[i], xb_[i], nrm); \
+        }                                                                                \
+        nz |= va_.x | va_.y;                                                             \
+        nz |= va_.z | va_.w;                                                             \
+        nz |= vb_.x | vb_.y;                                                             \
+        nz |= vb_.z | vb_.w;                                                             \
+        const bf16x2 t0_ = __builtin_convertvector(f32x2{xa_[0], xa_[1]}, bf16x2);       \
+        const bf16x2 t1_ = __builtin_convertvector(f32x2{xa_[2], xa_[3]}, bf16x2);       \
+        const bf16x2 t2_ = __builtin_convertvector(f32x2{xb_[0], xb_[1]}, bf16x2);       \
+        const bf16x2 t3_ = __builtin_convertvector(f32x2{xb_[2], xb_[3]}, bf16x2);       \
+        const bf16x8 bop_ = {t0_[0], t0_[1], t1_[0], t1_[1], t2_[0], t2_[1], t3_[0], t3_[1]}; \
+        const int qnext_ = lane + (cs + 1 == SS ? 0 : cs + 1) * (NB * 64);               \
+        _Pragma("unroll") for (int b = 0; b < NB; b++)                                   \
+        {                                                                                \
+            const v4i32b qc_ = qn[b];                                                    \
+            qn[b] = qimg[qnext_ + b * 64];                                               \
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qc_), bop_, acc[b], 0, 0, 0); \
+        }                                                                                \
+        if (++cs == SS) {                                                                \
+            nz &= 0x7FFFFFFFu;                                                           \
+            finish_tile(ctile);                                                          \
+            cs = 0;                                                                      \
+            ctile += tile_stride;                                                        \
+        }                                                                                \
+    }
+
+    // a row tile is done: row norms across the 4 chunk lanes, keys out (as mq_score_kernel)
+    auto finish_tile = [&](uint64_t tile) {
+        nrm += __shfl_xor(nrm, 16);
+        nrm += __shfl_xor(nrm, 32);
+        nz |= __shfl_xor(nz, 16);
+        nz |= __shfl_xor(nz, 32);
+        const uint64_t row = tile * 16 + trow;
+        const float inv = __frsqrt_rn(nrm);
+        if (COLLECT || row < a.n_rows) {
+            float keys[NB][4];
+            uint32_t hm = 0;
+            const bool row_ok = row < a.n_rows;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const float4 th = COLLECT ? *reinterpret_cast<const float4 *>(thr_lds + b * 16 + c * 4)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float thv[4] = {th.x, th.y, th.z, th.w};
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int q = b * 16 + c * 4 + r;
+                    float key;
+                    if (METRIC == kCosine) {
+                        key = -acc[b][r] * inv;
+                        if (nrm == 0.f) key = nz ? -2.0f : 1.0f;  // zero row: distance 1.0 (collection.go:828-830)
+                    } else {
+                        key = fmaf(-2.0f, acc[b][r], nrm + a.qnorm2[q < 48 ? q : 47]);
+                    }
+                    if (!(key == key)) key = 3.0e38f;
+                    if (key > 3.0e38f) key = 3.0e38f;
+                    keys[b][r] = key;
+                    if (COLLECT)
+                        hm |= (row_ok && q < a.n_queries && key <= thv[r]) ? (1u << (b * 4 + r)) : 0u;
+                    else if (q < a.n_queries)
+                        a.keys[(size_t)q * a.key_stride + row] = key;
+                }
+            }
+            if (COLLECT) offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row);
+        }
+        if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores (see mq_score_kernel)
+#pragma unroll
+        for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        nrm = 0.f;
+        nz = 0;
+    };
+
+    {
+        uint64_t issued = kRingB, consumed = 0;
+#pragma unroll
+        for (int u = 0; u < kRingB; u++) {
+            MQB_ISSUE(u)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();  // the query image is complete (the rows do not depend on it)
+#pragma unroll
+        for (int b = 0; b < NB; b++) qn[b] = qimg[lane + b * 64];
+        while (consumed + 2 * kRingB <= NP) {
+#pragma unroll
+            for (int u = 0; u < kRingB; u++) {
+                MQB_CONSUME(u)
+                MQB_ISSUE(u)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            consumed += kRingB;
+            issued += kRingB;
+        }
+        while (consumed < NP) {
+#pragma unroll
+            for (int u = 0; u < kRingB; u++) {
+                if (consumed < NP) {
+                    MQB_CONSUME(u)
+                    consumed++;
+                    if (issued < NP) {
+                        MQB_ISSUE(u)
+                        issued++;
+                    }
+                }
+            }
+        }
+    }
+#undef MQB_ISSUE
+#undef MQB_CONSUME
+    if (COLLECT) hit_flush(a, hb, lane);
+}
+
+// Staged form: a load instruction reads 128 contiguous bytes of each of 8 rows (8 lanes x 16 bytes per
+// row) instead of 64 bytes of each of 16 -- the streaming pattern the memory system likes better
+// (scripts/readbw: 6.95 vs 6.2 TB/s) -- and the wave turns the two loads of a 32-element step into
+// the MFMA operand layout through its own KiB of LDS: convert, ds_write_b64 in row-major order,
+// ds_read_b128 as lane (row, k-group).  The image is in natural order: lane (query, k-group g)
+// holds elements 8g..8g+7 of the step.
+template <int NB, int METRIC, bool COLLECT>
+__global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArgs a)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int steps = a.r16 / 4;
+    const int SS = (steps + 1) / 2;
+    const bool odd = (steps & 1) != 0;
+    const int n16 = SS * NB * 64;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (int i = tid; i < n16; i += blockDim.x) dst[i] = src[i];
+        if (COLLECT && tid < 48)
+            reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
+    }
+    const v4i32b *qimg = reinterpret_cast<const v4i32b *>(smem);
+    const float *thr_lds = reinterpret_cast<const float *>(smem + (size_t)n16 * 16);
+    HitBuf hb;
+    uint8_t *stage;
+    {
+        uint8_t *base = smem + (size_t)n16 * 16 + 48 * sizeof(float);
+        hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
+        hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
+        hb.n = 0;
+        stage = base + (size_t)nwaves * kHitCap * 9 + (size_t)wave * 1024;  // (kHitCap * 9 * nwaves is a multiple of 16)
+    }
+
+    const int trow = lane & 15, c = lane >> 4;  // MFMA role: row of the tile, k-group
+    const int r8 = lane >> 3, ch = lane & 7;    // load role: rows r8 and 8 + r8, 16-byte chunk of the 128-byte step
+    uint2 *w_a = reinterpret_cast<uint2 *>(stage + r8 * 64 + ch * 8);
+    uint2 *w_b = reinterpret_cast<uint2 *>(stage + 512 + r8 * 64 + ch * 8);
+    const v4i32b *r_op = reinterpret_cast<const v4i32b *>(stage + trow * 64 + c * 16);
+
+    const uint64_t n_tiles = ((uint64_t)a.n_rows + 15) / 16;
+    const uint64_t tile_stride = (uint64_t)gridDim.x * nwaves;
+    const uint64_t tile_first = (uint64_t)blockIdx.x * nwaves + wave;
+    const uint64_t n_it = tile_first < n_tiles ? (n_tiles - tile_first + tile_stride - 1) / tile_stride : 0;
+    const uint64_t NP = n_it * (uint64_t)SS;
+
+    uint64_t itile = tile_first;
+    int is = 0;
+    uint64_t ctile = tile_first;
+    int cs = 0;
+
+    u32x4 ring_a[kRingB], ring_b[kRingB];
+    f32x4 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float nrm_a = 0.f, nrm_b = 0.f;
+    uint32_t nz_a = 0, nz_b = 0;
+    v4i32b qn[NB];
+
+    const uint8_t *iptr_a, *iptr_b;
+    auto set_rows = [&](uint64_t tile) {
+        const uint64_t last = (uint64_t)a.n_rows - 1;  // past the end: a valid row, discarded
+        iptr_a = a.rows + (size_t)min(tile * 16 + r8, last) * a.pitch + (size_t)ch * 16;
+        iptr_b = a.rows + (size_t)min(tile * 16 + 8 + r8, last) * a.pitch + (size_t)ch * 16;
+    };
+    set_rows(tile_first);
+    // the half step at the end of an odd row: its upper four chunks lie past the row; those lanes read
+    // the lower four again (zeros stand against them in the image) and keep them out of the norm
+    const int back = ch >= 4 ? -64 : 0;
+
+#define MQS_ISSUE(u)                                                                     \
+    {                                                                                    \
+        const int adj_ = (odd && is == SS - 1) ? back : 0;                               \
+        ring_a[u] = load_stream(iptr_a + adj_, !(SZG_ABL & 32)); /* whole 128-byte lines, used once: non-temporal */ \
+        ring_b[u] = load_stream(iptr_b + adj_, !(SZG_ABL & 32));                         \
+        if (++is == SS) {                                                                \
+            is = 0;                                                                      \
+            itile += tile_stride;                                                        \
+            set_rows(itile);                                                             \
+        } else {                                                                         \
+            iptr_a += 128;                                                               \
+            iptr_b += 128;                                                               \
+        }                                                                                \
+    }
+
+#define MQS_CONSUME(u)                                                                   \
+    {                                                                                    \
+        const u32x4 va_ = ring_a[u], vb_ = ring_b[u];                                    \
+        const bool skip_ = odd && cs == SS - 1 && ch >= 4;                               \
+        const float xa_[4] = {__uint_as_float(va_.x), __uint_as_float(va_.y), __uint_as_float(va_.z),       \
+                              __uint_as_float(va_.w)};                                   \
+        const float xb_[4] = {__uint_as_float(vb_.x), __uint_as_float(vb_.y), __uint_as_float(vb_.z),       \
+                              __uint_as_float(vb_.w)};                                   \
+        if (!skip_ && !(SZG_ABL & 2)) {                                                  \
+            _Pragma("unroll") for (int i = 0; i < 4; i++) nrm_a = fmaf(xa_[i], xa_[i], nrm_a); \
+            _Pragma("unroll") for (int i = 0; i < 4; i++) nrm_b = fmaf(xb_[i], xb_[i], nrm_b); \
+        }                                                                                \
+        nz_a |= va_.x | va_.y;                                                           \
+        nz_a |= va_.z | va_.w;                                                           \
+        nz_b |= vb_.x | vb_.y;                                                           \
+        nz_b |= vb_.z | vb_.w;                                                           \
+        const bf16x2 t0_ = __builtin_convertvector(f32x2{xa_[0], xa_[1]}, bf16x2);       \
+        const bf16x2 t1_ = __builtin_convertvector(f32x2{xa_[2], xa_[3]}, bf16x2);       \
+        const bf16x2 t2_ = __builtin_convertvector(f32x2{xb_[0], xb_[1]}, bf16x2);       \
+        const bf16x2 t3_ = __builtin_convertvector(f32x2{xb_[2], xb_[3]}, bf16x2);       \
+        *w_a = make_uint2(__builtin_bit_cast(uint32_t, t0_), __builtin_bit_cast(uint32_t, t1_)); \
+        *w_b = make_uint2(__builtin_bit_cast(uint32_t, t2_), __builtin_bit_cast(uint32_t, t3_)); \
+        __builtin_amdgcn_wave_barrier();                                                 \
+        const v4i32b bop_ = *r_op;                                                       \
+        __builtin_amdgcn_wave_barrier();                                                 \
+        const int qnext_ = lane + (cs + 1 == SS ? 0 : cs + 1) * (NB * 64);               \
+        _Pragma("unroll") for (int b = 0; b < NB; b++)                                   \
+        {                                                                                \
+            const v4i32b qc_ = qn[b];                                                    \
+            if (SZG_ABL & 4) { asm volatile("" :: "v"(bop_)); continue; }                \
+            qn[b] = qimg[qnext_ + b * 64];                                               \
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qc_),              \
+                                                             __builtin_bit_cast(bf16x8, bop_), acc[b], 0, 0, 0); \
+        }                                                                                \
+        if (++cs == SS) {                                                                \
+            if (SZG_ABL & 1) { asm volatile("" :: "v"(acc[0]), "v"(nrm_a), "v"(nrm_b), "v"(nz_a), "v"(nz_b)); } else \
+            finish_tile(ctile);                                                          \
+            cs = 0;                                                                      \
+            ctile += tile_stride;                                                        \
+        }                                                                                \
+    }
+
+    auto finish_tile = [&](uint64_t tile) {
+        // row norms: over the 8 chunk lanes of each row, then to the lanes of the MFMA result (column = row)
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            nrm_a += __shfl_xor(nrm_a, o);
+            nrm_b += __shfl_xor(nrm_b, o);
+            nz_a |= __shfl_xor(nz_a, o);
+            nz_b |= __shfl_xor(nz_b, o);
+        }
+        const int src = (trow & 7) * 8;
+        const float na = __shfl(nrm_a, src), nb2 = __shfl(nrm_b, src);
+        const uint32_t za = __shfl(nz_a, src), zb = __shfl(nz_b, src);
+        const float nrm = trow < 8 ? na : nb2;
+        const uint32_t nz = (trow < 8 ? za : zb) & 0x7FFFFFFFu;
+        const uint64_t row = tile * 16 + trow;
+        const float inv = __frsqrt_rn(nrm);
+        if (COLLECT || row < a.n_rows) {
+            float keys[NB][4];
+            uint32_t hm = 0;
+            const bool row_ok = row < a.n_rows;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const float4 th = COLLECT ? *reinterpret_cast<const float4 *>(thr_lds + b * 16 + c * 4)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float thv[4] = {th.x, th.y, th.z, th.w};
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int q = b * 16 + c * 4 + r;
+                    float key;
+                    if (METRIC == kCosine) {
+                        key = -acc[b][r] * inv;
+                        if (nrm == 0.f) key = nz ? -2.0f : 1.0f;  // zero row: distance 1.0 (collection.go:828-830)
+                    } else {
+                        key = fmaf(-2.0f, acc[b][r], nrm + a.qnorm2[q < 48 ? q : 47]);
+                    }
+                    if (!(key == key)) key = 3.0e38f;
+                    if (key > 3.0e38f) key = 3.0e38f;
+                    keys[b][r] = key;
+                    if (COLLECT)
+                        hm |= (row_ok && q < a.n_queries && key <= thv[r]) ? (1u << (b * 4 + r)) : 0u;
+                    else if (q < a.n_queries)
+                        a.keys[(size_t)q * a.key_stride + row] = key;
+                }
+            }
+            if (COLLECT) offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row);
+        }
+        if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores (see mq_score_kernel)
+#pragma unroll
+        for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        nrm_a = nrm_b = 0.f;
+        nz_a = nz_b = 0;
+    };
+
+    {
+        uint64_t issued = kRingB, consumed = 0;
+#pragma unroll
+        for (int u = 0; u < kRingB; u++) {
+            MQS_ISSUE(u)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();  // the query image is complete (the rows do not depend on it)
+#pragma unroll
+        for (int b = 0; b < NB; b++) qn[b] = qimg[lane + b * 64];
+        while (consumed + 2 * kRingB <= NP) {
+#pragma unroll
+            for (int u = 0; u < kRingB; u++) {
+                MQS_CONSUME(u)
+                MQS_ISSUE(u)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            consumed += kRingB;
+            issued += kRingB;
+        }
+        while (consumed < NP) {
+#pragma unroll
+            for (int u = 0; u < kRingB; u++) {
+                if (consumed < NP) {
+                    MQS_CONSUME(u)
+                    consumed++;
+                    if (issued < NP) {
+                        MQS_ISSUE(u)
+                        issued++;
+                    }
+                }
+            }
+        }
+    }
+#undef MQS_ISSUE
+#undef MQS_CONSUME
+    if (COLLECT) hit_flush(a, hb, lane);
+}
+
+#endif  // SZG_MQ_PART == 3
+
 #if SZG_MQ_PART == 1 || SZG_MQ_PART == 2
 // ---- exact integer shared sweep, 8-bit rows (part 1) and 4-bit rows (part 2) ---------------------------------------
 //
@@ -833,6 +1284,65 @@ __global__ __launch_bounds__(256) void cand_select_kernel(const uint64_t *cand_b
     block_merge_lists(wl_lds, nwaves, kp, lists + (size_t)q * kp, tid, blockDim.x);
 }
 
+
+// Second stage of the bfloat16 sweep: the (few thousand) candidates it collected are scored again in
+// float32 -- one wave per (query, candidate), the query as float32 in LDS -- and the key inside the
+// candidate word is replaced, so that the selection and the certification that follow work with
+// float32 keys (bound: key_eps, mq branch).  grid (blocks, queries); 32-bit rows, dim % 4 == 0.
+template <int METRIC>
+__global__ __launch_bounds__(256) void cand_rescore_kernel(const uint8_t *rows, uint32_t pitch, int dim,
+                                                           const double *q64, const double *qscale,
+                                                           uint64_t *cand_buf, const uint32_t *cand_count,
+                                                           uint32_t cand_cap)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    float *qf = reinterpret_cast<float *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.y;
+    const uint32_t n = min(cand_count[q * kCandCountStride], cand_cap);
+    const double sc = qscale[q];
+    for (int i = tid; i < dim; i += blockDim.x) qf[i] = (float)(q64[(size_t)q * dim + i] * sc);
+    __syncthreads();
+    const float4 *qf4 = reinterpret_cast<const float4 *>(qf);
+    const int d4 = dim >> 2;
+    uint64_t *cb = cand_buf + (size_t)q * cand_cap;
+    for (uint32_t ci = blockIdx.x * 4 + wave; ci < n; ci += gridDim.x * 4) {
+        const uint32_t row = (uint32_t)cb[ci];
+        const float4 *rp = reinterpret_cast<const float4 *>(rows + (size_t)row * pitch);
+        float dot = 0.f, nrm = 0.f;
+        uint32_t nz = 0;
+        for (int i = lane; i < d4; i += 64) {
+            const float4 x = rp[i], y = qf4[i];
+            if (METRIC == kCosine) {
+                dot = fmaf(x.x, y.x, dot); dot = fmaf(x.y, y.y, dot); dot = fmaf(x.z, y.z, dot); dot = fmaf(x.w, y.w, dot);
+                nrm = fmaf(x.x, x.x, nrm); nrm = fmaf(x.y, x.y, nrm); nrm = fmaf(x.z, x.z, nrm); nrm = fmaf(x.w, x.w, nrm);
+                nz |= (__float_as_uint(x.x) | __float_as_uint(x.y) | __float_as_uint(x.z) | __float_as_uint(x.w)) & 0x7FFFFFFFu;
+            } else {
+                const float a0 = x.x - y.x, a1 = x.y - y.y, a2 = x.z - y.z, a3 = x.w - y.w;
+                dot = fmaf(a0, a0, dot); dot = fmaf(a1, a1, dot); dot = fmaf(a2, a2, dot); dot = fmaf(a3, a3, dot);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            dot += __shfl_xor(dot, o);
+            if (METRIC == kCosine) {
+                nrm += __shfl_xor(nrm, o);
+                nz |= __shfl_xor(nz, o);
+            }
+        }
+        float key;
+        if (METRIC == kCosine) {
+            key = -dot * __frsqrt_rn(nrm);
+            if (nrm == 0.f) key = nz ? -2.0f : 1.0f;
+        } else {
+            key = dot;
+        }
+        if (!(key == key)) key = 3.0e38f;
+        if (key > 3.0e38f) key = 3.0e38f;
+        if (lane == 0) cb[ci] = ((uint64_t)ordered_key(key) << 32) | row;
+    }
+}
+
 #endif  // SZG_MQ_PART == 0
 
 }  // namespace
@@ -850,6 +1360,22 @@ hipError_t launch_cand_select(const uint64_t *cand_buf, const uint32_t *cand_cou
     const size_t lds = (size_t)4 * kp * sizeof(uint64_t);
     hipLaunchKernelGGL(cand_select_kernel, dim3(n_queries), dim3(256), lds, stream, cand_buf, cand_count,
                        cand_cap, kp, lists);
+    return hipGetLastError();
+}
+
+hipError_t launch_cand_rescore(int metric, const uint8_t *rows, uint32_t pitch, int dim, const double *q64,
+                               const double *qscale, uint64_t *cand_buf, const uint32_t *cand_count,
+                               uint32_t cand_cap, int n_queries, hipStream_t stream)
+{
+    if (dim % 4 != 0) return hipErrorInvalidValue;
+    const dim3 grid(64, n_queries);
+    const size_t lds = (size_t)dim * sizeof(float);
+    if (metric == kCosine)
+        hipLaunchKernelGGL(cand_rescore_kernel<kCosine>, grid, dim3(256), lds, stream, rows, pitch, dim, q64, qscale,
+                           cand_buf, cand_count, cand_cap);
+    else
+        hipLaunchKernelGGL(cand_rescore_kernel<kEuclidean>, grid, dim3(256), lds, stream, rows, pitch, dim, q64,
+                           qscale, cand_buf, cand_count, cand_cap);
     return hipGetLastError();
 }
 
@@ -931,6 +1457,18 @@ size_t mq_i8_lds_bytes(int row_bits, int r16, int nb)
 {   // + constants, thresholds, the 12 waves' hit buffers
     return mq_i8_image_bytes(row_bits, r16, nb) + 4 * 48 * sizeof(float) + (size_t)SZG_MQ8_WAVES * 64 * 9;
 }
+size_t mq_bf16_image_bytes(int r16, int nb) { return (size_t)((r16 / 4 + 1) / 2) * nb * 1024; }
+size_t mq_bf16_lds_bytes(int r16, int nb)
+{   // + thresholds and the waves' hit buffers
+    return mq_bf16_image_bytes(r16, nb) + 48 * sizeof(float) + (size_t)SZG_MQB_WAVES * kHitCap * 9 +
+           (SZG_MQB_STAGED ? (size_t)SZG_MQB_WAVES * 1024 : 0);  // + a KiB of operand staging per wave
+}
+int mq_bf16_image_natural() { return SZG_MQB_STAGED; }
+hipError_t launch_mq_score_bf16_rows32(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
+hipError_t launch_mq_score_bf16(const MqArgs &a, int nb, int grid, hipStream_t stream)
+{
+    return launch_mq_score_bf16_rows32(a, nb, grid, mq_bf16_lds_bytes(a.r16, nb), stream);
+}
 hipError_t launch_mq_score_i8_rows8(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
 hipError_t launch_mq_score_i8_rows4(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
 hipError_t launch_mq_score_i8(int row_bits, const MqArgs &a, int nb, int grid, hipStream_t stream)
@@ -941,6 +1479,46 @@ hipError_t launch_mq_score_i8(int row_bits, const MqArgs &a, int nb, int grid, h
     return hipErrorInvalidValue;
 }
 #endif  // SZG_MQ_PART == 0
+
+#if SZG_MQ_PART == 3
+namespace {
+template <int NB, int METRIC, bool COLLECT>
+hipError_t launch_mq_score_bf16_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
+{
+#if SZG_MQB_STAGED
+    auto *kern = &mq_score_bf16s_kernel<NB, METRIC, COLLECT>;
+#else
+    auto *kern = &mq_score_bf16_kernel<NB, METRIC, COLLECT>;
+#endif
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kMqbThreads), lds, stream, a);
+    return hipGetLastError();
+}
+template <int NB>
+hipError_t launch_mq_score_bf16_m(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
+{
+    if (a.collect) {
+        if (a.metric == kCosine) return launch_mq_score_bf16_t<NB, kCosine, true>(a, grid, lds, stream);
+        return launch_mq_score_bf16_t<NB, kEuclidean, true>(a, grid, lds, stream);
+    }
+    if (a.metric == kCosine) return launch_mq_score_bf16_t<NB, kCosine, false>(a, grid, lds, stream);
+    return launch_mq_score_bf16_t<NB, kEuclidean, false>(a, grid, lds, stream);
+}
+}  // namespace
+
+hipError_t launch_mq_score_bf16_rows32(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
+{
+    if (a.r16 % 4 != 0 || a.dim != a.r16 * 4 || a.tiled || a.n_rows == 0) return hipErrorInvalidValue;
+    switch (nb) {
+    case 1: return launch_mq_score_bf16_m<1>(a, grid, lds, stream);
+    case 2: return launch_mq_score_bf16_m<2>(a, grid, lds, stream);
+    case 3: return launch_mq_score_bf16_m<3>(a, grid, lds, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+#endif  // SZG_MQ_PART == 3
 
 #if SZG_MQ_PART == 1 || SZG_MQ_PART == 2
 namespace {

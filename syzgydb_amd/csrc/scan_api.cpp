@@ -170,12 +170,14 @@ struct QMeta {
     // in qscale / qconst for the escalation sweep)
     bool mq_int = false;
     double mq_qscale = 0, mq_qconst = 0;
+    bool mq_bf16 = false;  // (with mq) the shared sweep multiplied bfloat16 roundings of rows and query
 };
 
 struct Cand {
     uint64_t row;  // index-level row
     double dist;   // reference float64 distance
     float key;     // the scan's ranking key for this row
+    double ub;     // key + the error bound of the arithmetic that produced it: the real-number key is <= ub
 };
 
 // ---- one in-flight batch of queries on one shard --------------------------------
@@ -212,6 +214,11 @@ struct Ctx {
     size_t keys_cap = 0;           // floats
     // fused selection of the shared sweep: thresholds, candidate buffers, hit counts
     float *d_thr = nullptr;
+    float *h_thr = nullptr;        // (pinned) the prefix thresholds of a two-stage batch, for certification
+    double *h_qscale = nullptr, *d_qscale = nullptr;  // [64] float32-query scale per staged query (re-score)
+    int kp_used = 0;               // candidates per query in h_out for the batch in flight
+    bool mq_stage2 = false;        // bfloat16 sweep -> float32 re-score of its candidates -> selection
+    bool mq_bf16_used = false;     // the list keys of this batch are bfloat16-sweep keys (matrix form)
     uint64_t *d_cand = nullptr;
     size_t cand_cap_total = 0;     // entries
     uint32_t *d_cand_count = nullptr, *h_cand_count = nullptr;
@@ -305,6 +312,11 @@ struct szg_index {
     int coalesce = 1;         // concurrent single-query calls share sweeps (see Combiner)
     int mq_fused = 1;         // shared sweep: threshold-collect selection instead of a score matrix
     int mq_i8 = 1;            // 8-bit rows: exact integer shared sweep (v_mfma_i32_16x16x64_i8)
+    int mq_bf16 = 1;          // 32-bit rows: shared sweep on bfloat16 roundings (v_mfma_f32_16x16x32_bf16), certified
+                              // against its own bound and re-ranked in float64 like every other path
+    int mq_overlap = 1;       // bfloat16 sweeps: a batch's threshold pass and its post-processing run on the context's
+                              // stream beside the neighbouring batches' sweeps (the sweep is a bare stream of the rows)
+    int mq_bf16_slack = 118;  // candidates kept beyond k by a bfloat16 sweep (its band holds more rows)
     int mq_tail_overlap = 0;  // shared sweep: post-processing of a batch beside the next batch's sweep
     int mq_min = 2;           // smallest batch worth a shared sweep (measured: 2 queries already break even)
     int mq_blocks_max = 3;    // query blocks of 16 per shared sweep (LDS image permitting)
@@ -463,6 +475,19 @@ double key_eps(const szg_index *ix, double key, const QMeta &m)
         // difference form's when rows sit far from the origin; certification then simply
         // escalates more often.
         const double u = 0x1p-24, n = (double)ix->dim + 16.0;
+        if (m.mq_bf16) {
+            // bfloat16 sweep: each operand is rounded to 8 significant bits (relative error <= 2^-9,
+            // the query once more from float32), the products are exact in float32 and summed by the
+            // matrix core in float32.  |sum bf(x_i) bf(g_i) - sum x_i g_i| <= c |x| |g| (Cauchy-Schwarz)
+            // with c = (1 + 2^-9)^2 (1 + 2^-24) - 1 < 1.01 * 2^-8; the float32 part of the bound is
+            // doubled (the accumulation order and rounding of the matrix core are its own).
+            const double c = 1.01 * 0x1p-8;
+            if (ix->metric == SZG_COSINE) return c + 4.0 * n * u + 1e-6;
+            // euclid: the key moves by 2 c |x| |g|, and |x| <= |g| + d with d^2 <= key + 2 c |x| |g|
+            // gives |x| <= 1.1 |g| + sqrt(key) for this c; the last term keeps key - eps(key) monotone
+            const double s = 2.0 * m.qnorm + std::sqrt(k);
+            return 2.0 * c * m.qnorm * (1.1 * m.qnorm + std::sqrt(k)) + c * c * m.qnorm2 + 3.0 * n * u * s * s + 1e-30;
+        }
         if (ix->metric == SZG_COSINE) return 2.0 * n * u;
         const double s = 2.0 * m.qnorm + std::sqrt(k);
         return 1.5 * n * u * s * s + 1e-30;
@@ -547,6 +572,9 @@ void ctx_free(Ctx *c)
     free(c->h_mqQ);
     (void)hipFree(c->d_mq);
     (void)hipFree(c->d_thr);
+    (void)hipHostFree(c->h_thr);
+    (void)hipHostFree(c->h_qscale);
+    (void)hipFree(c->d_qscale);
     (void)hipFree(c->d_cand);
     (void)hipFree(c->d_cand_count);
     (void)hipHostFree(c->h_cand_count);
@@ -759,6 +787,9 @@ int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg
 // top-k pass for the nq staged queries of one shard: scan -> merges -> rerank -> D2H (async)
 int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allow)
 {
+    c->kp_used = kp;
+    c->mq_stage2 = false;
+    c->mq_bf16_used = false;
     HIPCHK(hipSetDevice(sh->device));
     const LaunchGeom g = scan_geometry(ix, sh, kp, !has_allow && !sh->has_dead);
     const size_t need = (size_t)nq * g.grid * kp;
@@ -841,6 +872,21 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
 // ---- multi-query sweep (32-bit rows, cosine): B queries share one pass ------------
 
 bool mq_uses_i8(const szg_index *ix) { return (ix->bits == 8 || ix->bits == 4) && ix->mq_i8; }
+// 32-bit rows of whole 64-byte steps: the bfloat16 sweep
+bool mq_uses_bf16(const szg_index *ix)
+{
+    return ix->bits == 32 && ix->mq_bf16 && ix->map.r16 % 4 == 0 && ix->dim == ix->map.r16 * 4 && !ix->layout.tiled;
+}
+
+// round to nearest even, as v_cvt_pk_bf16_f32 does (NaN stays NaN)
+uint16_t bf16_rne(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
 
 // the prepared real query of the integer sweeps: q/|q| (cosine) or maxInt*q (euclid)
 double mq_int_scale(const szg_index *ix, double m1)
@@ -874,6 +920,7 @@ int mq_blocks(const szg_index *ix, int nq)
     if (!ix->multi_query || ix->bits == 64 || nq < ix->mq_min) return 0;
     int nb = std::min((nq + 15) / 16, ix->mq_blocks_max);
     auto lds = [&](int n) {
+        if (mq_uses_bf16(ix)) return szg::mq_bf16_lds_bytes(ix->map.r16, n);
         return mq_uses_i8(ix) ? szg::mq_i8_lds_bytes(ix->bits, ix->map.r16, n)
                               : szg::mq_lds_bytes(ix->bits, ix->map.r16, n);
     };
@@ -883,19 +930,41 @@ int mq_blocks(const szg_index *ix, int nq)
 
 // top-k pass for the nq staged queries through ONE shared sweep:
 // score matrix -> per-query selection -> merges -> rerank -> D2H (async)
-int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bool has_allow,
+// kp_wide: the list length when the lists hold bfloat16-sweep keys themselves (matrix form: small
+// shards, overflow reruns), whose error band needs more candidates than kp
+int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int nq, int nb, bool has_allow,
                     bool force_matrix = false)
 {
     HIPCHK(hipSetDevice(sh->device));
     const int r16 = ix->map.r16;
     const bool i8 = mq_uses_i8(ix);
-    const size_t img = i8 ? szg::mq_i8_lds_bytes(ix->bits, r16, nb) : szg::mq_lds_bytes(ix->bits, r16, nb);
+    const bool bf16 = mq_uses_bf16(ix);
+    const size_t img = bf16 ? szg::mq_bf16_image_bytes(r16, nb)
+                            : i8 ? szg::mq_i8_lds_bytes(ix->bits, r16, nb) : szg::mq_lds_bytes(ix->bits, r16, nb);
     int rc = ensure_host(&c->h_mq, &c->h_mq_cap, img);
     if (rc) return rc;
     rc = ensure_dev(&c->d_mq, &c->d_mq_cap, img);
     if (rc) return rc;
     memset(c->h_mq, 0, img);
-    if (i8) {
+    if (bf16) {
+        // [32-element step][query block][lane = chunk*16 + query][8 bf16]: slots 0..3 hold elements
+        // 4*chunk + 0..3 of the step's first 16, slots 4..7 the same of its second 16.  Cosine: q/|q|.
+        uint16_t *im = reinterpret_cast<uint16_t *>(c->h_mq);
+        for (int q = 0; q < nq; q++) {
+            const double *src = c->h_q64 + (size_t)q * ix->dim;
+            const double m1 = c->meta[q].m1;
+            double scale = m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0;
+            if (ix->metric != SZG_COSINE) scale = 1.0;
+            const int b = q / 16, qi = q % 16;
+            const bool natural = szg::mq_bf16_image_natural() != 0;  // (the staged kernel: lane (query, g) = 8g..8g+7)
+            for (int e = 0; e < ix->dim; e++) {
+                const int S = e >> 5, w = e & 31, half = w >> 4, ch = (w & 15) >> 2, m = w & 3;
+                const size_t at = natural ? ((((size_t)S * nb + b) * 64) + (w >> 3) * 16 + qi) * 8 + (w & 7)
+                                          : ((((size_t)S * nb + b) * 64) + ch * 16 + qi) * 8 + half * 4 + m;
+                im[at] = bf16_rne((float)(src[e] * scale));
+            }
+        }
+    } else if (i8) {
         // [64-byte step][digit plane h..l][T halves][query block][lane = chunk*16 + query][16 bytes] of the
         // int8 digits of Q = round(v / mq_qscale), then the table [qscale | qconst | qnorm2][48].
         // 8-bit rows (T = 1): byte i of a lane's word belongs to element 16*piece + i; the row
@@ -950,6 +1019,23 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     }
     HIPCHK(hipMemcpyAsync(c->d_mq, c->h_mq, img, hipMemcpyHostToDevice, c->stream));
 
+    // Fused selection: sweep a prefix of the rows into a small score matrix, take each
+    // query's kp-th best key there as its threshold, then sweep everything and collect the
+    // (query, row) pairs at or below their threshold -- about `hits` per query -- instead of
+    // writing and re-reading n_rows x batch keys.  Every row outside a query's buffer has a
+    // key above the threshold, which is >= the kp-th kept key: certification is unchanged.
+    // bfloat16 sweep: the collected candidates are scored again in float32 before the selection
+    // (two stages); rows outside the buffer are bounded by the bfloat16 threshold, rows inside it by
+    // the float32 keys.  In matrix form its lists hold bfloat16 keys and are kp_wide long.
+    const uint64_t hits = std::max<uint64_t>((uint64_t)ix->mq_hits, 16ull * kp);
+    uint64_t prefix = ((sh->n_rows * (uint64_t)kp + hits - 1) / hits + 15) & ~15ull;
+    prefix = std::max<uint64_t>(prefix, 16ull * kp);
+    const bool fused = ix->mq_fused && !force_matrix && prefix * 4 <= sh->n_rows;
+    const bool stage2 = bf16 && fused;
+    if (bf16 && !fused) kp = std::max(kp, kp_wide);
+    const uint32_t cand_cap = (uint32_t)(4 * hits);
+    const size_t key_stride = fused ? (size_t)prefix : (((size_t)sh->n_rows + 3) & ~(size_t)3);
+
     const int sb = 16;  // select blocks per query
     const size_t need = (size_t)nq * sb * kp;
     if (c->lists_cap < need) {
@@ -965,18 +1051,6 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     if (rc) return rc;
     rc = ensure_host(&c->h_out, &c->h_out_cap, (size_t)nq * kp);
     if (rc) return rc;
-
-    // Fused selection: sweep a prefix of the rows into a small score matrix, take each
-    // query's kp-th best key there as its threshold, then sweep everything and collect the
-    // (query, row) pairs at or below their threshold -- about `hits` per query -- instead of
-    // writing and re-reading n_rows x batch keys.  Every row outside a query's buffer has a
-    // key above the threshold, which is >= the kp-th kept key: certification is unchanged.
-    const uint64_t hits = std::max<uint64_t>((uint64_t)ix->mq_hits, 16ull * kp);
-    uint64_t prefix = ((sh->n_rows * (uint64_t)kp + hits - 1) / hits + 15) & ~15ull;
-    prefix = std::max<uint64_t>(prefix, 16ull * kp);
-    const bool fused = ix->mq_fused && !force_matrix && prefix * 4 <= sh->n_rows;
-    const uint32_t cand_cap = (uint32_t)(4 * hits);
-    const size_t key_stride = fused ? (size_t)prefix : (((size_t)sh->n_rows + 3) & ~(size_t)3);
     rc = ensure_dev(&c->d_keys, &c->keys_cap, key_stride * nq);
     if (rc) return rc;
     if (fused) {
@@ -987,10 +1061,23 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
         rc = ensure_dev(&c->d_cand, &c->cand_cap_total, (size_t)cand_cap * nq);
         if (rc) return rc;
     }
+    if (stage2) {
+        if (!c->h_thr) HIPCHK(hipHostMalloc((void **)&c->h_thr, 64 * sizeof(float), hipHostMallocDefault));
+        if (!c->h_qscale) HIPCHK(hipHostMalloc((void **)&c->h_qscale, 64 * sizeof(double), hipHostMallocDefault));
+        if (!c->d_qscale) HIPCHK(hipMalloc((void **)&c->d_qscale, 64 * sizeof(double)));
+        for (int q = 0; q < nq; q++) {
+            const double m1 = c->meta[q].m1;
+            c->h_qscale[q] = ix->metric == SZG_COSINE ? (m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0) : 1.0;
+        }
+        HIPCHK(hipMemcpyAsync(c->d_qscale, c->h_qscale, sizeof(double) * nq, hipMemcpyHostToDevice, c->stream));
+    }
     c->mq_fused_used = fused;
     c->mq_cand_cap = cand_cap;
     c->mq_nb = nb;
     c->mq_has_allow = has_allow;
+    c->kp_used = kp;
+    c->mq_stage2 = stage2;
+    c->mq_bf16_used = bf16 && !stage2;
 
     szg::MqArgs a;
     memset(&a, 0, sizeof(a));
@@ -1016,13 +1103,17 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
     {
         std::lock_guard<std::mutex> lk(sh->chain_mu);
         hipStream_t st = ix->serialize_scans ? sh->scan_stream : c->stream;
-        if (st != c->stream) {
+        const bool overlap = bf16 && ix->mq_overlap && st != c->stream;
+        // (overlap: the threshold pass goes ahead on the context's stream, the sweep follows on the scan stream)
+        hipStream_t head = overlap ? c->stream : st;
+        if (st != c->stream && !overlap) {
             HIPCHK(hipEventRecord(c->ev_up, c->stream));
             HIPCHK(hipStreamWaitEvent(st, c->ev_up, 0));
         }
-        auto launch_score = [&](const szg::MqArgs &x) -> hipError_t {
-            return i8 ? szg::launch_mq_score_i8(ix->bits, x, nb, sh->cu_count, st)
-                      : szg::launch_mq_score(ix->bits, x, nb, sh->cu_count, st);
+        auto launch_score = [&](const szg::MqArgs &x, hipStream_t s2) -> hipError_t {
+            if (bf16) return szg::launch_mq_score_bf16(x, nb, sh->cu_count, s2);
+            return i8 ? szg::launch_mq_score_i8(ix->bits, x, nb, sh->cu_count, s2)
+                      : szg::launch_mq_score(ix->bits, x, nb, sh->cu_count, s2);
         };
         // score matrix of rows [0, n_sel) -> per-query sorted list of kp (returns its buffer)
         auto select_chain = [&](uint32_t n_sel, size_t kstride, hipStream_t s2, uint64_t **out) -> hipError_t {
@@ -1044,12 +1135,12 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
         if (fused) {
             szg::MqArgs pa = a;  // the prefix, into the (small) score matrix
             pa.n_rows = (uint32_t)prefix;
-            HIPCHK(launch_score(pa));
+            HIPCHK(launch_score(pa, head));
             // one block per query selects over the prefix's keys, publishes the query's
             // threshold and zeroes its hit counter
             HIPCHK(szg::launch_mq_select(c->d_keys, key_stride, (uint32_t)prefix,
                                          sh->has_dead ? sh->live_bits : nullptr, has_allow ? c->d_allow : nullptr,
-                                         (uint32_t)shard_words(sh), kp, nq, 1, c->d_lists_a, st, c->d_thr,
+                                         (uint32_t)shard_words(sh), kp, nq, 1, c->d_lists_a, head, c->d_thr,
                                          c->d_cand_count));
             a.collect = 1;
             a.thr = c->d_thr;
@@ -1060,8 +1151,12 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
             a.allow_bits = has_allow ? c->d_allow : nullptr;
             a.allow_stride = (uint32_t)shard_words(sh);
         }
+        if (overlap) {
+            HIPCHK(hipEventRecord(c->ev_up, c->stream));
+            HIPCHK(hipStreamWaitEvent(st, c->ev_up, 0));
+        }
         if (ix->timing) HIPCHK(hipEventRecord(c->ev_scan0, st));  // the full sweep (not the prefix pass)
-        HIPCHK(launch_score(a));
+        HIPCHK(launch_score(a, st));
         if (ix->timing) {
             HIPCHK(hipEventRecord(c->ev_scan1, st));
             c->timed_scan = true;
@@ -1071,10 +1166,15 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, int nb, bo
         // stream (default) or, with "mq_tail_overlap", on the context's stream, where they run
         // beside the NEXT batch's sweep (the sweep is MFMA-bound and leaves wave slots free).
         hipStream_t tail = st;
-        if (ix->mq_tail_overlap && st != c->stream) {
+        if ((ix->mq_tail_overlap || overlap) && st != c->stream) {
             HIPCHK(hipEventRecord(c->ev_scan_done, st));
             HIPCHK(hipStreamWaitEvent(c->stream, c->ev_scan_done, 0));
             tail = c->stream;
+        }
+        if (stage2) {
+            HIPCHK(szg::launch_cand_rescore(ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64, c->d_qscale, c->d_cand,
+                                            c->d_cand_count, cand_cap, nq, tail));
+            HIPCHK(hipMemcpyAsync(c->h_thr, c->d_thr, 64 * sizeof(float), hipMemcpyDeviceToHost, tail));
         }
         if (fused) {
             HIPCHK(szg::launch_cand_select(c->d_cand, c->d_cand_count, cand_cap, kp, nq, c->d_lists_a, tail));
@@ -1120,11 +1220,17 @@ int finish_timing(szg_index *ix, Ctx *c)
     return SZG_OK;
 }
 
-// candidates of staged query `slot` from a finished top-k pass; *thr = the worst
-// kept key if the shard's list is full, +inf if every eligible row is in it
-void gather_topk(const Shard *sh, const Ctx *c, int kp, int slot, std::vector<Cand> *cands,
-                 double *thr)
+// candidates of staged query `slot` from a finished top-k pass, each with the upper bound of its
+// real-number key; *lb = a lower bound of the real-number key of every eligible row of the shard that
+// is NOT among them (+inf if every eligible row is).  `m` = the query's constants with the flags
+// of the path the ticket was prepared for; the shard's context says which arithmetic actually
+// produced the keys.
+void gather_topk(const szg_index *ix, const Shard *sh, const Ctx *c, const QMeta &m, int slot,
+                 std::vector<Cand> *cands, double *lb)
 {
+    const int kp = c->kp_used;
+    QMeta lm = m;  // class of the list's keys
+    if (m.mq) lm.mq_bf16 = c->mq_bf16_used;
     int valid = 0;
     float worst = -INFINITY;
     for (int i = 0; i < kp; i++) {
@@ -1133,9 +1239,18 @@ void gather_topk(const Shard *sh, const Ctx *c, int kp, int slot, std::vector<Ca
         valid++;
         const float key = szg::key_from_ordered(r.ukey);
         worst = std::max(worst, key);
-        cands->push_back(Cand{sh->first + r.row, r.dist, key});
+        cands->push_back(Cand{sh->first + r.row, r.dist, key, (double)key + key_eps(ix, key, lm)});
     }
-    *thr = valid == kp ? (double)worst : INFINITY;
+    *lb = valid == kp ? (double)worst - key_eps(ix, worst, lm) : INFINITY;
+    if (c->mq_stage2) {
+        // rows the bfloat16 sweep did not collect: bfloat16 key above the prefix threshold
+        const float thr = c->h_thr[slot];
+        if (thr < 3.0e38f) {
+            QMeta bm = m;
+            bm.mq_bf16 = true;
+            *lb = std::min(*lb, (double)thr - key_eps(ix, thr, bm));
+        }
+    }
 }
 
 // collect pass (radius search / escalation) for staged query `slot`: every row
@@ -1188,7 +1303,7 @@ int run_collect(szg_index *ix, Shard *sh, Ctx *c, int slot, float thr_key, bool 
         cands->reserve(cands->size() + count);
         for (uint32_t i = 0; i < count; i++) {
             const szg::RerankOut &r = c->h_out[i];
-            cands->push_back(Cand{sh->first + r.row, r.dist, szg::key_from_ordered(r.ukey)});
+            cands->push_back(Cand{sh->first + r.row, r.dist, szg::key_from_ordered(r.ukey), 0.0});
         }
         return SZG_OK;
     }
@@ -1340,7 +1455,7 @@ struct Ticket {
     int first = 0, nq = 0;       // queries [first, first+nq) of the call
     std::vector<Ctx *> ctx;      // one per shard
     std::vector<QMeta> meta;
-    int kp = 0;
+    int kp = 0, kp_wide = 0;
     bool failed = false;         // enqueueing failed part-way: drain and release only
     bool any_mask = false;       // some query of the batch carries a filter mask
     szg_index *owner = nullptr;
@@ -1425,7 +1540,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                         ix->stats.mq_queries -= (uint64_t)t.nq;
                         ix->stats.mq_fallbacks += 1;
                     }
-                    rc = enqueue_topk_mq(ix, sh, c, t.kp, t.nq, c->mq_nb, c->mq_has_allow, true);
+                    rc = enqueue_topk_mq(ix, sh, c, t.kp, t.kp_wide, t.nq, c->mq_nb, c->mq_has_allow, true);
                     if (rc == SZG_OK) {
                         e = hipStreamSynchronize(c->stream);
                         if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "hipStreamSynchronize", e);
@@ -1446,9 +1561,9 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 for (size_t s = 0; s < n_sh; s++) {
                     Shard *sh = ix->shards[s];
                     if (sh->n_rows == 0) continue;
-                    double thr;
-                    gather_topk(sh, t.ctx[s], t.kp, j, &all[j], &thr);
-                    thr_min[j] = std::min(thr_min[j], thr);
+                    double lb;
+                    gather_topk(ix, sh, t.ctx[s], t.meta[j], j, &all[j], &lb);
+                    thr_min[j] = std::min(thr_min[j], lb);
                     const Ctx *c = t.ctx[s];
                     for (int i = 0; i < c->sent_n; i++) {
                         const szg::RerankOut &r = c->h_sent_out[(size_t)j * c->sent_n + i];
@@ -1472,25 +1587,24 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 }
             } else {
             replay_topk(cands, k, &res);
-            // certification: every row outside the lists has scan key >= thr_min, so
-            // the result is final once its worst key clears thr_min by the error bound
+            // certification: every row outside the lists has a real-number key >= thr_min (the
+            // lists' own lower bound), so the result is final once the upper bound of its worst
+            // key stays below that
             bool certified = true;
-            float kmax = -INFINITY;
+            double kmax = -INFINITY;  // upper bound of the real-number key of the worst result
             const bool zero_query = ix->metric == SZG_COSINE && t.meta[j].m1 == 0;  // all distances 1.0
-            if (std::isfinite(thr_min[j]) && !zero_query) {
-                std::vector<std::pair<uint64_t, float>> by_row;  // cands are sorted by row now
+            if (thr_min[j] < INFINITY && !zero_query) {
+                std::vector<std::pair<uint64_t, double>> by_row;  // cands are sorted by row now
                 by_row.reserve(cands.size());
-                for (const Cand &c : cands) by_row.emplace_back(c.row, c.key);
+                for (const Cand &c : cands) by_row.emplace_back(c.row, c.ub);
                 for (const HeapItem &h : res) {
                     auto it = std::lower_bound(by_row.begin(), by_row.end(),
-                                               std::make_pair(h.row, -INFINITY));
+                                               std::make_pair(h.row, (double)-INFINITY));
                     kmax = std::max(kmax, it->second);
                 }
-                const double lhs = (double)kmax + key_eps(ix, kmax, t.meta[j]) +
-                                   key_eps(ix, thr_min[j], t.meta[j]);
-                certified = (int)res.size() == k && lhs < thr_min[j];
+                certified = (int)res.size() == k && kmax < thr_min[j];
             }
-            if (ix->force_escalate && std::isfinite(thr_min[j])) certified = false;
+            if (ix->force_escalate && thr_min[j] < INFINITY) certified = false;
             if (nan_first[j] && ix->tie_mode == 0) certified = true;  // answered by the replay below
             if (!certified) {
                 {
@@ -1499,14 +1613,14 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 }
                 double thr = INFINITY;
                 if ((int)res.size() == k && std::isfinite(kmax) && !zero_query) {
-                    // kmax carries the error of the sweep that produced it; the collect sweep
-                    // (always the single-query kernel) adds its own on the rows it tests
+                    // kmax bounds the worst result's real-number key; the collect sweep (always
+                    // the single-query kernel) adds its own error on the rows it tests
                     QMeta single = t.meta[j];
                     single.mq = false;
                     single.mq_int = false;
-                    const double e1 = key_eps(ix, (double)kmax + key_eps(ix, kmax, t.meta[j]), t.meta[j]);
-                    const double e2 = key_eps(ix, (double)kmax + e1, single);
-                    thr = (double)kmax + 1.05 * (e1 + e2);
+                    single.mq_bf16 = false;
+                    const double e2 = key_eps(ix, kmax, single);
+                    thr = kmax + 1.05 * e2 + 0.05 * std::fabs(kmax) * 0x1p-20;
                 }
                 const float thr_f = thr >= 3.0e38 ? 3.0e38f : std::nextafter((float)thr, INFINITY);
                 cands.clear();
@@ -1566,7 +1680,11 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
         const int left = n_queries - q0;
         const int nb = replay_all ? 0 : mq_blocks(ix, std::min(left, 16 * ix->mq_blocks_max));
         t.nq = nb ? std::min(left, 16 * nb) : std::min(B1, left);
+        const bool bf16_sweep = nb > 0 && mq_uses_bf16(ix);
         t.kp = kp;
+        // lists of bfloat16-sweep keys (matrix form): the error band holds more rows than the
+        // float32 one's, keep enough candidates for the k-th result to clear it
+        t.kp_wide = bf16_sweep ? std::min(4096, std::max(kp, k + std::max(ix->mq_bf16_slack, k / 2))) : kp;
         t.ctx.assign(n_sh, nullptr);
         t.meta.assign(t.nq, QMeta{});
         // one context per shard; never block while holding in-flight work
@@ -1615,6 +1733,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 for (int j = 0; j < t.nq; j++) {
                     prep_query(ix, q + (size_t)j * ix->dim, cx->h_qsw + (size_t)j * ix->qsw_bytes, &t.meta[j]);
                     t.meta[j].mq = nb > 0 && !mq_uses_i8(ix);  // the integer sweeps keep the integer bound
+                    t.meta[j].mq_bf16 = bf16_sweep;
                     if (int_planes)
                         prep_mq_int(ix, q + (size_t)j * ix->dim, &t.meta[j], cx->h_mqQ + (size_t)j * ix->dim);
                     cx->meta[j] = t.meta[j];
@@ -1643,7 +1762,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
             // (before the sweeps: on the context's stream this runs while the scan stream sweeps)
             if (rc == SZG_OK && !sent.empty()) rc = enqueue_sentinels(ix, sh, t.ctx[s], sent, t.nq);
             if (rc == SZG_OK && !replay_all)
-                rc = nb ? enqueue_topk_mq(ix, sh, t.ctx[s], kp, t.nq, nb, t.any_mask)
+                rc = nb ? enqueue_topk_mq(ix, sh, t.ctx[s], t.kp, t.kp_wide, t.nq, nb, t.any_mask)
                         : enqueue_topk(ix, sh, t.ctx[s], kp, t.nq, t.any_mask);
             if (rc == SZG_OK && replay_all && ix->timing >= 2) {
                 const hipError_t e = hipEventRecord(t.ctx[s]->ev_all1, t.ctx[s]->stream);
@@ -2691,6 +2810,13 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
         ix->mq_fused = value != 0;
     } else if (n == "mq_i8") {
         ix->mq_i8 = value != 0;
+    } else if (n == "mq_bf16") {
+        ix->mq_bf16 = value != 0;
+    } else if (n == "mq_overlap") {
+        ix->mq_overlap = value != 0;
+    } else if (n == "mq_bf16_slack") {
+        if (value < 0 || value > 4000) return fail(SZG_E_INVALID, "mq_bf16_slack out of range");
+        ix->mq_bf16_slack = (int)value;
     } else if (n == "mq_tail_overlap") {
         ix->mq_tail_overlap = value != 0;
     } else if (n == "mq_hits") {
