@@ -195,6 +195,8 @@ typedef struct szg_stats {
     double host_prep_us;
     double host_finish_us;
     double host_enqueue_us;
+    uint64_t mq_bf16_sweeps;   /* shared sweeps that ran on the bfloat16 matrix cores (32-bit rows; their candidates
+                                  are re-scored in float32 and re-ranked in float64 like every other path's) */
 } szg_stats;
 
 /* HIP-event timing on the library's own streams (off by default): 1 = events around the scan
@@ -229,7 +231,18 @@ int szg_reset_stats(szg_index *ix);
  *                             up to 16 * mq_blocks (3) queries per sweep; 0 = one sweep per query
  *     mq_i8               1   8- and 4-bit rows: exact integer sweep on the int8 matrix cores
  *                             (v_mfma_i32_16x16x64_i8); 0 = the float32 MFMA sweep
+ *     mq_bf16             1   32-bit rows of whole 64-byte steps (dim % 16 == 0): the sweep multiplies
+ *                             bfloat16 roundings of rows and queries (v_mfma_f32_16x16x32_bf16, 16 x the
+ *                             float32 matrix rate: the sweep becomes a plain stream of the rows), its
+ *                             candidates are scored again in float32 before the selection, and the
+ *                             certification uses the bfloat16 bound (2^-8 |x||q|) for the rows it left
+ *                             out; 0 = the float32 MFMA sweep
+ *     mq_overlap          1   bfloat16 sweeps: a batch's threshold pass and post-processing run on the
+ *                             context's stream beside the neighbouring batches' sweeps (+13 % queries/s)
+ *     mq_bf16_slack       118 candidates kept beyond k where the lists hold bfloat16 keys themselves
+ *                             (score-matrix form: small shards, overflow reruns)
  *     mq_fused            1   threshold-collect selection instead of a score matrix
+ *     mq_hits             1024 candidates per query the threshold from the prefix pass aims at
  *     mq_tail_overlap     0   1 = a batch's selection / rerank / copy-back run beside the next
  *                             batch's sweep (+3-6 % queries/s, the sweep itself 5 % slower)
  *     coalesce            1   concurrent szg_search_topk calls with ONE query each -- the

@@ -57,6 +57,7 @@ class SzgStats(ctypes.Structure):
         ("host_prep_us", ctypes.c_double),
         ("host_finish_us", ctypes.c_double),
         ("host_enqueue_us", ctypes.c_double),
+        ("mq_bf16_sweeps", ctypes.c_uint64),
     ]
 
 

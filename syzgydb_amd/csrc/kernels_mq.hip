@@ -523,12 +523,14 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16_kernel(const MqArgs
         for (int i = tid; i < n16; i += blockDim.x) dst[i] = src[i];
         if (COLLECT && tid < 48)
             reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
+        if (METRIC != kCosine && tid >= 64 && tid < 112)
+            reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid - 16] = a.qnorm2[tid - 64];  // [48..95] = |q|^2
     }
     const v4i32b *qimg = reinterpret_cast<const v4i32b *>(smem);
     const float *thr_lds = reinterpret_cast<const float *>(smem + (size_t)n16 * 16);
     HitBuf hb;
     {
-        uint8_t *base = smem + (size_t)n16 * 16 + 48 * sizeof(float);
+        uint8_t *base = smem + (size_t)n16 * 16 + 96 * sizeof(float);
         hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
         hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
         hb.n = 0;
@@ -629,6 +631,9 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16_kernel(const MqArgs
                 const float4 th = COLLECT ? *reinterpret_cast<const float4 *>(thr_lds + b * 16 + c * 4)
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float thv[4] = {th.x, th.y, th.z, th.w};
+                const float4 qn4 = METRIC == kCosine ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                                     : *reinterpret_cast<const float4 *>(thr_lds + 48 + b * 16 + c * 4);
+                const float qnv[4] = {qn4.x, qn4.y, qn4.z, qn4.w};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int q = b * 16 + c * 4 + r;
@@ -637,7 +642,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16_kernel(const MqArgs
                         key = -acc[b][r] * inv;
                         if (nrm == 0.f) key = nz ? -2.0f : 1.0f;  // zero row: distance 1.0 (collection.go:828-830)
                     } else {
-                        key = fmaf(-2.0f, acc[b][r], nrm + a.qnorm2[q < 48 ? q : 47]);
+                        key = fmaf(-2.0f, acc[b][r], nrm + qnv[r]);
                     }
                     if (!(key == key)) key = 3.0e38f;
                     if (key > 3.0e38f) key = 3.0e38f;
@@ -720,13 +725,15 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
         for (int i = tid; i < n16; i += blockDim.x) dst[i] = src[i];
         if (COLLECT && tid < 48)
             reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
+        if (METRIC != kCosine && tid >= 64 && tid < 112)
+            reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid - 16] = a.qnorm2[tid - 64];  // [48..95] = |q|^2
     }
     const v4i32b *qimg = reinterpret_cast<const v4i32b *>(smem);
     const float *thr_lds = reinterpret_cast<const float *>(smem + (size_t)n16 * 16);
     HitBuf hb;
     uint8_t *stage;
     {
-        uint8_t *base = smem + (size_t)n16 * 16 + 48 * sizeof(float);
+        uint8_t *base = smem + (size_t)n16 * 16 + 96 * sizeof(float);
         hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
         hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
         hb.n = 0;
@@ -851,6 +858,9 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
                 const float4 th = COLLECT ? *reinterpret_cast<const float4 *>(thr_lds + b * 16 + c * 4)
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float thv[4] = {th.x, th.y, th.z, th.w};
+                const float4 qn4 = METRIC == kCosine ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                                     : *reinterpret_cast<const float4 *>(thr_lds + 48 + b * 16 + c * 4);
+                const float qnv[4] = {qn4.x, qn4.y, qn4.z, qn4.w};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int q = b * 16 + c * 4 + r;
@@ -859,7 +869,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
                         key = -acc[b][r] * inv;
                         if (nrm == 0.f) key = nz ? -2.0f : 1.0f;  // zero row: distance 1.0 (collection.go:828-830)
                     } else {
-                        key = fmaf(-2.0f, acc[b][r], nrm + a.qnorm2[q < 48 ? q : 47]);
+                        key = fmaf(-2.0f, acc[b][r], nrm + qnv[r]);
                     }
                     if (!(key == key)) key = 3.0e38f;
                     if (key > 3.0e38f) key = 3.0e38f;
@@ -1459,8 +1469,8 @@ size_t mq_i8_lds_bytes(int row_bits, int r16, int nb)
 }
 size_t mq_bf16_image_bytes(int r16, int nb) { return (size_t)((r16 / 4 + 1) / 2) * nb * 1024; }
 size_t mq_bf16_lds_bytes(int r16, int nb)
-{   // + thresholds and the waves' hit buffers
-    return mq_bf16_image_bytes(r16, nb) + 48 * sizeof(float) + (size_t)SZG_MQB_WAVES * kHitCap * 9 +
+{   // + thresholds, |q|^2 table and the waves' hit buffers
+    return mq_bf16_image_bytes(r16, nb) + 96 * sizeof(float) + (size_t)SZG_MQB_WAVES * kHitCap * 9 +
            (SZG_MQB_STAGED ? (size_t)SZG_MQB_WAVES * 1024 : 0);  // + a KiB of operand staging per wave
 }
 int mq_bf16_image_natural() { return SZG_MQB_STAGED; }

@@ -1199,6 +1199,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
         ix->stats.scan_bytes += sh->n_rows * (uint64_t)ix->row_bytes;  // ONE pass for the batch
         ix->stats.mq_launches += 1;
         ix->stats.mq_queries += (uint64_t)nq;
+        ix->stats.mq_bf16_sweeps += bf16 ? 1 : 0;
     }
     if (ix->timing >= 2) HIPCHK(hipEventRecord(c->ev_all1, c->stream));
     return SZG_OK;
@@ -1538,6 +1539,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                         std::lock_guard<std::mutex> lk(ix->stats_mu);
                         ix->stats.mq_launches -= 1;  // counted again by the rerun
                         ix->stats.mq_queries -= (uint64_t)t.nq;
+                        ix->stats.mq_bf16_sweeps -= (c->mq_stage2 || c->mq_bf16_used) ? 1 : 0;
                         ix->stats.mq_fallbacks += 1;
                     }
                     rc = enqueue_topk_mq(ix, sh, c, t.kp, t.kp_wide, t.nq, c->mq_nb, c->mq_has_allow, true);

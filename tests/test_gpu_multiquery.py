@@ -203,3 +203,70 @@ def test_fused_selection_overflow_falls_back(bits):
                 got = np.sort(d[qi, : c1[qi]])
                 want = np.sort(o_dist)
                 assert ((got == want) | (np.isnan(got) & np.isnan(want))).all(), qi
+
+
+# ---- bfloat16 shared sweep (32-bit rows of whole 64-byte steps) ------------------------------------
+
+@pytest.mark.parametrize("metric", [SZG_COSINE, SZG_EUCLIDEAN])
+@pytest.mark.parametrize("dim,n", [(768, 3000), (48, 6000), (16, 9000), (80, 4000), (1040, 2500), (1536, 2000)])
+def test_bf16_sweep_matches_oracle(metric, dim, n):
+    """Even and odd numbers of 64-byte steps per row (the last 32-element step half empty), two-stage
+    selection; answers identical to the reference loop's."""
+    rows = orc.synth_rows(900 + dim, 0, n, dim, 32)
+    Q = orc.synth_vectors(901 + dim, 0, 50, dim)
+    with ScanIndex(dim, 32, metric) as ix:
+        ix.load(rows)
+        check(ix, rows, dim, Q, 10, metric=metric)
+        st = ix.stats()
+        if DEFAULT_TUNABLES:
+            assert st["mq_bf16_sweeps"] == st["mq_launches"] == 2
+            assert st["mq_fallbacks"] == 0
+        ix.set_option("mq_bf16", 0)
+        ix.reset_stats()
+        check(ix, rows, dim, Q[:20], 10, metric=metric)
+        assert ix.stats()["mq_bf16_sweeps"] == 0
+
+
+def test_bf16_sweep_near_duplicates_and_scales():
+    """Rows that bfloat16 cannot tell apart (relative differences of 1e-4 .. 1e-7, far below 2^-8), rows
+    scaled by 1e+-18 (the same direction: equal cosine keys, the norms near the float32 range ends) and
+    exact duplicates: the float32 re-score and the float64 re-rank decide, the order is the reference's."""
+    rng = np.random.default_rng(77)
+    dim, n = 256, 6000
+    base = rng.standard_normal((8, dim))
+    V = rng.standard_normal((n, dim))
+    for i in range(400):          # clusters of near-copies of 8 directions
+        V[i] = base[i % 8] * (1.0 + rng.standard_normal(dim) * 10.0 ** -(4 + i % 4))
+    V[400:420] = base[0] * 1e18
+    V[420:440] = base[1] * 1e-18
+    V[440:460] = base[2]          # exact duplicates: equal distances -> the exact replay answers
+    rows = orc.encode_rows(V, 32)
+    Q = np.concatenate([base + rng.standard_normal((8, dim)) * 1e-3, rng.standard_normal((24, dim))])
+    for metric in (SZG_COSINE, SZG_EUCLIDEAN):
+        with ScanIndex(dim, 32, metric) as ix:
+            ix.load(rows)
+            check(ix, rows, dim, Q, 25, metric=metric)
+            if DEFAULT_TUNABLES:
+                assert ix.stats()["mq_bf16_sweeps"] >= 1
+
+
+def test_bf16_sweep_masks_and_k_beyond_the_slack():
+    """Filter masks and tombstones act in the bfloat16 sweep's hit path; k = 200 (kp = 300)."""
+    dim, n = 128, 20000
+    rows = orc.synth_rows(950, 0, n, dim, 32)
+    Q = orc.synth_vectors(951, 0, 33, dim)
+    allow = np.arange(n) % 3 != 1
+    with ScanIndex(dim, 32, SZG_COSINE) as ix:
+        ix.load(rows)
+        for r in range(0, n, 7):
+            ix.tombstone(r)
+        live = np.ones(n, bool)
+        live[::7] = False
+        r, d, c = ix.search_topk(Q, 200, allow=np.tile(allow, (33, 1)))
+        for qi in range(33):
+            o_rows, o_dist, _ = orc.search_exact(rows, dim, 32, SZG_COSINE, Q[qi], k=200,
+                                                 allow=(allow & live).astype(np.uint8))
+            assert [int(x) for x in r[qi, : c[qi]]] == [int(x) for x in o_rows]
+            assert (d[qi, : c[qi]] == o_dist).all()
+        if DEFAULT_TUNABLES:
+            assert ix.stats()["mq_bf16_sweeps"] == 1
