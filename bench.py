@@ -544,19 +544,50 @@ def main():
         per_sweep = bst["mq_queries"] / max(bst["mq_launches"], 1)
         flops = 2.0 * n_rows * dim * per_sweep
         tf = flops / (sweep_ms * 1e-3) / 1e12
+        gbps = n_rows * ix.row_bytes / (sweep_ms * 1e-3) / 1e9
+        bf16 = bst.get("mq_bf16_sweeps", 0) > 0
         out["batched"] = {
             "queries": 1024,
             "queries_per_sweep": round(per_sweep, 2),
             "value": round(1024 / b_elapsed, 1), "unit": "queries/s",
-            "kernel": "szg::mq_score_kernel<3,32,cosine,collect> (v_mfma_f32_16x16x4_f32)",
             "avg_sweep_ms": round(sweep_ms, 5),
-            "hbm_GBps": round(n_rows * ix.row_bytes / (sweep_ms * 1e-3) / 1e9, 1),
-            "mfma_TFLOPs": round(tf, 2),
-            "mfma_peak_TFLOPs": MFMA_F32_PEAK_TF,
-            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None},
+            "hbm_GBps": round(gbps, 1),
             "ids_identical_to_single_query_path": bool((b_rows[:64] == s_rows).all()),
         }
+        if bf16:
+            # rows and queries rounded to bfloat16 on the fly, v_mfma_f32_16x16x32_bf16: the sweep is a
+            # stream of the rows (HBM-bound); candidates re-scored in float32, re-ranked in float64
+            out["batched"].update({
+                "kernel": "szg::mq_score_bf16s_kernel<3,cosine,collect> (v_mfma_f32_16x16x32_bf16)",
+                "f32_equivalent_TFLOPs": round(tf, 2),
+                "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(gbps / HBM_PEAK_GBS, 4), "traffic": None},
+            })
+            # the float32 MFMA form of the same sweep (mq_bf16 = 0), for comparison
+            ix.set_option("multi_query", 1)
+            ix.set_option("mq_bf16", 0)
+            ix.search_topk(qb[:96], k)
+            ix.set_timing(True)
+            ix.reset_stats()
+            ix.search_topk(qb[:480], k)
+            fst = ix.stats()
+            ix.set_timing(False)
+            ix.set_option("mq_bf16", 1)
+            ix.set_option("multi_query", 0)
+            f_ms = fst["scan_ms"] / max(fst["timed_launches"], 1)
+            f_tf = 2.0 * n_rows * dim * (fst["mq_queries"] / max(fst["mq_launches"], 1)) / (f_ms * 1e-3) / 1e12
+            out["batched"]["float32_mfma_form"] = {
+                "kernel": "szg::mq_score_kernel<3,32,cosine,collect> (v_mfma_f32_16x16x4_f32)",
+                "avg_sweep_ms": round(f_ms, 5), "mfma_TFLOPs": round(f_tf, 2), "mfma_peak_TFLOPs": MFMA_F32_PEAK_TF,
+                "frac": round(f_tf / MFMA_F32_PEAK_TF, 4)}
+        else:
+            out["batched"].update({
+                "kernel": "szg::mq_score_kernel<3,32,cosine,collect> (v_mfma_f32_16x16x4_f32)",
+                "mfma_TFLOPs": round(tf, 2),
+                "mfma_peak_TFLOPs": MFMA_F32_PEAK_TF,
+                "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                             "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None},
+            })
 
     # ---- recall / parity spot check + CPU baseline (rank 0, N=1) -----------------
     if rank == 0 and world == 1 and not args.no_cpu:

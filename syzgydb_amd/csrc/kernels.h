@@ -145,6 +145,9 @@ size_t scan_lds_bytes(int qbits, const RowMap &m, int kp, int block);
 // Merge n_lists sorted lists of kp candidates into ceil(n_lists/merge_fan(kp)) lists.
 int merge_fan(int kp);
 // ---- multi-query sweep (kernels_mq.hip): 4/8/16/32-bit rows, cosine -------------
+// queries per shared sweep: 48 (3 blocks of 16) for the float32 and int8 sweeps, whose LDS images are
+// 4 and 2-4 bytes per element and query; 96 for the bfloat16 sweep (2 bytes)
+constexpr int kMqMaxQueries = 96;
 struct MqArgs {
     const uint8_t *rows;      // resident mirror
     uint32_t n_rows;
@@ -156,7 +159,7 @@ struct MqArgs {
     int n_queries;            // <= 16 * query blocks
     int metric;               // kCosine: image = q/|q|, key = -cos.  kEuclidean: image = the scan's
                               // prepared query (maxInt*q for quantized rows), key = |n - image|^2
-    float qnorm2[48];         // euclid: |image_q|^2 per query
+    float qnorm2[kMqMaxQueries];  // euclid: |image_q|^2 per query
     float norm_bias;          // integer sweep: turns 4*(sum v'^2 + sum v') into sum n^2 of the real elements
     float *keys;              // out: [n_queries][key_stride] ranking keys
     size_t key_stride;        // floats, multiple of 4, >= n_rows

@@ -521,16 +521,17 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16_kernel(const MqArgs
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (int i = tid; i < n16; i += blockDim.x) dst[i] = src[i];
-        if (COLLECT && tid < 48)
+        // table: [0, 96) thresholds, [96, 192) |q|^2
+        if (COLLECT && tid < kMqMaxQueries)
             reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
-        if (METRIC != kCosine && tid >= 64 && tid < 112)
-            reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid - 16] = a.qnorm2[tid - 64];  // [48..95] = |q|^2
+        if (METRIC != kCosine && tid >= 128 && tid < 128 + kMqMaxQueries)
+            reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid - 32] = a.qnorm2[tid - 128];
     }
     const v4i32b *qimg = reinterpret_cast<const v4i32b *>(smem);
     const float *thr_lds = reinterpret_cast<const float *>(smem + (size_t)n16 * 16);
     HitBuf hb;
     {
-        uint8_t *base = smem + (size_t)n16 * 16 + 96 * sizeof(float);
+        uint8_t *base = smem + (size_t)n16 * 16 + 2 * kMqMaxQueries * sizeof(float);
         hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
         hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
         hb.n = 0;
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16_kernel(const MqArgs
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float thv[4] = {th.x, th.y, th.z, th.w};
                 const float4 qn4 = METRIC == kCosine ? make_float4(0.f, 0.f, 0.f, 0.f)
-                                                     : *reinterpret_cast<const float4 *>(thr_lds + 48 + b * 16 + c * 4);
+                                                     : *reinterpret_cast<const float4 *>(thr_lds + kMqMaxQueries + b * 16 + c * 4);
                 const float qnv[4] = {qn4.x, qn4.y, qn4.z, qn4.w};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -723,17 +724,18 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (int i = tid; i < n16; i += blockDim.x) dst[i] = src[i];
-        if (COLLECT && tid < 48)
+        // table: [0, 96) thresholds, [96, 192) |q|^2
+        if (COLLECT && tid < kMqMaxQueries)
             reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
-        if (METRIC != kCosine && tid >= 64 && tid < 112)
-            reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid - 16] = a.qnorm2[tid - 64];  // [48..95] = |q|^2
+        if (METRIC != kCosine && tid >= 128 && tid < 128 + kMqMaxQueries)
+            reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid - 32] = a.qnorm2[tid - 128];
     }
     const v4i32b *qimg = reinterpret_cast<const v4i32b *>(smem);
     const float *thr_lds = reinterpret_cast<const float *>(smem + (size_t)n16 * 16);
     HitBuf hb;
     uint8_t *stage;
     {
-        uint8_t *base = smem + (size_t)n16 * 16 + 96 * sizeof(float);
+        uint8_t *base = smem + (size_t)n16 * 16 + 2 * kMqMaxQueries * sizeof(float);
         hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
         hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
         hb.n = 0;
@@ -859,7 +861,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float thv[4] = {th.x, th.y, th.z, th.w};
                 const float4 qn4 = METRIC == kCosine ? make_float4(0.f, 0.f, 0.f, 0.f)
-                                                     : *reinterpret_cast<const float4 *>(thr_lds + 48 + b * 16 + c * 4);
+                                                     : *reinterpret_cast<const float4 *>(thr_lds + kMqMaxQueries + b * 16 + c * 4);
                 const float qnv[4] = {qn4.x, qn4.y, qn4.z, qn4.w};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -1470,7 +1472,7 @@ size_t mq_i8_lds_bytes(int row_bits, int r16, int nb)
 size_t mq_bf16_image_bytes(int r16, int nb) { return (size_t)((r16 / 4 + 1) / 2) * nb * 1024; }
 size_t mq_bf16_lds_bytes(int r16, int nb)
 {   // + thresholds, |q|^2 table and the waves' hit buffers
-    return mq_bf16_image_bytes(r16, nb) + 96 * sizeof(float) + (size_t)SZG_MQB_WAVES * kHitCap * 9 +
+    return mq_bf16_image_bytes(r16, nb) + 2 * kMqMaxQueries * sizeof(float) + (size_t)SZG_MQB_WAVES * kHitCap * 9 +
            (SZG_MQB_STAGED ? (size_t)SZG_MQB_WAVES * 1024 : 0);  // + a KiB of operand staging per wave
 }
 int mq_bf16_image_natural() { return SZG_MQB_STAGED; }
@@ -1525,6 +1527,9 @@ hipError_t launch_mq_score_bf16_rows32(const MqArgs &a, int nb, int grid, size_t
     case 1: return launch_mq_score_bf16_m<1>(a, grid, lds, stream);
     case 2: return launch_mq_score_bf16_m<2>(a, grid, lds, stream);
     case 3: return launch_mq_score_bf16_m<3>(a, grid, lds, stream);
+    case 4: return launch_mq_score_bf16_m<4>(a, grid, lds, stream);
+    case 5: return launch_mq_score_bf16_m<5>(a, grid, lds, stream);
+    case 6: return launch_mq_score_bf16_m<6>(a, grid, lds, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -29,7 +29,7 @@
 
 namespace {
 
-constexpr int kMaxBatch = 64;  // queries one scan launch may walk
+constexpr int kMaxBatch = 96;  // queries one batch may stage (szg::kMqMaxQueries: a bfloat16 shared sweep)
 
 thread_local std::string g_last_error;
 
@@ -215,7 +215,7 @@ struct Ctx {
     // fused selection of the shared sweep: thresholds, candidate buffers, hit counts
     float *d_thr = nullptr;
     float *h_thr = nullptr;        // (pinned) the prefix thresholds of a two-stage batch, for certification
-    double *h_qscale = nullptr, *d_qscale = nullptr;  // [64] float32-query scale per staged query (re-score)
+    double *h_qscale = nullptr, *d_qscale = nullptr;  // [128] float32-query scale per staged query (re-score)
     int kp_used = 0;               // candidates per query in h_out for the batch in flight
     bool mq_stage2 = false;        // bfloat16 sweep -> float32 re-score of its candidates -> selection
     bool mq_bf16_used = false;     // the list keys of this batch are bfloat16-sweep keys (matrix form)
@@ -319,7 +319,8 @@ struct szg_index {
     int mq_bf16_slack = 118;  // candidates kept beyond k by a bfloat16 sweep (its band holds more rows)
     int mq_tail_overlap = 0;  // shared sweep: post-processing of a batch beside the next batch's sweep
     int mq_min = 2;           // smallest batch worth a shared sweep (measured: 2 queries already break even)
-    int mq_blocks_max = 3;    // query blocks of 16 per shared sweep (LDS image permitting)
+    int mq_blocks_max = 6;    // query blocks of 16 per shared sweep (LDS image permitting; 3 at most for the
+                              // float32 and int8 sweeps, 6 for the bfloat16 sweep)
     int mq_hits = 1024;       // fused selection: candidates per query the full sweep is expected to collect
                               // (sets the prefix: n_rows * kp / mq_hits rows)
     int timing = 0;           // 0 off, 1 HIP events around the scan launches, 2 + around the whole per-batch pipeline
@@ -916,15 +917,16 @@ void prep_mq_int(const szg_index *ix, const double *q, QMeta *meta, int32_t *Qou
 }
 
 int mq_blocks(const szg_index *ix, int nq)
-{   // query blocks of 16 the batch needs, or 0 when the shared sweep does not apply
+{   // query blocks of 16 the batch gets (nq = the queries left in the call), or 0 when the shared sweep does not apply
     if (!ix->multi_query || ix->bits == 64 || nq < ix->mq_min) return 0;
-    int nb = std::min((nq + 15) / 16, ix->mq_blocks_max);
-    auto lds = [&](int n) {
-        if (mq_uses_bf16(ix)) return szg::mq_bf16_lds_bytes(ix->map.r16, n);
-        return mq_uses_i8(ix) ? szg::mq_i8_lds_bytes(ix->bits, ix->map.r16, n)
-                              : szg::mq_lds_bytes(ix->bits, ix->map.r16, n);
+    const bool bf16 = mq_uses_bf16(ix);
+    int nb = std::min((nq + 15) / 16, std::min(ix->mq_blocks_max, bf16 ? 6 : 3));
+    auto fits = [&](int n) {  // the image (+ tables, hit buffers, staging) must fit LDS
+        if (bf16) return szg::mq_bf16_lds_bytes(ix->map.r16, n) <= 160u * 1024u;
+        return (mq_uses_i8(ix) ? szg::mq_i8_lds_bytes(ix->bits, ix->map.r16, n)
+                               : szg::mq_lds_bytes(ix->bits, ix->map.r16, n)) <= 150u * 1024u;
     };
-    while (nb > 0 && lds(nb) > 150u * 1024u) nb--;  // image must fit LDS
+    while (nb > 0 && !fits(nb)) nb--;
     return nb;
 }
 
@@ -1054,17 +1056,17 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
     rc = ensure_dev(&c->d_keys, &c->keys_cap, key_stride * nq);
     if (rc) return rc;
     if (fused) {
-        if (!c->d_thr) HIPCHK(hipMalloc((void **)&c->d_thr, 64 * sizeof(float)));
-        if (!c->d_cand_count) HIPCHK(hipMalloc((void **)&c->d_cand_count, 64 * szg::kCandCountStride * sizeof(uint32_t)));
+        if (!c->d_thr) HIPCHK(hipMalloc((void **)&c->d_thr, 128 * sizeof(float)));
+        if (!c->d_cand_count) HIPCHK(hipMalloc((void **)&c->d_cand_count, 128 * szg::kCandCountStride * sizeof(uint32_t)));
         if (!c->h_cand_count)
-            HIPCHK(hipHostMalloc((void **)&c->h_cand_count, 64 * szg::kCandCountStride * sizeof(uint32_t), hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void **)&c->h_cand_count, 128 * szg::kCandCountStride * sizeof(uint32_t), hipHostMallocDefault));
         rc = ensure_dev(&c->d_cand, &c->cand_cap_total, (size_t)cand_cap * nq);
         if (rc) return rc;
     }
     if (stage2) {
-        if (!c->h_thr) HIPCHK(hipHostMalloc((void **)&c->h_thr, 64 * sizeof(float), hipHostMallocDefault));
-        if (!c->h_qscale) HIPCHK(hipHostMalloc((void **)&c->h_qscale, 64 * sizeof(double), hipHostMallocDefault));
-        if (!c->d_qscale) HIPCHK(hipMalloc((void **)&c->d_qscale, 64 * sizeof(double)));
+        if (!c->h_thr) HIPCHK(hipHostMalloc((void **)&c->h_thr, 128 * sizeof(float), hipHostMallocDefault));
+        if (!c->h_qscale) HIPCHK(hipHostMalloc((void **)&c->h_qscale, 128 * sizeof(double), hipHostMallocDefault));
+        if (!c->d_qscale) HIPCHK(hipMalloc((void **)&c->d_qscale, 128 * sizeof(double)));
         for (int q = 0; q < nq; q++) {
             const double m1 = c->meta[q].m1;
             c->h_qscale[q] = ix->metric == SZG_COSINE ? (m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0) : 1.0;
@@ -1091,7 +1093,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
     a.queries = c->d_mq;
     a.n_queries = nq;
     a.metric = ix->metric;
-    for (int q = 0; q < nq && q < 48; q++) a.qnorm2[q] = (float)c->meta[q].qnorm2;
+    for (int q = 0; q < nq && q < szg::kMqMaxQueries; q++) a.qnorm2[q] = (float)c->meta[q].qnorm2;
     a.keys = c->d_keys;
     a.key_stride = key_stride;
     a.zero16 = sh->zero16;
@@ -1103,7 +1105,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
     {
         std::lock_guard<std::mutex> lk(sh->chain_mu);
         hipStream_t st = ix->serialize_scans ? sh->scan_stream : c->stream;
-        const bool overlap = bf16 && ix->mq_overlap && st != c->stream;
+        const bool overlap = (bf16 || i8) && ix->mq_overlap && st != c->stream;  // the HBM-bound sweeps
         // (overlap: the threshold pass goes ahead on the context's stream, the sweep follows on the scan stream)
         hipStream_t head = overlap ? c->stream : st;
         if (st != c->stream && !overlap) {
@@ -1174,12 +1176,12 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
         if (stage2) {
             HIPCHK(szg::launch_cand_rescore(ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64, c->d_qscale, c->d_cand,
                                             c->d_cand_count, cand_cap, nq, tail));
-            HIPCHK(hipMemcpyAsync(c->h_thr, c->d_thr, 64 * sizeof(float), hipMemcpyDeviceToHost, tail));
+            HIPCHK(hipMemcpyAsync(c->h_thr, c->d_thr, 128 * sizeof(float), hipMemcpyDeviceToHost, tail));
         }
         if (fused) {
             HIPCHK(szg::launch_cand_select(c->d_cand, c->d_cand_count, cand_cap, kp, nq, c->d_lists_a, tail));
             src = c->d_lists_a;
-            HIPCHK(hipMemcpyAsync(c->h_cand_count, c->d_cand_count, 64 * szg::kCandCountStride * sizeof(uint32_t),
+            HIPCHK(hipMemcpyAsync(c->h_cand_count, c->d_cand_count, 128 * szg::kCandCountStride * sizeof(uint32_t),
                                   hipMemcpyDeviceToHost, tail));
         } else {
             HIPCHK(select_chain((uint32_t)sh->n_rows, key_stride, tail, &src));
@@ -1680,7 +1682,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
         t.first = q0;
         // batches of up to 32 share one sweep when the multi-query path applies
         const int left = n_queries - q0;
-        const int nb = replay_all ? 0 : mq_blocks(ix, std::min(left, 16 * ix->mq_blocks_max));
+        const int nb = replay_all ? 0 : mq_blocks(ix, left);
         t.nq = nb ? std::min(left, 16 * nb) : std::min(B1, left);
         const bool bf16_sweep = nb > 0 && mq_uses_bf16(ix);
         t.kp = kp;
@@ -2530,7 +2532,7 @@ int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
     std::vector<PendingSearch *> batch;
     std::unique_lock<std::mutex> lk(ix->comb_mu);
     try {
-        batch.reserve(48);  // nothing below that touches the combiner's state may throw
+        batch.reserve(kMaxBatch);  // nothing below that touches the combiner's state may throw
         ix->comb_waiting.push_back(&me);
     } catch (...) {
         return fail(SZG_E_NOMEM, "out of memory (host)");
@@ -2548,7 +2550,7 @@ int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
     while (!me.done) {
         batch.clear();
         const int kk = ix->comb_waiting.front()->k;  // never empty here: `me` is in it until done
-        for (auto it = ix->comb_waiting.begin(); it != ix->comb_waiting.end() && batch.size() < 48;) {
+        for (auto it = ix->comb_waiting.begin(); it != ix->comb_waiting.end() && batch.size() < (size_t)kMaxBatch;) {
             if ((*it)->k == kk) {
                 batch.push_back(*it);  // within the reserved capacity
                 it = ix->comb_waiting.erase(it);
@@ -2802,7 +2804,7 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
     } else if (n == "multi_query") {
         ix->multi_query = value != 0;
     } else if (n == "mq_blocks") {
-        if (value < 1 || value > 3) return fail(SZG_E_INVALID, "mq_blocks must be 1..3");
+        if (value < 1 || value > 6) return fail(SZG_E_INVALID, "mq_blocks must be 1..6");
         ix->mq_blocks_max = (int)value;
     } else if (n == "mask_dense") {
         ix->mask_dense = value != 0;

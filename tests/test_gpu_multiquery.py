@@ -39,8 +39,10 @@ def test_shared_sweep_matches_oracle(dim, n, nq):
         ix.load(rows)
         check(ix, rows, dim, Q, 10)
         st = ix.stats()
-        shared = nq - (nq % 48 if nq % 48 < 2 else 0)   # a tail below mq_min (2) gets its own sweep
-        assert st["mq_queries"] == shared and st["mq_launches"] == (shared + 47) // 48
+        if DEFAULT_TUNABLES:
+            cap = 96 if dim % 16 == 0 else 48   # bfloat16 sweep (whole 64-byte steps): 6 query blocks, else 3
+            shared = nq - (nq % cap if nq % cap < 2 else 0)   # a tail below mq_min (2) gets its own sweep
+            assert st["mq_queries"] == shared and st["mq_launches"] == (shared + cap - 1) // cap
         ix.set_option("multi_query", 0)
         ix.reset_stats()
         check(ix, rows, dim, Q[:9], 10)
@@ -219,8 +221,15 @@ def test_bf16_sweep_matches_oracle(metric, dim, n):
         check(ix, rows, dim, Q, 10, metric=metric)
         st = ix.stats()
         if DEFAULT_TUNABLES:
-            assert st["mq_bf16_sweeps"] == st["mq_launches"] == 2
+            # 50 queries: one sweep of 4 query blocks where the image fits LDS (a KiB per 32 elements and block)
+            blocks = min(6, (160 * 1024 - 13600) // (((dim + 31) // 32) * 1024))
+            assert st["mq_bf16_sweeps"] == st["mq_launches"] == (50 + 16 * blocks - 1) // (16 * blocks)
             assert st["mq_fallbacks"] == 0
+            ix.set_option("mq_blocks", 2)
+            ix.reset_stats()
+            check(ix, rows, dim, Q, 10, metric=metric)
+            assert ix.stats()["mq_bf16_sweeps"] == 2
+            ix.set_option("mq_blocks", 6)
         ix.set_option("mq_bf16", 0)
         ix.reset_stats()
         check(ix, rows, dim, Q[:20], 10, metric=metric)
