@@ -203,10 +203,9 @@ size_t mq_i8_image_bytes(int row_bits, int r16, int nb);   // digit image only
 size_t mq_i8_lds_bytes(int row_bits, int r16, int nb);     // image + constants table + hit buffers
 hipError_t launch_mq_score_i8(int row_bits, const MqArgs &a, int nb, int grid, hipStream_t stream);
 // bfloat16 shared sweep for 32-bit rows of whole 64-byte steps (v_mfma_f32_16x16x32_bf16): MqArgs.queries is the
-// image [32-element step][query block][lane = chunk*16 + query][8 bf16]: slots 0..3 = elements 4*chunk + 0..3 of the
-// step's first 16, slots 4..7 = the same of its second 16 (zeros where the row has ended)
+// image [32-element step][query block][lane = k-group*16 + query][8 bf16 = elements 8*k-group + 0..7 of the step]
+// (zeros where the row has ended).
 size_t mq_bf16_image_bytes(int r16, int nb);
-int mq_bf16_image_natural();  // 1: the built kernel wants lane (query, k-group g) = elements 8g..8g+7 of the step
 size_t mq_bf16_lds_bytes(int r16, int nb);
 hipError_t launch_mq_score_bf16(const MqArgs &a, int nb, int grid, hipStream_t stream);
 hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStream_t stream);  // a.metric picks the key

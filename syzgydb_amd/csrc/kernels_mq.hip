@@ -47,9 +47,6 @@ namespace {
 #ifndef SZG_ABL
 #define SZG_ABL 0  // timing experiments (answers become wrong): bit 0 no tile finish, bit 1 no norm work, bit 2 no MFMA,
 #endif             // bit 3 keys formed but hits dropped
-#ifndef SZG_MQB_STAGED
-#define SZG_MQB_STAGED 1  // bfloat16 sweep: 128-byte row segments per load, operands through LDS (0: direct, 64-byte)
-#endif
 #ifndef SZG_MQB_WAVES
 #define SZG_MQB_WAVES 8  // waves per block (one block per CU) of the bfloat16 sweep: 8 x 2 steps x 2 KiB = 32 KiB in
 #endif                    // flight per CU (16 waves or 3 steps: -3..-6 %, as on every streaming kernel here)
@@ -489,13 +486,10 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 // Cauchy-Schwarz the dot product moves by at most (2^-8 + 2^-18) |x| |q|, i.e. 0.0039 in -cos:
 // a band that holds a few dozen rows of a million, all of which the float64 re-rank sees.
 //
-// A wave owns a tile of 16 rows; lane (row = lane & 15, chunk = lane >> 4) loads 16 bytes of
-// two consecutive 64-byte steps (one 128-byte line per row, both halves requested back to
-// back), converts the 8 floats to one B operand, and multiplies with one A operand per query
-// block from LDS (image [32-element step][query block][lane = chunk*16 + query][8 bf16], the
-// same element in the same slot of both operands).  Row norms (of the float32 values) are
-// VALU side work as in mq_score_kernel.  Whole 64-byte steps only (dim % 16 == 0); other
-// shapes use mq_score_kernel.
+// A wave owns a tile of 16 rows and multiplies 32 elements of them per step with one A operand per
+// query block (image [32-element step][query block][lane = k-group*16 + query][8 bf16]).  Row
+// norms (of the float32 values) are VALU side work as in mq_score_kernel.  Whole 64-byte steps
+// only (dim % 16 == 0); other shapes use mq_score_kernel.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -504,203 +498,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define SZG_MQB_RING 2  // 32-byte (two-load) steps per lane in flight
 #endif
 constexpr int kRingB = SZG_MQB_RING;
-
-template <int NB, int METRIC, bool COLLECT>
-__global__ __launch_bounds__(kMqbThreads) void mq_score_bf16_kernel(const MqArgs a)
-{
-    extern __shared__ __align__(16) uint8_t smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int nwaves = blockDim.x >> 6;
-    const int steps = a.r16 / 4;          // 64-byte steps per row (whole ones)
-    const int SS = (steps + 1) / 2;       // 32-element steps; an odd row ends with half a one
-    const bool odd = (steps & 1) != 0;
-    const int n16 = SS * NB * 64;         // image, 16-byte words
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
-        uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (int i = tid; i < n16; i += blockDim.x) dst[i] = src[i];
-        // table: [0, 96) thresholds, [96, 192) |q|^2
-        if (COLLECT && tid < kMqMaxQueries)
-            reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
-        if (METRIC != kCosine && tid >= 128 && tid < 128 + kMqMaxQueries)
-            reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid - 32] = a.qnorm2[tid - 128];
-    }
-    const v4i32b *qimg = reinterpret_cast<const v4i32b *>(smem);
-    const float *thr_lds = reinterpret_cast<const float *>(smem + (size_t)n16 * 16);
-    HitBuf hb;
-    {
-        uint8_t *base = smem + (size_t)n16 * 16 + 2 * kMqMaxQueries * sizeof(float);
-        hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
-        hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
-        hb.n = 0;
-    }
-
-    const int trow = lane & 15;
-    const int c = lane >> 4;
-    const uint64_t n_tiles = ((uint64_t)a.n_rows + 15) / 16;
-    const uint64_t tile_stride = (uint64_t)gridDim.x * nwaves;
-    const uint64_t tile_first = (uint64_t)blockIdx.x * nwaves + wave;
-    const uint64_t n_it = tile_first < n_tiles ? (n_tiles - tile_first + tile_stride - 1) / tile_stride : 0;
-    const uint64_t NP = n_it * (uint64_t)SS;
-
-    uint64_t itile = tile_first;
-    int is = 0;
-    uint64_t ctile = tile_first;
-    int cs = 0;
-
-    u32x4 ring_a[kRingB], ring_b[kRingB];
-    f32x4 acc[NB];
-#pragma unroll
-    for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float nrm = 0.f;
-    uint32_t nz = 0;
-    v4i32b qn[NB];  // A operands of the step about to be multiplied (one ahead)
-
-    auto row_ptr = [&](uint64_t tile) -> const uint8_t * {
-        const uint64_t r = min(tile * 16 + trow, (uint64_t)a.n_rows - 1);  // past the end: a valid row, discarded
-        return a.rows + (size_t)r * a.pitch + (size_t)c * 16;
-    };
-    const uint8_t *iptr = row_ptr(tile_first);
-
-    // the half step at the end of an odd row reads its one real piece twice; the image holds
-    // zeros against the second copy and the norm skips it
-#define MQB_ISSUE(u)                                                                     \
-    {                                                                                    \
-        ring_a[u] = load_nt(iptr);                                                       \
-        ring_b[u] = load_nt(iptr + ((odd && is == SS - 1) ? 0 : 64));                    \
-        if (++is == SS) {                                                                \
-            is = 0;                                                                      \
-            itile += tile_stride;                                                        \
-            iptr = row_ptr(itile);                                                       \
-        } else {                                                                         \
-            iptr += 128;                                                                 \
-        }                                                                                \
-    }
-
-#define MQB_CONSUME(u)                                                                   \
-    {                                                                                    \
-        const u32x4 va_ = ring_a[u], vb_ = ring_b[u];                                    \
-        const bool half_ = odd && cs == SS - 1;                                          \
-        const float xa_[4] = {__uint_as_float(va_.x), __uint_as_float(va_.y), __uint_as_float(va_.z),       \
-                              __uint_as_float(va_.w)};                                   \
-        const float xb_[4] = {__uint_as_float(vb_.x), __uint_as_float(vb_.y), __uint_as_float(vb_.z),       \
-                              __uint_as_float(vb_.w)};                                   \
-        _Pragma("unroll") for (int i = 0; i < 4; i++) nrm = fmaf(xa_[i], xa_[i], nrm);   \
-        if (!half_) {                                                                    \
-            _Pragma("unroll") for (int i = 0; i < 4; i++) nrm = fmaf(xb_[i], xb_[i], nrm); \
-        }                                                                                \
-        nz |= va_.x | va_.y;                                                             \
-        nz |= va_.z | va_.w;                                                             \
-        nz |= vb_.x | vb_.y;                                                             \
-        nz |= vb_.z | vb_.w;                                                             \
-        const bf16x2 t0_ = __builtin_convertvector(f32x2{xa_[0], xa_[1]}, bf16x2);       \
-        const bf16x2 t1_ = __builtin_convertvector(f32x2{xa_[2], xa_[3]}, bf16x2);       \
-        const bf16x2 t2_ = __builtin_convertvector(f32x2{xb_[0], xb_[1]}, bf16x2);       \
-        const bf16x2 t3_ = __builtin_convertvector(f32x2{xb_[2], xb_[3]}, bf16x2);       \
-        const bf16x8 bop_ = {t0_[0], t0_[1], t1_[0], t1_[1], t2_[0], t2_[1], t3_[0], t3_[1]}; \
-        const int qnext_ = lane + (cs + 1 == SS ? 0 : cs + 1) * (NB * 64);               \
-        _Pragma("unroll") for (int b = 0; b < NB; b++)                                   \
-        {                                                                                \
-            const v4i32b qc_ = qn[b];                                                    \
-            qn[b] = qimg[qnext_ + b * 64];                                               \
-            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qc_), bop_, acc[b], 0, 0, 0); \
-        }                                                                                \
-        if (++cs == SS) {                                                                \
-            nz &= 0x7FFFFFFFu;                                                           \
-            finish_tile(ctile);                                                          \
-            cs = 0;                                                                      \
-            ctile += tile_stride;                                                        \
-        }                                                                                \
-    }
-
-    // a row tile is done: row norms across the 4 chunk lanes, keys out (as mq_score_kernel)
-    auto finish_tile = [&](uint64_t tile) {
-        nrm += __shfl_xor(nrm, 16);
-        nrm += __shfl_xor(nrm, 32);
-        nz |= __shfl_xor(nz, 16);
-        nz |= __shfl_xor(nz, 32);
-        const uint64_t row = tile * 16 + trow;
-        const float inv = __frsqrt_rn(nrm);
-        if (COLLECT || row < a.n_rows) {
-            float keys[NB][4];
-            uint32_t hm = 0;
-            const bool row_ok = row < a.n_rows;
-#pragma unroll
-            for (int b = 0; b < NB; b++) {
-                const float4 th = COLLECT ? *reinterpret_cast<const float4 *>(thr_lds + b * 16 + c * 4)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float thv[4] = {th.x, th.y, th.z, th.w};
-                const float4 qn4 = METRIC == kCosine ? make_float4(0.f, 0.f, 0.f, 0.f)
-                                                     : *reinterpret_cast<const float4 *>(thr_lds + kMqMaxQueries + b * 16 + c * 4);
-                const float qnv[4] = {qn4.x, qn4.y, qn4.z, qn4.w};
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int q = b * 16 + c * 4 + r;
-                    float key;
-                    if (METRIC == kCosine) {
-                        key = -acc[b][r] * inv;
-                        if (nrm == 0.f) key = nz ? -2.0f : 1.0f;  // zero row: distance 1.0 (collection.go:828-830)
-                    } else {
-                        key = fmaf(-2.0f, acc[b][r], nrm + qnv[r]);
-                    }
-                    if (!(key == key)) key = 3.0e38f;
-                    if (key > 3.0e38f) key = 3.0e38f;
-                    keys[b][r] = key;
-                    if (COLLECT)
-                        hm |= (row_ok && q < a.n_queries && key <= thv[r]) ? (1u << (b * 4 + r)) : 0u;
-                    else if (q < a.n_queries)
-                        a.keys[(size_t)q * a.key_stride + row] = key;
-                }
-            }
-            if (COLLECT) offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row);
-        }
-        if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores (see mq_score_kernel)
-#pragma unroll
-        for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        nrm = 0.f;
-        nz = 0;
-    };
-
-    {
-        uint64_t issued = kRingB, consumed = 0;
-#pragma unroll
-        for (int u = 0; u < kRingB; u++) {
-            MQB_ISSUE(u)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();  // the query image is complete (the rows do not depend on it)
-#pragma unroll
-        for (int b = 0; b < NB; b++) qn[b] = qimg[lane + b * 64];
-        while (consumed + 2 * kRingB <= NP) {
-#pragma unroll
-            for (int u = 0; u < kRingB; u++) {
-                MQB_CONSUME(u)
-                MQB_ISSUE(u)
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            consumed += kRingB;
-            issued += kRingB;
-        }
-        while (consumed < NP) {
-#pragma unroll
-            for (int u = 0; u < kRingB; u++) {
-                if (consumed < NP) {
-                    MQB_CONSUME(u)
-                    consumed++;
-                    if (issued < NP) {
-                        MQB_ISSUE(u)
-                        issued++;
-                    }
-                }
-            }
-        }
-    }
-#undef MQB_ISSUE
-#undef MQB_CONSUME
-    if (COLLECT) hit_flush(a, hb, lane);
-}
+#ifndef SZG_MQB_RING_PREFIX
+#define SZG_MQB_RING_PREFIX 6
+#endif
+constexpr int kRingBPrefix = SZG_MQB_RING_PREFIX;
 
 // Staged form: a load instruction reads 128 contiguous bytes of each of 8 rows (8 lanes x 16 bytes per
 // row) instead of 64 bytes of each of 16 -- the streaming pattern the memory system likes better
@@ -759,7 +560,9 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
     uint64_t ctile = tile_first;
     int cs = 0;
 
-    u32x4 ring_a[kRingB], ring_b[kRingB];
+    // the threshold pass (no COLLECT) sweeps a few tiles per wave on a few CUs: latency-bound, deeper ring
+    constexpr int R = COLLECT ? kRingB : kRingBPrefix;
+    u32x4 ring_a[R], ring_b[R];
     f32x4 acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -892,28 +695,28 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
     };
 
     {
-        uint64_t issued = kRingB, consumed = 0;
+        uint64_t issued = R, consumed = 0;
 #pragma unroll
-        for (int u = 0; u < kRingB; u++) {
+        for (int u = 0; u < R; u++) {
             MQS_ISSUE(u)
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();  // the query image is complete (the rows do not depend on it)
 #pragma unroll
         for (int b = 0; b < NB; b++) qn[b] = qimg[lane + b * 64];
-        while (consumed + 2 * kRingB <= NP) {
+        while (consumed + 2 * R <= NP) {
 #pragma unroll
-            for (int u = 0; u < kRingB; u++) {
+            for (int u = 0; u < R; u++) {
                 MQS_CONSUME(u)
                 MQS_ISSUE(u)
                 __builtin_amdgcn_sched_barrier(0);
             }
-            consumed += kRingB;
-            issued += kRingB;
+            consumed += R;
+            issued += R;
         }
         while (consumed < NP) {
 #pragma unroll
-            for (int u = 0; u < kRingB; u++) {
+            for (int u = 0; u < R; u++) {
                 if (consumed < NP) {
                     MQS_CONSUME(u)
                     consumed++;
@@ -1236,18 +1039,29 @@ __global__ __launch_bounds__(256) void mq_select_kernel(const float *keys, size_
     const uint64_t *allow = allow_bits ? allow_bits + (size_t)q * allow_stride : nullptr;
     const uint32_t n4 = (n_rows + 3) / 4;  // key_stride is a multiple of 4, the tail holds +inf
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + tid; i < ((n4 + stride - 1) / stride) * stride; i += stride) {
-        float4 v = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f);
-        if (i < n4) v = reinterpret_cast<const float4 *>(kq)[i];
-        const float kk[4] = {v.x, v.y, v.z, v.w};
+    constexpr int U = 4;  // loads in flight per thread (one block per query walks its keys: latency-bound)
+    for (uint32_t i0 = blockIdx.x * blockDim.x + tid; i0 < ((n4 + stride - 1) / stride) * stride; i0 += U * stride) {
+        float4 v[U];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const uint32_t row = i * 4 + e;
-            bool ok = i < n4 && row < n_rows;
-            if (ok && live_bits) ok = (live_bits[row >> 6] >> (row & 63)) & 1;
-            if (ok && allow) ok = (allow[row >> 6] >> (row & 63)) & 1;
-            const uint64_t cnd = ((uint64_t)ordered_key(kk[e]) << 32) | row;
-            wl.offer(ok, cnd, lane);
+        for (int u = 0; u < U; u++) {
+            const uint32_t i = i0 + u * stride;
+            v[u] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f);
+            if (i < n4) v[u] = reinterpret_cast<const float4 *>(kq)[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t i = i0 + u * stride;
+            if (i >= ((n4 + stride - 1) / stride) * stride) break;  // (uniform over the block)
+            const float kk[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t row = i * 4 + e;
+                bool ok = i < n4 && row < n_rows;
+                if (ok && live_bits) ok = (live_bits[row >> 6] >> (row & 63)) & 1;
+                if (ok && allow) ok = (allow[row >> 6] >> (row & 63)) & 1;
+                const uint64_t cnd = ((uint64_t)ordered_key(kk[e]) << 32) | row;
+                wl.offer(ok, cnd, lane);
+            }
         }
     }
     wl.flush(lane);
@@ -1473,9 +1287,8 @@ size_t mq_bf16_image_bytes(int r16, int nb) { return (size_t)((r16 / 4 + 1) / 2)
 size_t mq_bf16_lds_bytes(int r16, int nb)
 {   // + thresholds, |q|^2 table and the waves' hit buffers
     return mq_bf16_image_bytes(r16, nb) + 2 * kMqMaxQueries * sizeof(float) + (size_t)SZG_MQB_WAVES * kHitCap * 9 +
-           (SZG_MQB_STAGED ? (size_t)SZG_MQB_WAVES * 1024 : 0);  // + a KiB of operand staging per wave
+           (size_t)SZG_MQB_WAVES * 1024;  // + a KiB of operand staging per wave
 }
-int mq_bf16_image_natural() { return SZG_MQB_STAGED; }
 hipError_t launch_mq_score_bf16_rows32(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
 hipError_t launch_mq_score_bf16(const MqArgs &a, int nb, int grid, hipStream_t stream)
 {
@@ -1497,11 +1310,7 @@ namespace {
 template <int NB, int METRIC, bool COLLECT>
 hipError_t launch_mq_score_bf16_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
-#if SZG_MQB_STAGED
     auto *kern = &mq_score_bf16s_kernel<NB, METRIC, COLLECT>;
-#else
-    auto *kern = &mq_score_bf16_kernel<NB, METRIC, COLLECT>;
-#endif
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

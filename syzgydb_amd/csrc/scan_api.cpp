@@ -297,7 +297,8 @@ struct szg_index {
     std::vector<Shard *> shards;
     // tunables
     int slack_min = 16;
-    int n_ctx = 3;
+    int n_ctx = 3;            // contexts (and streams) per shard
+    int n_ctx_active = 3;
     int blocks_per_cu = 0;    // 0 = choose from the row format (scan_geometry)
     int block_threads = 256;
     int query_batch = 16;     // queries per scan launch
@@ -949,8 +950,8 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
     if (rc) return rc;
     memset(c->h_mq, 0, img);
     if (bf16) {
-        // [32-element step][query block][lane = chunk*16 + query][8 bf16]: slots 0..3 hold elements
-        // 4*chunk + 0..3 of the step's first 16, slots 4..7 the same of its second 16.  Cosine: q/|q|.
+        // [32-element step][query block][lane = k-group*16 + query][8 bf16 = elements 8*k-group + 0..7
+        // of the step]; cosine: q/|q|.
         uint16_t *im = reinterpret_cast<uint16_t *>(c->h_mq);
         for (int q = 0; q < nq; q++) {
             const double *src = c->h_q64 + (size_t)q * ix->dim;
@@ -958,12 +959,9 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
             double scale = m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0;
             if (ix->metric != SZG_COSINE) scale = 1.0;
             const int b = q / 16, qi = q % 16;
-            const bool natural = szg::mq_bf16_image_natural() != 0;  // (the staged kernel: lane (query, g) = 8g..8g+7)
             for (int e = 0; e < ix->dim; e++) {
-                const int S = e >> 5, w = e & 31, half = w >> 4, ch = (w & 15) >> 2, m = w & 3;
-                const size_t at = natural ? ((((size_t)S * nb + b) * 64) + (w >> 3) * 16 + qi) * 8 + (w & 7)
-                                          : ((((size_t)S * nb + b) * 64) + ch * 16 + qi) * 8 + half * 4 + m;
-                im[at] = bf16_rne((float)(src[e] * scale));
+                const int S = e >> 5, w = e & 31;
+                im[((((size_t)S * nb + b) * 64) + (w >> 3) * 16 + qi) * 8 + (w & 7)] = bf16_rne((float)(src[e] * scale));
             }
         }
     } else if (i8) {
@@ -2095,7 +2093,7 @@ int szg_index_create(szg_index **out, int dim, int quant_bits, int metric, const
                 return rc;
             }
             sh->all_ctx.push_back(c);
-            sh->free_ctx.push_back(c);
+            (i < ix->n_ctx_active ? sh->free_ctx : sh->parked_ctx).push_back(c);
         }
     }
     *out = ix;
