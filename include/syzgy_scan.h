@@ -228,7 +228,9 @@ int szg_reset_stats(szg_index *ix);
  *   shared sweeps
  *     multi_query         1   batches of >= mq_min (2) queries share ONE sweep of the corpus, the
  *                             dot products on the matrix cores (4/8/16/32-bit rows, either metric),
- *                             up to 16 * mq_blocks (3) queries per sweep; 0 = one sweep per query
+ *                             up to 16 * mq_blocks queries per sweep (mq_blocks 6: 96 for the bfloat16
+ *                             sweep of 32-bit rows, 48 = 3 blocks at most for the others, fewer when
+ *                             the image does not fit LDS); 0 = one sweep per query
  *     mq_i8               1   8- and 4-bit rows: exact integer sweep on the int8 matrix cores
  *                             (v_mfma_i32_16x16x64_i8); 0 = the float32 MFMA sweep
  *     mq_bf16             1   32-bit rows of whole 64-byte steps (dim % 16 == 0): the sweep multiplies
@@ -246,7 +248,7 @@ int szg_reset_stats(szg_index *ix);
  *     mq_tail_overlap     0   1 = a batch's selection / rerank / copy-back run beside the next
  *                             batch's sweep (+3-6 % queries/s, the sweep itself 5 % slower)
  *     coalesce            1   concurrent szg_search_topk calls with ONE query each -- the
- *                             reference's Searches under RLock -- are answered together, up to 48
+ *                             reference's Searches under RLock -- are answered together, up to 96
  *                             per shared sweep, by whichever caller finds no batch in flight
  *   tests / tuning hooks: force_escalate, lanes_per_row
  */
