@@ -42,7 +42,7 @@ while time.time() < t_end:
         n = max(1, 4_000_000 // dim)
     nq = int(rng.choice([1, 2, 7, 8, 9, 16, 17, 33, 50]))
     k = int(rng.choice([1, 2, 10, 11, 50, 100, 300, 5000]))
-    kind = int(rng.integers(0, 7))
+    kind = int(rng.integers(0, 8))
     vec = rng.uniform(-1, 1, (n, dim))
     if kind == 1:          # duplicates
         vec[rng.integers(0, n, n // 2)] = vec[0]
@@ -59,6 +59,9 @@ while time.time() < t_end:
     elif kind == 6 and bits >= 32:   # NaN / Inf elements in stored rows
         for r0 in rng.integers(0, n, 3):
             vec[r0, int(rng.integers(0, dim))] = float(rng.choice([np.nan, np.inf, -np.inf]))
+    elif kind == 7 and bits == 32:   # elements whose squares overflow float32 (finite in the reference's float64)
+        for r0 in rng.integers(0, n, 4):
+            vec[r0] = vec[r0] * float(rng.choice([1e19, 1e25, 1e37]))
     rows = orc.encode_rows(vec, bits)
     if kind == 3 and bits >= 32:
         Q = Q * 1e3 + 5e3

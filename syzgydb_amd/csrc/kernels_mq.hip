@@ -399,6 +399,7 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
                     if (METRIC == kCosine) {
                         key = -acc[b][r] * inv;
                         if (nrm == 0.f) key = nz ? -2.0f : 1.0f;  // zero row: distance 1.0 (collection.go:828-830)
+                        if (QBITS == 32 && !(nrm <= 3.0e38f)) key = -2.0f;  // norm overflow: forced in (see RowAcc::finish)
                     } else {  // |x - q|^2 = |x|^2 - 2 x.q + |q|^2 (the error bound knows: key_eps, mq)
                         key = fmaf(-2.0f, acc[b][r], nrm + a.qnorm2[q < 48 ? q : 47]);
                     }
@@ -673,6 +674,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
                     if (METRIC == kCosine) {
                         key = -acc[b][r] * inv;
                         if (nrm == 0.f) key = nz ? -2.0f : 1.0f;  // zero row: distance 1.0 (collection.go:828-830)
+                        if (!(nrm <= 3.0e38f)) key = -2.0f;  // norm overflow: forced in (see RowAcc::finish)
                     } else {
                         key = fmaf(-2.0f, acc[b][r], nrm + qnv[r]);
                     }
@@ -1160,6 +1162,7 @@ __global__ __launch_bounds__(256) void cand_rescore_kernel(const uint8_t *rows, 
         if (METRIC == kCosine) {
             key = -dot * __frsqrt_rn(nrm);
             if (nrm == 0.f) key = nz ? -2.0f : 1.0f;
+            if (!(nrm <= 3.0e38f)) key = -2.0f;  // norm overflow: forced in (see RowAcc::finish)
         } else {
             key = dot;
         }

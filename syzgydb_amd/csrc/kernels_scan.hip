@@ -214,16 +214,21 @@ struct RowAcc {
         if (METRIC != kCosine) return (float)a0;
         a1 = grp_sum(a1, g);
         // a zero row is distance 1.0 (collection.go:828-830) == cos -1; an underflowed
-        // norm is forced in (key -2) and settled by the float64 rerank
+        // norm is forced in (key -2) and settled by the float64 rerank -- and so is an
+        // overflowed one (float32 rows with elements beyond ~1e19: finite in float64, the
+        // reference ranks them; a row with an Inf / NaN element lands here too, its float64
+        // distance is NaN and the host drops it)
         const bool zero = a1 == (acc_t)0;
+        const bool over = sizeof(acc_t) == 4 && !((float)a1 <= 3.0e38f);
         float key;
         if (sizeof(acc_t) == 4)
             key = -(float)a0 * __frsqrt_rn((float)a1);
         else
             key = (float)(-a0 / sqrt(a1));
-        if (__ballot(zero && lead)) {  // rare
+        if (__ballot((zero || over) && lead)) {  // rare
             nz = grp_or(nz, g);
             if (zero) key = nz ? -2.0f : 1.0f;
+            if (over) key = -2.0f;
         }
         return key;
     }

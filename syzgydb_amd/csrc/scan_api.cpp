@@ -1588,6 +1588,15 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                     ix->stats.full_replays++;
                 }
             } else {
+            // A NaN distance outside the query's first k eligible rows never enters the reference's heap
+            // (`distance < worst` is false, collection.go:608-619); rows with an Inf / NaN element are forced
+            // into the lists by the kernels (their float32 norm is not finite) and leave here.  A NaN among
+            // the first k rows is the sentinels' business (nan_first: exact replay).
+            auto drop_nan = [&](std::vector<Cand> &v) {
+                if (nan_first[j]) return;
+                v.erase(std::remove_if(v.begin(), v.end(), [](const Cand &c) { return std::isnan(c.dist); }), v.end());
+            };
+            drop_nan(cands);
             replay_topk(cands, k, &res);
             // certification: every row outside the lists has a real-number key >= thr_min (the
             // lists' own lower bound), so the result is final once the upper bound of its worst
@@ -1624,7 +1633,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                     const double e2 = key_eps(ix, kmax, single);
                     thr = kmax + 1.05 * e2 + 0.05 * std::fabs(kmax) * 0x1p-20;
                 }
-                const float thr_f = thr >= 3.0e38 ? 3.0e38f : std::nextafter((float)thr, INFINITY);
+                const float thr_f = !(thr < 3.0e38) ? 3.0e38f : std::nextafter((float)thr, INFINITY);
                 cands.clear();
                 const double td = now_us();
                 for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
@@ -1633,7 +1642,10 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                     rc = run_collect(ix, sh, t.ctx[s], j, thr_f, t.any_mask, &cands);
                 }
                 t_dev += now_us() - td;
-                if (rc == SZG_OK) replay_topk(cands, k, &res);
+                if (rc == SZG_OK) {
+                    drop_nan(cands);
+                    replay_topk(cands, k, &res);
+                }
             }
             if (rc == SZG_OK && ix->tie_mode == 0) {
                 std::vector<double> d(cands.size());
@@ -2633,7 +2645,8 @@ int szg_search_radius(szg_index *ix, const double *query, double radius,
         const double scale = ix->bits <= 16 ? (double)((1u << ix->bits) - 1u) : 1.0;
         const double kk = (radius * scale) * (radius * scale);
         const double t = kk * (1.0 + 1e-12) + 2.0 * key_eps(ix, kk, meta);
-        thr_f = t >= 3.0e38 ? 3.0e38f : std::nextafter((float)t, INFINITY);
+        // (an infinite radius with a zero query makes t = inf + 0 * inf = NaN: everything, as for any t beyond the floats)
+        thr_f = !(t < 3.0e38) ? 3.0e38f : std::nextafter((float)t, INFINITY);
     }
 
     std::vector<Cand> cands;

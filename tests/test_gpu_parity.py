@@ -361,3 +361,53 @@ def test_tie_mode_1_returns_a_valid_topk(bits, metric, dim):
                 assert (np.diff(got_d) >= 0).all()
                 assert (got_d == want_all[got_r.astype(np.int64)]).all()
                 assert (np.sort(got_d) == np.sort(np.asarray(o_dist))).all()
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_infinite_radius_with_zero_query(bits):
+    """Radius = +inf (a distance of a row with an infinite element, used as the radius) and an all-zero
+    query: the key threshold must not turn into NaN (0 * inf) -- every row at a non-NaN distance is a hit."""
+    rng = np.random.default_rng(12)
+    dim, n = 5, 40
+    V = rng.uniform(-1, 1, (n, dim))
+    V[3, 2] = np.inf
+    V[7, 0] = np.nan
+    rows = orc.encode_rows(V, bits)
+    q = np.zeros(dim)
+    with ScanIndex(dim, bits, SZG_EUCLIDEAN) as ix:
+        ix.load(rows)
+        r, d = ix.search_radius(q, np.inf)
+    o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, SZG_EUCLIDEAN, q, radius=np.inf)
+    assert len(o_rows) == n - 1
+    assert [int(x) for x in r] == [int(x) for x in o_rows]
+    assert (np.asarray(d) == np.asarray(o_dist)).all()
+
+
+@pytest.mark.parametrize("metric", [SZG_COSINE, SZG_EUCLIDEAN])
+@pytest.mark.parametrize("n_inf", [3, 40])
+def test_float32_rows_beyond_the_float32_norm_range(metric, n_inf):
+    """Elements of 1e19 .. 3e37 are ordinary float32 values whose squared norm overflows float32 but not
+    the reference's float64: such rows are forced into the candidate lists and ranked by the float64
+    re-rank (they are the nearest rows here, by angle).  Rows with an Inf / NaN element take the same way
+    in and are dropped on the host (NaN distance) unless they are among a query's first k rows -- also
+    when there are more of them than list slots."""
+    rng = np.random.default_rng(5)
+    dim, n = 64, 5000
+    V = rng.standard_normal((n, dim))
+    Q = rng.standard_normal((20, dim))
+    for i, s in enumerate([1e19, 1e20, 1e25, 1e30, 3e37]):
+        V[100 + i] = Q[0] * s + rng.standard_normal(dim) * s * 1e-3
+    V[200] = Q[1] * 1e-25                       # float32 norm underflows to 0
+    for r in rng.choice(np.arange(300, n), n_inf, replace=False):
+        V[r, int(rng.integers(0, dim))] = [np.inf, -np.inf, np.nan][int(r) % 3]
+    rows = orc.encode_rows(V, 32)
+    with ScanIndex(dim, 32, metric) as ix:
+        ix.load(rows)
+        for multi in (0, 1):
+            ix.set_option("multi_query", multi)
+            qs = Q if multi else Q[:3]
+            r, d, c = ix.search_topk(qs, 10)
+            for qi in range(qs.shape[0]):
+                o_rows, o_dist, _ = orc.search_exact(rows, dim, 32, metric, qs[qi], k=10)
+                assert [int(x) for x in r[qi, : c[qi]]] == [int(x) for x in o_rows], (multi, qi)
+                assert (d[qi, : c[qi]] == o_dist).all()
