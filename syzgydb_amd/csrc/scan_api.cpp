@@ -1240,7 +1240,11 @@ void gather_topk(const szg_index *ix, const Shard *sh, const Ctx *c, const QMeta
         valid++;
         const float key = szg::key_from_ordered(r.ukey);
         worst = std::max(worst, key);
-        cands->push_back(Cand{sh->first + r.row, r.dist, key, (double)key + key_eps(ix, key, lm)});
+        double ub = (double)key + key_eps(ix, key, lm);
+        // a row forced in (key -2: float32 norm under- or overflowed) carries no information in its key;
+        // its float64 distance does: -cos(pi d) is the real-number key
+        if (ix->metric == SZG_COSINE && key <= -1.5f && !std::isnan(r.dist)) ub = -std::cos(M_PI * r.dist) + 1e-9;
+        cands->push_back(Cand{sh->first + r.row, r.dist, key, ub});
     }
     *lb = valid == kp ? (double)worst - key_eps(ix, worst, lm) : INFINITY;
     if (c->mq_stage2) {

@@ -411,3 +411,27 @@ def test_float32_rows_beyond_the_float32_norm_range(metric, n_inf):
                 o_rows, o_dist, _ = orc.search_exact(rows, dim, 32, metric, qs[qi], k=10)
                 assert [int(x) for x in r[qi, : c[qi]]] == [int(x) for x in o_rows], (multi, qi)
                 assert (d[qi, : c[qi]] == o_dist).all()
+
+
+@pytest.mark.parametrize("multi", [0, 1])
+def test_forced_rows_do_not_hide_the_true_nearest(multi):
+    """k = 1 without slack: the one list slot goes to a forced row (float32 norm overflow, key -2), the true
+    nearest row has key -1.  The escalation must start from the forced row's real key (from its float64
+    distance), not from -2 (found by the fuzzer)."""
+    rng = np.random.default_rng(9)
+    dim, n = 5, 200
+    V = rng.uniform(-1, 1, (n, dim))
+    for r in (100, 120, 150, 180):
+        V[r] *= 1e25
+    rows = orc.encode_rows(V, 32)
+    Q = rng.uniform(-1, 1, (16, dim))
+    Q[0] = V[25]
+    with ScanIndex(dim, 32, SZG_COSINE) as ix:
+        ix.load(rows)
+        ix.set_option("slack", 0)
+        ix.set_option("multi_query", multi)
+        r, d, c = ix.search_topk(Q, 1)
+        for qi in range(16):
+            o_rows, o_dist, _ = orc.search_exact(rows, dim, 32, SZG_COSINE, Q[qi], k=1)
+            assert [int(x) for x in r[qi, : c[qi]]] == [int(x) for x in o_rows], qi
+            assert (d[qi, : c[qi]] == o_dist).all()
