@@ -47,6 +47,9 @@ namespace {
 #ifndef SZG_ABL
 #define SZG_ABL 0  // timing experiments (answers become wrong): bit 0 no tile finish, bit 1 no norm work, bit 2 no MFMA,
 #endif             // bit 3 keys formed but hits dropped
+#ifndef SZG_RESCORE_BLOCKS
+#define SZG_RESCORE_BLOCKS 64  // blocks (of 4 waves) per query of the float32 re-score
+#endif
 #ifndef SZG_MQB_WAVES
 #define SZG_MQB_WAVES 8  // waves per block (one block per CU) of the bfloat16 sweep: 8 x 2 steps x 2 KiB = 32 KiB in
 #endif                    // flight per CU (16 waves or 3 steps: -3..-6 %, as on every streaming kernel here)
@@ -1197,7 +1200,7 @@ hipError_t launch_cand_rescore(int metric, const uint8_t *rows, uint32_t pitch, 
                                uint32_t cand_cap, int n_queries, hipStream_t stream)
 {
     if (dim % 4 != 0) return hipErrorInvalidValue;
-    const dim3 grid(64, n_queries);
+    const dim3 grid(SZG_RESCORE_BLOCKS, n_queries);  // x 4 waves: one candidate per wave and trip
     const size_t lds = (size_t)dim * sizeof(float);
     if (metric == kCosine)
         hipLaunchKernelGGL(cand_rescore_kernel<kCosine>, grid, dim3(256), lds, stream, rows, pitch, dim, q64, qscale,
