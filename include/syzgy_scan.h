@@ -195,6 +195,8 @@ typedef struct szg_stats {
     double host_prep_us;
     double host_finish_us;
     double host_enqueue_us;
+    uint64_t sketch_queries;   /* top-k queries answered through the 8-bit sketch pre-pass ("sketch" option) */
+    uint64_t sketch_fallbacks; /* ... that it could not settle and handed to the full-precision path */
     uint64_t mq_bf16_sweeps;   /* shared sweeps that ran on the bfloat16 matrix cores (32-bit rows; their candidates
                                   are re-scored in float32 and re-ranked in float64 like every other path's) */
 } szg_stats;
@@ -225,6 +227,17 @@ int szg_reset_stats(szg_index *ix);
  *                             0) compact the row steps that hold a passing row first
  *     shape_kernels       1   row-shape-specialised kernels where they exist (4-bit rows)
  *     serialize_scans     1   sweeps of one shard never overlap each other; contexts 3 = batches in flight
+ *   sketch pre-pass (float32 rows, cosine)
+ *     sketch              0   1 = keep an 8-bit sketch of every row (+25 % memory, built on the device at the
+ *                             first search after a load, kept up to date across appends / overwrites /
+ *                             tombstones) and answer one-query-per-sweep searches by sweeping the sketch
+ *                             (a quarter of the bytes) for k + sketch_extra candidates, re-ranking those on
+ *                             the float32 rows in float64 and certifying with the triangle inequality of the
+ *                             reference's angular distance (k-th distance < candidates' last sketch distance
+ *                             - largest row-to-sketch angle); unsettled queries take the full sweep.  Same
+ *                             answers.  1M x 768: 2.2 k -> 8.0 k queries/s
+ *     sketch_extra        30  candidates beyond k (3k when larger)
+ *     sketch_min_rows     4096  collections below this size always take the full sweep
  *   shared sweeps
  *     multi_query         1   batches of >= mq_min (2) queries share ONE sweep of the corpus, the
  *                             dot products on the matrix cores (4/8/16/32-bit rows, either metric),

@@ -18,7 +18,8 @@ rng = np.random.default_rng(seed)
 OPTS = [("queries_per_launch", [1, 3, 16]), ("multi_query", [0, 1]), ("mq_fused", [0, 1]), ("mq_i8", [0, 1]),
         ("serialize_scans", [0, 1]), ("shape_kernels", [0, 1]), ("blocks_per_cu", [0, 1, 3]),
         ("mq_min", [2, 8]), ("mq_blocks", [1, 2, 3]), ("slack", [0, 16, 40]), ("mq_bf16", [0, 1, 1]),
-        ("mq_overlap", [0, 1]), ("mq_bf16_slack", [0, 118]), ("mq_hits", [64, 1024])]
+        ("mq_overlap", [0, 1]), ("mq_bf16_slack", [0, 118]), ("mq_hits", [64, 1024]), ("sketch", [0, 1, 1]),
+        ("sketch_extra", [0, 30]), ("sketch_min_rows", [1, 1, 4096])]
 
 
 def same(got_r, got_d, want_r, want_d):
@@ -37,7 +38,7 @@ while time.time() < t_end:
     bits = int(rng.choice([4, 8, 16, 32, 64]))
     metric = int(rng.integers(0, 2))
     dim = int(rng.choice([1, 2, 3, 5, 16, 17, 31, 32, 33, 64, 100, 128, 129, 384, 500, 768, 1024]))
-    n = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 200, 1000, 3000, 9000]))
+    n = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 200, 1000, 3000, 5000, 9000]))
     if dim * n > 4_000_000:
         n = max(1, 4_000_000 // dim)
     nq = int(rng.choice([1, 2, 7, 8, 9, 16, 17, 33, 50]))

@@ -57,6 +57,8 @@ class SzgStats(ctypes.Structure):
         ("host_prep_us", ctypes.c_double),
         ("host_finish_us", ctypes.c_double),
         ("host_enqueue_us", ctypes.c_double),
+        ("sketch_queries", ctypes.c_uint64),
+        ("sketch_fallbacks", ctypes.c_uint64),
         ("mq_bf16_sweeps", ctypes.c_uint64),
     ]
 

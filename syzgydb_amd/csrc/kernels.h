@@ -240,6 +240,13 @@ hipError_t launch_rerank_pairs(int qbits, int metric, const uint8_t *rows, RowLa
 
 // Page-in transform: n_rows rows in the reference encoding at `ref` (big-endian 16/32/64-bit,
 // row_bytes apart) <-> rows [first_row, first_row + n_rows) of the resident mirror `rows`.
+// 8-bit sketch of float32 rows for the cosine pre-pass (kernels_exact.hip): rows [first_row, first_row + n_rows) of
+// `src` (or the listed rows), written into `dst` in its resident layout; *max_ang = max over the rows of the angular
+// distance row <-> sketch (bits of a double); rows without a direction or with a non-finite element are reported
+hipError_t launch_sketch_build(const uint8_t *src, RowLayout src_lay, int dim, uint8_t *dst, RowLayout dst_lay,
+                               uint64_t first_row, uint64_t n_rows, const uint32_t *row_list,
+                               unsigned long long *max_ang, uint32_t *exc_rows, uint32_t *exc_count, uint32_t exc_cap,
+                               hipStream_t stream);
 hipError_t launch_repack(int qbits, uint8_t *ref, uint32_t row_bytes, uint8_t *rows, RowLayout layout,
                          uint64_t first_row, uint64_t n_rows, int to_reference, hipStream_t stream);
 

@@ -342,6 +342,90 @@ __global__ void repack_vec_kernel(uint4 *ref, uint8_t *rows, RowLayout lay, uint
         *res = v;
 }
 
+// ---- 8-bit sketch of float32 rows (cosine) --------------------------------------
+// One wave per row.  x_i / max|x| is quantized to the library's own 8-bit element form (byte v, value
+// n = 2v - 255: odd integers; cosine does not see the scale), written in the sketch shard's resident
+// layout.  The angular distance between the row and its sketch -- the reference's own metric,
+// acos(cos)/pi, in float64 -- goes into a running maximum: by the triangle inequality on the sphere
+// |d(q, x) - d(q, sketch)| <= d(x, sketch) for every query.  Rows without a direction (all zero) or with
+// a non-finite element get a dummy sketch and are reported (they are always re-ranked).
+__global__ __launch_bounds__(256) void sketch_build_kernel(const uint8_t *src, RowLayout src_lay, int dim, uint8_t *dst,
+                                                           RowLayout dst_lay, uint64_t first_row, uint64_t n_rows,
+                                                           const uint32_t *row_list, unsigned long long *max_ang,
+                                                           uint32_t *exc_rows, uint32_t *exc_count, uint32_t exc_cap)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t i = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n_rows) return;
+    const uint64_t row = row_list ? (uint64_t)row_list[i] : first_row + i;
+    const int pieces = (dim + 15) / 16;  // 16-element pieces of the sketch row
+    float mx = 0.f;
+    bool bad = false;
+    for (int p = lane; p < pieces; p += 64) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int e0 = p * 16 + t * 4;
+            if (e0 >= dim) break;
+            const float4 v = *reinterpret_cast<const float4 *>(src + piece_offset(src_lay, row, (uint32_t)(p * 4 + t)));
+            const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (e0 + k >= dim) continue;
+                const float ax = fabsf(x[k]);
+                if (!(ax <= 3.4e38f)) bad = true;  // Inf or NaN
+                mx = fmaxf(mx, ax);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    bad = __ballot(bad) != 0 || !(mx > 0.f);
+    const double inv = bad ? 0.0 : 1.0 / (double)mx;
+    double dot = 0.0, nx = 0.0, nn = 0.0;
+    for (int p = lane; p < pieces; p += 64) {
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int e0 = p * 16 + t * 4;
+            if (e0 >= dim) break;
+            const float4 v = *reinterpret_cast<const float4 *>(src + piece_offset(src_lay, row, (uint32_t)(p * 4 + t)));
+            const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (e0 + k >= dim) continue;  // padding bytes stay 0, as the page-in leaves them
+                int q = 128;
+                if (!bad) {
+                    q = (int)rint(((double)x[k] * inv + 1.0) * 127.5);
+                    q = q < 0 ? 0 : (q > 255 ? 255 : q);
+                    const double n = (double)(2 * q - 255), xd = (double)x[k];
+                    dot += xd * n;
+                    nx += xd * xd;
+                    nn += n * n;
+                }
+                w[t] |= (uint32_t)q << (8 * k);
+            }
+        }
+        *reinterpret_cast<uint4 *>(dst + piece_offset(dst_lay, row, (uint32_t)p)) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dot += __shfl_xor(dot, o);
+        nx += __shfl_xor(nx, o);
+        nn += __shfl_xor(nn, o);
+    }
+    if (lane == 0) {
+        if (bad) {
+            const uint32_t at = atomicAdd(exc_count, 1u);
+            if (at < exc_cap) exc_rows[at] = (uint32_t)row;
+        } else {
+            double c = dot / sqrt(nx * nn);
+            c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+            const double ang = acos(c) / 3.14159265358979323846264338327950288;
+            atomicMax(max_ang, (unsigned long long)__double_as_longlong(ang));  // non-negative doubles order as integers
+        }
+    }
+}
+
 __global__ void fill_bits_kernel(uint64_t *bits, uint64_t n_rows, uint64_t n_words)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -415,6 +499,19 @@ hipError_t launch_rerank_pairs(int qbits, int metric, const uint8_t *rows, RowLa
     case 64: return launch_rerank_q<64>(metric, rows, pitch, dim, nullptr, right_cands, nullptr, n_pairs, 1, out, stream, left_rows);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_sketch_build(const uint8_t *src, RowLayout src_lay, int dim, uint8_t *dst, RowLayout dst_lay,
+                               uint64_t first_row, uint64_t n_rows, const uint32_t *row_list,
+                               unsigned long long *max_ang, uint32_t *exc_rows, uint32_t *exc_count, uint32_t exc_cap,
+                               hipStream_t stream)
+{
+    if (n_rows == 0) return hipSuccess;
+    const uint64_t grid = (n_rows + 3) / 4;
+    if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sketch_build_kernel, dim3((unsigned)grid), dim3(256), 0, stream, src, src_lay, dim, dst, dst_lay,
+                       first_row, n_rows, row_list, max_ang, exc_rows, exc_count, exc_cap);
+    return hipGetLastError();
 }
 
 hipError_t launch_repack(int qbits, uint8_t *ref, uint32_t row_bytes, uint8_t *rows, RowLayout lay,
