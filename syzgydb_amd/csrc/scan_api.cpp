@@ -268,6 +268,10 @@ struct Shard {
     uint8_t *stage = nullptr;
     size_t stage_cap = 0;
     std::mutex stage_mu;         // szg_index_read_rows may run beside other readers (szg_pair_distances)
+    // second stage of the sketch pre-pass: queries | candidate lists | distances, kept between calls
+    uint8_t *sk_buf = nullptr;
+    size_t sk_buf_cap = 0;
+    std::mutex sk_buf_mu;
 };
 
 }  // namespace
@@ -301,7 +305,7 @@ struct szg_index {
     int sketch_extra = 30;               // sketch neighbours asked for beyond k (at least; 3k when larger): k = 10 -> 40,
                                          // which keeps the sketch sweep's lists in registers (kp <= 64)
     int sketch_min_rows = 4096;          // smaller collections are not worth a second index
-    std::mutex sk_mu;                    // sync and the second stage's buffers
+    std::mutex sk_mu;                    // the sync
     uint64_t gen = 1, sk_gen = 0;        // mutation counter / the value the sketch was synced at
     bool sk_need_full = true;            // load / synth / reset since the last sync
     bool sk_live_dirty = true;           // tombstones since the last sync
@@ -1986,22 +1990,28 @@ int sketch_exact_distances(szg_index *ix, const double *queries, int nq, const s
         }
         if (width == 0) continue;
         HIPCHK(hipSetDevice(sh->device));
-        double *d_q = nullptr;
-        uint64_t *d_c = nullptr;
-        szg::RerankOut *d_o = nullptr;
+        std::lock_guard<std::mutex> bl(sh->sk_buf_mu);
+        const size_t q_bytes = (sizeof(double) * (size_t)nq * ix->dim + 255) & ~(size_t)255;
+        const size_t c_bytes = (sizeof(uint64_t) * local.size() + 255) & ~(size_t)255;
+        const size_t o_bytes = sizeof(szg::RerankOut) * local.size();
+        if (sh->sk_buf_cap < q_bytes + c_bytes + o_bytes) {
+            if (sh->sk_buf) (void)hipFree(sh->sk_buf);
+            sh->sk_buf = nullptr;
+            sh->sk_buf_cap = 0;
+            const size_t want = (q_bytes + c_bytes + o_bytes) * 2;
+            if (hipMalloc((void **)&sh->sk_buf, want) != hipSuccess) return fail(SZG_E_NOMEM, "hipMalloc(sketch re-rank)");
+            sh->sk_buf_cap = want;
+        }
+        double *d_q = reinterpret_cast<double *>(sh->sk_buf);
+        uint64_t *d_c = reinterpret_cast<uint64_t *>(sh->sk_buf + q_bytes);
+        szg::RerankOut *d_o = reinterpret_cast<szg::RerankOut *>(sh->sk_buf + q_bytes + c_bytes);
         std::vector<szg::RerankOut> h_o((size_t)nq * most);
-        hipError_t e = hipMalloc((void **)&d_q, sizeof(double) * (size_t)nq * ix->dim);
-        if (e == hipSuccess) e = hipMalloc((void **)&d_c, sizeof(uint64_t) * local.size());
-        if (e == hipSuccess) e = hipMalloc((void **)&d_o, sizeof(szg::RerankOut) * local.size());
-        if (e == hipSuccess) e = hipMemcpy(d_q, queries, sizeof(double) * (size_t)nq * ix->dim, hipMemcpyHostToDevice);
+        hipError_t e = hipMemcpy(d_q, queries, sizeof(double) * (size_t)nq * ix->dim, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_c, local.data(), sizeof(uint64_t) * local.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess)
             e = szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, d_q, d_c, nullptr, (uint32_t)most,
                                    nq, d_o, nullptr);
         if (e == hipSuccess) e = hipMemcpy(h_o.data(), d_o, sizeof(szg::RerankOut) * h_o.size(), hipMemcpyDeviceToHost);
-        (void)hipFree(d_q);
-        (void)hipFree(d_c);
-        (void)hipFree(d_o);
         if (e != hipSuccess) return fail(SZG_E_DEVICE, "sketch re-rank", e);
         for (int j = 0; j < nq; j++)
             for (size_t n = 0; n < most; n++) {
@@ -2015,8 +2025,11 @@ int sketch_exact_distances(szg_index *ix, const double *queries, int nq, const s
 int search_topk_sketch(szg_index *ix, const double *queries, int n_queries, int k, const uint64_t *allow_bits,
                        uint64_t *out_rows, double *out_dist, int32_t *out_count, const uint64_t *const *allow_ptrs)
 {
-    std::lock_guard<std::mutex> lk(ix->sk_mu);
-    int rc = sketch_sync(ix);
+    int rc;
+    {   // (mutations come under the caller's write lock: after the sync, searches run side by side)
+        std::lock_guard<std::mutex> lk(ix->sk_mu);
+        rc = sketch_sync(ix);
+    }
     if (rc) return rc;
     if (ix->sk_disabled) return search_topk_impl(ix, queries, n_queries, k, allow_bits, out_rows, out_dist, out_count, allow_ptrs);
     szg_index *sk = ix->sketch;
@@ -2482,6 +2495,7 @@ void szg_index_destroy(szg_index *ix)
         if (sh->scan_stream) (void)hipStreamDestroy(sh->scan_stream);
         (void)hipFree(sh->zero16);
         (void)hipFree(sh->stage);
+        (void)hipFree(sh->sk_buf);
         (void)hipFree(sh->rows);
         (void)hipFree(sh->live_bits);
         delete sh;

@@ -116,3 +116,30 @@ def test_sketch_clustered_rows():
         check(ix, rows, dim, Q, 10)
         st = ix.stats()
         assert st["sketch_queries"] + st["sketch_fallbacks"] == 10
+
+
+def test_sketch_concurrent_lone_queries():
+    """Eight threads, one query per call, no coalescing: pre-pass searches run side by side after the sync."""
+    import threading
+    dim, n, k = 64, 30000, 5
+    rows = orc.synth_rows(740, 0, n, dim, 32)
+    Q = orc.synth_vectors(741, 0, 64, dim)
+    want = [orc.search_exact(rows, dim, 32, SZG_COSINE, Q[i], k=k) for i in range(Q.shape[0])]
+    bad = []
+    with ScanIndex(dim, 32, SZG_COSINE) as ix:
+        ix.load(rows)
+        ix.set_option("sketch", 1)
+        ix.set_option("coalesce", 0)
+
+        def work(t):
+            for i in range(t, Q.shape[0], 8):
+                r, d, c = ix.search_topk(Q[i], k)
+                if [int(x) for x in r[0, : c[0]]] != [int(x) for x in want[i][0]] or not (d[0, : c[0]] == want[i][1]).all():
+                    bad.append(i)
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        st = ix.stats()
+        assert not bad, bad
+        assert st["sketch_queries"] + st["sketch_fallbacks"] == 64
