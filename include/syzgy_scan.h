@@ -227,16 +227,18 @@ int szg_reset_stats(szg_index *ix);
  *                             0) compact the row steps that hold a passing row first
  *     shape_kernels       1   row-shape-specialised kernels where they exist (4-bit rows)
  *     serialize_scans     1   sweeps of one shard never overlap each other; contexts 3 = batches in flight
- *   sketch pre-pass (float32 rows, cosine)
+ *   sketch pre-pass (float32 rows)
  *     sketch              0   1 = keep an 8-bit sketch of every row (+25 % memory, built on the device at the
  *                             first search after a load, kept up to date across appends / overwrites /
  *                             tombstones) and answer one-query-per-sweep searches by sweeping the sketch
  *                             (a quarter of the bytes) for k + sketch_extra candidates, re-ranking those on
  *                             the float32 rows in float64 and certifying with the triangle inequality of the
- *                             reference's angular distance (k-th distance < candidates' last sketch distance
- *                             - largest row-to-sketch angle); unsettled queries take the full sweep.  Same
- *                             answers.  1M x 768: 2.2 k -> 8.0 k queries/s
- *     sketch_extra        30  candidates beyond k (3k when larger)
+ *                             reference's distance -- the angle, or the Euclidean distance with one scale for
+ *                             the collection -- (k-th distance < candidates' last sketch distance - largest
+ *                             row-to-sketch distance); unsettled queries take the full sweep.  Same answers.
+ *                             1M x 768 cosine k=10: 2.2 k -> 8.0 k queries/s
+ *     sketch_extra        30  candidates beyond k; the pre-pass serves k + sketch_extra <= 64 (longer candidate
+ *                             lists make the sketch sweep slower than the sweep it replaces)
  *     sketch_min_rows     4096  collections below this size always take the full sweep
  *   shared sweeps
  *     multi_query         1   batches of >= mq_min (2) queries share ONE sweep of the corpus, the

@@ -6,12 +6,14 @@ from syzgydb_amd.synth import synth_vectors
 n, dim, k = int(os.environ.get('SZG_ROWS', '1000000')), int(os.environ.get('SZG_DIM', '768')), 10
 nq = int(os.environ.get('SZG_NQ', '1024'))
 q = synth_vectors(99, 0, nq, dim)
-with ScanIndex(dim, 32, 1, devices=[0]) as ix:
+metric = int(os.environ.get('SZG_METRIC', '1'))
+k = int(os.environ.get('SZG_K', '10'))
+with ScanIndex(dim, 32, metric, devices=[0]) as ix:
     ix.synth(n, 1234)
     for o, val in [x.split('=') for x in os.environ.get('SZG_OPTS', '').split(',') if x]:
         ix.set_option(o, int(val))
     base = None
-    for sketch, multi, extra in ((0, 0, 54), (1, 0, 54), (1, 0, 30), (1, 0, 20), (1, 0, 10)):
+    for sketch, multi, extra in ((0, 0, 30), (1, 0, 30)):
         if True:
             ix.set_option("sketch", sketch); ix.set_option("multi_query", multi); ix.set_option("sketch_extra", extra)
             ix.search_topk(q[:128], k)

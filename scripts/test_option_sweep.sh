@@ -16,7 +16,8 @@ run() {  # $1 = label, rest = pytest arguments
 # (tie_mode=1 changes the contract -- any valid top-k among equal distances -- and has its own test,
 # tests/test_gpu_parity.py::test_tie_mode_1_returns_a_valid_topk.)
 # SWEEP_SETS="a=1 b=2,c=3" restricts the first loop to those sets (re-checking a fix)
-for opts in ${SWEEP_SETS:-serialize_scans=0 queries_per_launch=1 queries_per_launch=3,blocks_per_cu=1 shape_kernels=0,block_threads=128 \
+# SWEEP_SKIP_MAIN=1 skips this loop (a box allows 20 minutes per call: the two loops can go in two calls)
+[ -n "$SWEEP_SKIP_MAIN" ] || for opts in ${SWEEP_SETS:-serialize_scans=0 queries_per_launch=1 queries_per_launch=3,blocks_per_cu=1 shape_kernels=0,block_threads=128 \
             mq_fused=0,mq_i8=0 mq_tail_overlap=1,mq_blocks=2 multi_query=0,query_batch=5 contexts=1,blocks_per_cu=6 mask_dense=0,coalesce=0 \
             mq_min=8,tie_mode=0 ring=8,mq_hits=256 mq_bf16=0 mq_overlap=0,mq_bf16_slack=0 sketch=1,sketch_min_rows=1 sketch=1,multi_query=0,sketch_extra=0,sketch_min_rows=1}; do
   run "$opts" tests -m gpu -q -x --ignore=tests/test_gpu_fullsize.py --ignore=tests/test_gpu_bench_launch.py \

@@ -246,7 +246,9 @@ hipError_t launch_rerank_pairs(int qbits, int metric, const uint8_t *rows, RowLa
 hipError_t launch_sketch_build(const uint8_t *src, RowLayout src_lay, int dim, uint8_t *dst, RowLayout dst_lay,
                                uint64_t first_row, uint64_t n_rows, const uint32_t *row_list,
                                unsigned long long *max_ang, uint32_t *exc_rows, uint32_t *exc_count, uint32_t exc_cap,
-                               hipStream_t stream);
+                               double gscale, int max_only, hipStream_t stream);
+// (gscale > 0: Euclidean form -- one scale for the whole collection, *max_ang = largest Euclidean distance row <->
+//  sketch; max_only: report the largest finite |x_i| of the rows as float bits instead of building anything)
 hipError_t launch_repack(int qbits, uint8_t *ref, uint32_t row_bytes, uint8_t *rows, RowLayout layout,
                          uint64_t first_row, uint64_t n_rows, int to_reference, hipStream_t stream);
 

@@ -349,10 +349,15 @@ __global__ void repack_vec_kernel(uint4 *ref, uint8_t *rows, RowLayout lay, uint
 // acos(cos)/pi, in float64 -- goes into a running maximum: by the triangle inequality on the sphere
 // |d(q, x) - d(q, sketch)| <= d(x, sketch) for every query.  Rows without a direction (all zero) or with
 // a non-finite element get a dummy sketch and are reported (they are always re-ranked).
+// gscale > 0 (Euclidean collections): every row is scaled by the same 1 / gscale (gscale >= max |x_i| over the
+// collection), the sketch stands for gscale * n / 255, and the running maximum is the Euclidean distance
+// row <-> sketch; gscale == 0 (cosine): per-row scale, angular distance.  With max_only the kernel just
+// reports the largest finite |x_i| of the rows (bits of a float) through max_ang and writes nothing.
 __global__ __launch_bounds__(256) void sketch_build_kernel(const uint8_t *src, RowLayout src_lay, int dim, uint8_t *dst,
                                                            RowLayout dst_lay, uint64_t first_row, uint64_t n_rows,
                                                            const uint32_t *row_list, unsigned long long *max_ang,
-                                                           uint32_t *exc_rows, uint32_t *exc_count, uint32_t exc_cap)
+                                                           uint32_t *exc_rows, uint32_t *exc_count, uint32_t exc_cap,
+                                                           double gscale, int max_only)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t i = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -379,8 +384,17 @@ __global__ __launch_bounds__(256) void sketch_build_kernel(const uint8_t *src, R
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    bad = __ballot(bad) != 0 || !(mx > 0.f);
-    const double inv = bad ? 0.0 : 1.0 / (double)mx;
+    bad = __ballot(bad) != 0;
+    if (max_only) {
+        if (lane == 0 && !bad) atomicMax(max_ang, (unsigned long long)__float_as_uint(mx));
+        return;
+    }
+    if (gscale > 0.0) {
+        if ((double)mx > gscale) bad = true;  // (cannot happen after a max pass; such a row would be re-ranked always)
+    } else {
+        bad = bad || !(mx > 0.f);
+    }
+    const double inv = bad ? 0.0 : 1.0 / (gscale > 0.0 ? gscale : (double)mx);
     double dot = 0.0, nx = 0.0, nn = 0.0;
     for (int p = lane; p < pieces; p += 64) {
         uint32_t w[4] = {0u, 0u, 0u, 0u};
@@ -398,9 +412,14 @@ __global__ __launch_bounds__(256) void sketch_build_kernel(const uint8_t *src, R
                     q = (int)rint(((double)x[k] * inv + 1.0) * 127.5);
                     q = q < 0 ? 0 : (q > 255 ? 255 : q);
                     const double n = (double)(2 * q - 255), xd = (double)x[k];
-                    dot += xd * n;
-                    nx += xd * xd;
-                    nn += n * n;
+                    if (gscale > 0.0) {
+                        const double df = xd - gscale * n / 255.0;
+                        dot += df * df;
+                    } else {
+                        dot += xd * n;
+                        nx += xd * xd;
+                        nn += n * n;
+                    }
                 }
                 w[t] |= (uint32_t)q << (8 * k);
             }
@@ -417,6 +436,8 @@ __global__ __launch_bounds__(256) void sketch_build_kernel(const uint8_t *src, R
         if (bad) {
             const uint32_t at = atomicAdd(exc_count, 1u);
             if (at < exc_cap) exc_rows[at] = (uint32_t)row;
+        } else if (gscale > 0.0) {
+            atomicMax(max_ang, (unsigned long long)__double_as_longlong(sqrt(dot)));
         } else {
             double c = dot / sqrt(nx * nn);
             c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
@@ -504,13 +525,13 @@ hipError_t launch_rerank_pairs(int qbits, int metric, const uint8_t *rows, RowLa
 hipError_t launch_sketch_build(const uint8_t *src, RowLayout src_lay, int dim, uint8_t *dst, RowLayout dst_lay,
                                uint64_t first_row, uint64_t n_rows, const uint32_t *row_list,
                                unsigned long long *max_ang, uint32_t *exc_rows, uint32_t *exc_count, uint32_t exc_cap,
-                               hipStream_t stream)
+                               double gscale, int max_only, hipStream_t stream)
 {
     if (n_rows == 0) return hipSuccess;
     const uint64_t grid = (n_rows + 3) / 4;
     if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sketch_build_kernel, dim3((unsigned)grid), dim3(256), 0, stream, src, src_lay, dim, dst, dst_lay,
-                       first_row, n_rows, row_list, max_ang, exc_rows, exc_count, exc_cap);
+                       first_row, n_rows, row_list, max_ang, exc_rows, exc_count, exc_cap, gscale, max_only);
     return hipGetLastError();
 }
 

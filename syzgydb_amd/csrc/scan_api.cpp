@@ -302,8 +302,8 @@ struct szg_index {
     // 8-bit sketch pre-pass for float32 cosine collections ("sketch" option, sketch_sync / search_topk_sketch)
     szg_index *sketch = nullptr;         // an internal 8-bit cosine index over the same rows, same shard ranges
     int sketch_on = 0;
-    int sketch_extra = 30;               // sketch neighbours asked for beyond k (at least; 3k when larger): k = 10 -> 40,
-                                         // which keeps the sketch sweep's lists in registers (kp <= 64)
+    int sketch_extra = 30;               // sketch neighbours asked for beyond k: k = 10 -> 40, which keeps the sketch
+                                         // sweep's lists in registers (kp <= 64); the pre-pass serves k <= 34
     int sketch_min_rows = 4096;          // smaller collections are not worth a second index
     std::mutex sk_mu;                    // the sync
     uint64_t gen = 1, sk_gen = 0;        // mutation counter / the value the sketch was synced at
@@ -311,6 +311,7 @@ struct szg_index {
     bool sk_live_dirty = true;           // tombstones since the last sync
     std::vector<uint64_t> sk_dirty_rows; // rows overwritten since the last sync (index-level)
     double sk_max_ang = 0.0;             // max over the rows of d(row, its sketch), the reference's angular distance
+    double sk_gscale = 0.0;              // Euclidean collections: the sketch of a row is sk_gscale * n / 255 (0: cosine)
     std::vector<uint64_t> sk_exc;        // rows without a usable sketch (zero rows, non-finite elements): always re-ranked
     bool sk_disabled = false;            // too many such rows
     std::vector<std::pair<std::string, int64_t>> opt_log;  // tunables set so far (replayed on the sketch index)
@@ -1841,11 +1842,13 @@ int shard_set_live(Shard *sh, uint64_t lo, uint64_t hi);
 
 bool sketch_applies(const szg_index *ix, int k)
 {
-    if (!ix->sketch_on || ix->sk_disabled || ix->bits != 32 || ix->metric != SZG_COSINE) return false;
+    if (!ix->sketch_on || ix->sk_disabled || ix->bits != 32) return false;
     uint64_t n = 0;
     for (const Shard *sh : ix->shards) n += sh->n_rows;
-    const int kk = k + std::max(ix->sketch_extra, 3 * k);
-    return n >= (uint64_t)ix->sketch_min_rows && kk <= 1024;
+    // the sketch sweep must keep its lists short: 8-bit rows pass four times as fast as float32 rows, and with
+    // LDS-resident lists of hundreds (k = 100: 1.35 ms per sweep) the pre-pass is slower than the sweep it replaces
+    const int kk = k + ix->sketch_extra;
+    return n >= (uint64_t)ix->sketch_min_rows && kk + std::max(ix->slack_min, kk / 2) <= 96;
 }
 
 // bring the sketch index up to date with the rows (callers hold ix->sk_mu)
@@ -1855,7 +1858,7 @@ int sketch_sync(szg_index *ix)
     if (!ix->sketch) {
         std::vector<int> devs;
         for (Shard *sh : ix->shards) devs.push_back(sh->device);
-        int rc = szg_index_create(&ix->sketch, ix->dim, 8, SZG_COSINE, devs.data(), (int)devs.size());
+        int rc = szg_index_create(&ix->sketch, ix->dim, 8, ix->metric, devs.data(), (int)devs.size());
         if (rc) return rc;
         ix->sk_need_full = true;
         ix->sketch->timing = ix->timing;
@@ -1869,6 +1872,38 @@ int sketch_sync(szg_index *ix)
         if (b->n_rows > a->n_rows || (b->n_rows && b->first != a->first)) full = true;
     }
     if (ix->sk_dirty_rows.size() > 4096) full = true;
+    const bool euclid = ix->metric != SZG_COSINE;
+    // Euclidean collections share ONE scale (the largest |x_i|): rows beyond it force a rebuild
+    auto max_abs = [&](bool only_new, double *out) -> int {
+        double g = 0.0;
+        for (size_t s = 0; s < n_sh; s++) {
+            Shard *a = ix->shards[s], *b = sk->shards[s];
+            const uint64_t have = only_new ? b->n_rows : 0;
+            if (a->n_rows <= have) continue;
+            HIPCHK(hipSetDevice(a->device));
+            unsigned long long *d_max = nullptr, bits = 0;
+            HIPCHK(hipMalloc((void **)&d_max, 16));
+            hipError_t e = hipMemset(d_max, 0, 16);
+            if (e == hipSuccess)
+                e = szg::launch_sketch_build(a->rows, ix->layout, ix->dim, nullptr, sk->layout, have, a->n_rows - have,
+                                             nullptr, d_max, nullptr, nullptr, 0, 0.0, 1, nullptr);
+            if (e == hipSuccess) e = hipMemcpy(&bits, d_max, sizeof(bits), hipMemcpyDeviceToHost);
+            (void)hipFree(d_max);
+            if (e != hipSuccess) return fail(SZG_E_DEVICE, "sketch scale pass", e);
+            const uint32_t fb = (uint32_t)bits;
+            float f;
+            memcpy(&f, &fb, 4);
+            g = std::max(g, (double)f);
+        }
+        *out = g;
+        return SZG_OK;
+    };
+    if (euclid && !full) {
+        double g = 0.0;
+        int rc = max_abs(true, &g);
+        if (rc) return rc;
+        if (g > ix->sk_gscale) full = true;
+    }
     if (full) {
         std::vector<uint64_t> counts;
         for (Shard *sh : ix->shards) counts.push_back(sh->n_rows);
@@ -1878,6 +1913,13 @@ int sketch_sync(szg_index *ix)
         ix->sk_exc.clear();
         ix->sk_dirty_rows.clear();
         ix->sk_live_dirty = true;
+        ix->sk_gscale = 0.0;
+        if (euclid) {
+            double g = 0.0;
+            rc = max_abs(false, &g);
+            if (rc) return rc;
+            ix->sk_gscale = g > 0.0 ? g : 1.0;
+        }
     }
     const uint32_t exc_cap = 4096;
     for (size_t s = 0; s < n_sh; s++) {
@@ -1902,13 +1944,13 @@ int sketch_sync(szg_index *ix)
         hipError_t e = hipSuccess;
         if (a->n_rows > have)
             e = szg::launch_sketch_build(a->rows, ix->layout, ix->dim, b->rows, sk->layout, have, a->n_rows - have, nullptr,
-                                         d_ang, d_exc + 1, d_exc, exc_cap, nullptr);
+                                         d_ang, d_exc + 1, d_exc, exc_cap, ix->sk_gscale, 0, nullptr);
         if (e == hipSuccess && !list.empty()) {
             e = hipMalloc((void **)&d_list, list.size() * sizeof(uint32_t));
             if (e == hipSuccess) e = hipMemcpy(d_list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
             if (e == hipSuccess)
                 e = szg::launch_sketch_build(a->rows, ix->layout, ix->dim, b->rows, sk->layout, 0, list.size(), d_list,
-                                             d_ang, d_exc + 1, d_exc, exc_cap, nullptr);
+                                             d_ang, d_exc + 1, d_exc, exc_cap, ix->sk_gscale, 0, nullptr);
         }
         unsigned long long ang_bits = 0;
         std::vector<uint32_t> exc(exc_cap + 1, 0);
@@ -2049,8 +2091,10 @@ int search_topk_sketch(szg_index *ix, const double *queries, int n_queries, int 
             }
         return false;
     };
-    const int kk = k + std::max(ix->sketch_extra, 3 * k);
-    const double slack = ix->sk_max_ang * (1.0 + 1e-9) + 1e-7;  // (+ the rounding of the computed angles, which near 0 is ~1e-9)
+    const int kk = k + ix->sketch_extra;
+    const double gs = ix->sk_gscale;  // Euclidean: sketch distances are in units of gs (the sketch index sees q / gs)
+    const double slack = ix->sk_max_ang * (1.0 + 1e-9) + (gs > 0.0 ? 0.0 : 1e-7);  // (+ the rounding of the computed angles, ~1e-9 near 0)
+    std::vector<double> q_scaled;
     std::vector<int> redo;  // queries that go to the float32 path
     const int chunk = 512;
     std::vector<uint64_t> s_rows((size_t)chunk * kk);
@@ -2065,7 +2109,13 @@ int search_topk_sketch(szg_index *ix, const double *queries, int n_queries, int 
             masks[j] = mask_of(q0 + j);
             any_mask |= masks[j] != nullptr;
         }
-        rc = search_topk_impl(sk, q, nq, kk, nullptr, s_rows.data(), s_dist.data(), s_count.data(),
+        const double *q_sk = q;
+        if (gs > 0.0) {
+            q_scaled.resize((size_t)nq * ix->dim);
+            for (size_t i = 0; i < q_scaled.size(); i++) q_scaled[i] = q[i] / gs;
+            q_sk = q_scaled.data();
+        }
+        rc = search_topk_impl(sk, q_sk, nq, kk, nullptr, s_rows.data(), s_dist.data(), s_count.data(),
                               any_mask ? masks.data() : nullptr);
         if (rc) return rc;
         // candidates: the sketch neighbours, the query's first k eligible rows, the rows without a sketch
@@ -2102,8 +2152,9 @@ int search_topk_sketch(szg_index *ix, const double *queries, int n_queries, int 
             replay_topk(cs, k, &res);
             bool ok = !nan_first || ix->tie_mode != 0;
             if (ok && s_count[j] == kk) {  // rows exist that were not re-ranked: d(q, row) >= D - A for all of them
-                const double D = s_dist[(size_t)j * kk + kk - 1];
-                ok = (int)res.size() == k && res.back().priority < D - slack;
+                double D = s_dist[(size_t)j * kk + kk - 1];
+                if (gs > 0.0) D = D * gs * (1.0 - 1e-9);
+                ok = (int)res.size() == k && res.back().priority * (1.0 + 1e-9) < D - slack;
             }
             if (ok && ix->tie_mode == 0) {
                 std::vector<double> d(cs.size());

@@ -6,13 +6,13 @@ import numpy as np
 import pytest
 
 import oracle as orc
-from syzgydb_amd import ScanIndex, SZG_COSINE
+from syzgydb_amd import ScanIndex, SZG_COSINE, SZG_EUCLIDEAN
 
 pytestmark = pytest.mark.gpu
 DEFAULT_TUNABLES = not os.environ.get("SZG_OPTIONS")
 
 
-def check(ix, rows, dim, Q, k, allow=None, live=None):
+def check(ix, rows, dim, Q, k, allow=None, live=None, metric=SZG_COSINE):
     kw = {}
     if allow is not None:
         kw["allow"] = np.tile(allow, (Q.shape[0], 1))
@@ -26,14 +26,14 @@ def check(ix, rows, dim, Q, k, allow=None, live=None):
             m &= live
         m = m.astype(np.uint8)
     for qi in range(Q.shape[0]):
-        o_rows, o_dist, _ = orc.search_exact(rows, dim, 32, SZG_COSINE, Q[qi], k=k, allow=m)
+        o_rows, o_dist, _ = orc.search_exact(rows, dim, 32, metric, Q[qi], k=k, allow=m)
         assert c[qi] == len(o_rows)
         assert [int(x) for x in r[qi, : c[qi]]] == [int(x) for x in o_rows], qi
         got, want = d[qi, : c[qi]], o_dist
         assert ((got == want) | (np.isnan(got) & np.isnan(want))).all(), qi
 
 
-@pytest.mark.parametrize("dim,n,k", [(128, 30000, 10), (768, 8000, 10), (100, 20000, 3), (48, 40000, 50)])
+@pytest.mark.parametrize("dim,n,k", [(128, 30000, 10), (768, 8000, 10), (100, 20000, 3), (48, 40000, 30)])
 @pytest.mark.parametrize("multi", [0, 1])
 def test_sketch_prepass_matches_oracle(dim, n, k, multi):
     rows = orc.synth_rows(700 + dim, 0, n, dim, 32)
@@ -143,3 +143,31 @@ def test_sketch_concurrent_lone_queries():
         st = ix.stats()
         assert not bad, bad
         assert st["sketch_queries"] + st["sketch_fallbacks"] == 64
+
+
+@pytest.mark.parametrize("dim,n,k", [(128, 30000, 10), (768, 8000, 25), (100, 20000, 3)])
+def test_sketch_prepass_euclidean(dim, n, k):
+    """Euclidean collections: one scale for the whole collection (the largest |x_i|), the bound is the largest
+    Euclidean distance row <-> sketch; a later row beyond the scale forces a rebuild."""
+    rng = np.random.default_rng(50 + dim)
+    V = rng.uniform(-1, 1, (n + 500, dim)) * 3.0 + 0.5
+    rows = orc.encode_rows(V, 32)
+    Q = rng.uniform(-1, 1, (16, dim)) * 3.0 + 0.5
+    with ScanIndex(dim, 32, SZG_EUCLIDEAN) as ix:
+        ix.load(rows[:n])
+        ix.set_option("sketch", 1)
+        ix.set_option("multi_query", 0)
+        check(ix, rows[:n], dim, Q, k, metric=SZG_EUCLIDEAN)
+        st = ix.stats()
+        assert st["sketch_queries"] + st["sketch_fallbacks"] == 16
+        if DEFAULT_TUNABLES:
+            assert st["sketch_queries"] >= 12
+        V[n + 7] *= 40.0                                 # beyond the collection's scale: rebuild with the new one
+        V[n + 9, 2] = np.inf
+        rows = orc.encode_rows(V, 32)
+        ix.append(rows[n:])
+        check(ix, rows, dim, Q, k, metric=SZG_EUCLIDEAN)
+        ix.tombstone(n + 7)
+        live = np.ones(n + 500, bool)
+        live[n + 7] = False
+        check(ix, rows, dim, Q, k, live=live, metric=SZG_EUCLIDEAN)
