@@ -97,7 +97,8 @@ def test_sketch_follows_mutations_masks_and_odd_rows():
         check(ix, rows, dim, Q, 10, live=live)
         check(ix, rows, dim, Q, 10, allow=allow, live=live)
         st = ix.stats()
-        assert st["sketch_queries"] > 0 and st["sketch_fallbacks"] > 0
+        if DEFAULT_TUNABLES:
+            assert st["sketch_queries"] > 0 and st["sketch_fallbacks"] > 0
 
 
 def test_sketch_clustered_rows():
