@@ -25,3 +25,11 @@ with ScanIndex(dim, 32, metric, devices=[0]) as ix:
             print("sketch=%d multi=%d extra=%d: %.0f QPS  scan %.3f ms/launch x %d  bytes/query %.0f MB  sketch_q %d fb %d esc %d  same %s" % (
                 sketch, multi, extra, nq / wall, s["scan_ms"] / max(s["timed_launches"], 1), s["timed_launches"],
                 s["scan_bytes"] / nq / 1e6, s["sketch_queries"], s["sketch_fallbacks"], s["escalations"], same), flush=True)
+    # lone queries, one call each, one after the other (a single goroutine calling Search)
+    for sketch in (0, 1):
+        ix.set_option("sketch", sketch); ix.set_option("multi_query", 1); ix.set_timing(False)
+        for i in range(20): ix.search_topk(q[i], k)
+        t0 = time.perf_counter()
+        for i in range(200): ix.search_topk(q[i], k)
+        el = time.perf_counter() - t0
+        print("sketch=%d lone queries: %.3f ms per call (%.0f calls/s)" % (sketch, el / 200 * 1e3, 200 / el), flush=True)
