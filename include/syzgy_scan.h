@@ -258,6 +258,8 @@ int szg_reset_stats(szg_index *ix);
  *                             context's stream beside the neighbouring batches' sweeps (+13 % queries/s)
  *     mq_bf16_slack       118 candidates kept beyond k where the lists hold bfloat16 keys themselves
  *                             (score-matrix form: small shards, overflow reruns)
+ *     mq_i8_groups        2   int8 sweeps: one launch walks the passes of up to two groups of 48 queries
+ *                             (both LDS images staged up front); 1 = one group per launch
  *     mq_fused            1   threshold-collect selection instead of a score matrix
  *     mq_hits             1024 candidates per query the threshold from the prefix pass aims at
  *     mq_tail_overlap     0   1 = a batch's selection / rerank / copy-back run beside the next

@@ -30,7 +30,7 @@ run() {  # $1 = label, rest = pytest arguments
       --deselect tests/test_gpu_collection.py::test_concurrent_single_queries_are_coalesced
 done
 # shared-sweep variants on the shared-sweep tests (their statistics do not depend on these)
-for opts in ${SWEEP_MQ_SETS-mq_fused=0 mq_i8=0 mq_tail_overlap=1 mq_fused=0,mq_tail_overlap=1,serialize_scans=0 mq_bf16=0 mq_overlap=0 mq_fused=0,mq_bf16_slack=0}; do
+for opts in ${SWEEP_MQ_SETS-mq_fused=0 mq_i8=0 mq_tail_overlap=1 mq_fused=0,mq_tail_overlap=1,serialize_scans=0 mq_bf16=0 mq_overlap=0 mq_fused=0,mq_bf16_slack=0 mq_i8_groups=1}; do
   run "multiquery tests, $opts" tests/test_gpu_multiquery.py -q -x \
       --deselect tests/test_gpu_multiquery.py::test_fused_selection_overflow_falls_back
 done

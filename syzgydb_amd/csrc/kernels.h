@@ -167,6 +167,8 @@ struct MqArgs {
     // fused selection (collect != 0): instead of writing the score matrix, every (query,
     // row) whose key is <= thr[query] and whose mask bits allow it is appended to the
     // query's candidate buffer; thr comes from a sweep of a prefix of the rows
+    int n_groups;                // int8 sweep: query groups of 48 one launch walks (0 / 1: one); image g at
+    uint32_t group_stride;       // queries + g * group_stride bytes, thr / keys / candidates indexed by 48 g + q
     int collect;
     const float *thr;            // [n_queries]
     uint64_t *cand_buf;          // [n_queries][cand_cap]  (ordered key << 32 | row)
@@ -200,7 +202,7 @@ hipError_t launch_cand_rescore(int metric, const uint8_t *rows, uint32_t pitch, 
 // is [step][plane][even, odd elements][query block][lane][16 bytes] and the table's qconst
 // entries hold -15 * sum Q (n = 2x - 15).
 size_t mq_i8_image_bytes(int row_bits, int r16, int nb);   // digit image only
-size_t mq_i8_lds_bytes(int row_bits, int r16, int nb);     // image + constants table + hit buffers
+size_t mq_i8_lds_bytes(int row_bits, int r16, int nb, int groups = 1);  // groups x (image + constants + thresholds) + hit buffers
 hipError_t launch_mq_score_i8(int row_bits, const MqArgs &a, int nb, int grid, hipStream_t stream);
 // bfloat16 shared sweep for 32-bit rows of whole 64-byte steps (v_mfma_f32_16x16x32_bf16): MqArgs.queries is the
 // image [32-element step][query block][lane = k-group*16 + query][8 bf16 = elements 8*k-group + 0..7 of the step]

@@ -174,7 +174,7 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
 // common case instead of one ballot and branch per slot.
 template <int NB>
 __device__ __forceinline__ void offer_tile_hits(const MqArgs &a, HitBuf &hb, int lane, int c, uint32_t hm,
-                                                const float (&keys)[NB][4], uint64_t row)
+                                                const float (&keys)[NB][4], uint64_t row, int qoff = 0)
 {
     if (!__ballot(hm != 0)) return;
     const uint32_t un = wave_or_u32(hm);
@@ -183,7 +183,7 @@ __device__ __forceinline__ void offer_tile_hits(const MqArgs &a, HitBuf &hb, int
 #pragma unroll
         for (int r = 0; r < 4; r++)
             if (un & (1u << (b * 4 + r)))
-                hit_offer(a, hb, lane, (hm >> (b * 4 + r)) & 1u, b * 16 + c * 4 + r, row, keys[b][r]);
+                hit_offer(a, hb, lane, (hm >> (b * 4 + r)) & 1u, qoff + b * 16 + c * 4 + r, row, keys[b][r]);
 }
 
 #if SZG_MQ_PART >= 4
@@ -775,22 +775,33 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
     const RowLayout mlay{a.pitch, a.tiled, a.steps};
     const uint32_t istep = a.tiled ? 1024u : 64u;  // bytes from one 64-byte step of a row to the next
     const int n16 = steps * NPL * T * NB * 64;  // image, 16-byte words
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
-        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+    // One launch walks the passes of up to two query groups (48 queries each) back to back, as the
+    // single-query scan walks its sweeps: a 0.13 ms pass at 1M rows otherwise pays its start-up and its
+    // tail (9 %) once per launch.  Both groups' images are staged in LDS up front (2 x 73 KiB at 768
+    // dims), so a wave that finishes its share of the first pass goes straight on to the second.
+    const int n_groups = a.n_groups > 0 ? a.n_groups : 1;
+    const size_t grp_lds = (size_t)n16 * 16 + 4 * 48 * sizeof(float);  // image | qscale, qconst, qnorm2 | thresholds
+    for (int g = 0; g < n_groups; g++) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.queries) +
+                                                           (size_t)g * a.group_stride);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem + (size_t)g * grp_lds);
         const int n = n16 + (3 * 48 * 4) / 16;  // + constants table
         for (int i = tid; i < n; i += blockDim.x) dst[i] = src[i];
         if (COLLECT && tid < 48)
-            reinterpret_cast<float *>(smem + (size_t)n * 16)[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
+            reinterpret_cast<float *>(smem + (size_t)g * grp_lds + (size_t)n * 16)[tid] =
+                g * 48 + tid < a.n_queries ? a.thr[g * 48 + tid] : -3.0e38f;
     }
+    for (int grp = 0; grp < n_groups; grp++) {
+    const int qoff = grp * 48;  // first query of the group
+    const uint8_t *gbase = smem + (size_t)grp * grp_lds;
     // (the barrier that publishes the image comes after the ring's first loads have been issued:
     // the rows do not depend on it, and a 140 us sweep notices a 5 us start-up)
-    const v4i32 *qimg = reinterpret_cast<const v4i32 *>(smem);
-    const float *qtab = reinterpret_cast<const float *>(smem + (size_t)n16 * 16);
+    const v4i32 *qimg = reinterpret_cast<const v4i32 *>(gbase);
+    const float *qtab = reinterpret_cast<const float *>(gbase + (size_t)n16 * 16);
     const float *thr_lds = qtab + 3 * 48;
     HitBuf hb;
     {
-        uint8_t *base = smem + (size_t)n16 * 16 + 4 * 48 * sizeof(float);
+        uint8_t *base = smem + (size_t)n_groups * grp_lds;
         hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
         hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
         hb.n = 0;
@@ -951,12 +962,12 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
                     keys[b][r] = key;
                     if (COLLECT)
                         hm |= (row_ok && key <= thv[r]) ? (1u << (b * 4 + r)) : 0u;  // unused queries: thr = -3e38
-                    else if (q < a.n_queries)
-                        a.keys[(size_t)q * a.key_stride + row] = key;
+                    else if (qoff + q < a.n_queries)
+                        a.keys[(size_t)(qoff + q) * a.key_stride + row] = key;
                 }
             }
             if (SZG_ABL & 8) { asm volatile("" :: "v"(hm), "v"(keys[0][0])); }  // timing experiment: keys formed, hits dropped
-            else if (COLLECT) offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row);
+            else if (COLLECT) offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row, qoff);
         }
         if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores (see mq_score_kernel)
 #pragma unroll
@@ -975,7 +986,7 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
             ISSUE(u)                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                           \
         }                                                                                \
-        __syncthreads(); /* the query image is complete */                               \
+        if (grp == 0) __syncthreads(); /* the query images are complete */               \
         if (PF) {                                                                        \
             _Pragma("unroll") for (int p = 0; p < NPL; p++)                              \
                 _Pragma("unroll") for (int t = 0; t < T; t++)                            \
@@ -1010,13 +1021,14 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
         MQ8_RUN_RING(MQ8F_ISSUE, MQ8F_CONSUME)
     else
         MQ8_RUN_RING(MQ8_ISSUE, MQ8_CONSUME)
+    if (COLLECT) hit_flush(a, hb, lane);
+    }  // groups
 #undef MQ8F_ISSUE
 #undef MQ8F_CONSUME
 #undef MQ8_CONSUME_X
 #undef MQ8_RUN_RING
 #undef MQ8_ISSUE
 #undef MQ8_CONSUME
-    if (COLLECT) hit_flush(a, hb, lane);
 }
 
 #endif  // SZG_MQ_PART == 1 || 2
@@ -1285,9 +1297,9 @@ size_t mq_i8_image_bytes(int row_bits, int r16, int nb)
 {
     return (size_t)((r16 + 3) / 4) * kMqPlanes * (row_bits == 4 ? 2 : 1) * nb * 1024;
 }
-size_t mq_i8_lds_bytes(int row_bits, int r16, int nb)
-{   // + constants, thresholds, the 12 waves' hit buffers
-    return mq_i8_image_bytes(row_bits, r16, nb) + 4 * 48 * sizeof(float) + (size_t)SZG_MQ8_WAVES * 64 * 9;
+size_t mq_i8_lds_bytes(int row_bits, int r16, int nb, int groups)
+{   // per group: image + constants + thresholds; + the 12 waves' hit buffers
+    return (size_t)groups * (mq_i8_image_bytes(row_bits, r16, nb) + 4 * 48 * sizeof(float)) + (size_t)SZG_MQ8_WAVES * 64 * 9;
 }
 size_t mq_bf16_image_bytes(int r16, int nb) { return (size_t)((r16 / 4 + 1) / 2) * nb * 1024; }
 size_t mq_bf16_lds_bytes(int r16, int nb)
@@ -1304,7 +1316,7 @@ hipError_t launch_mq_score_i8_rows8(const MqArgs &a, int nb, int grid, size_t ld
 hipError_t launch_mq_score_i8_rows4(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
 hipError_t launch_mq_score_i8(int row_bits, const MqArgs &a, int nb, int grid, hipStream_t stream)
 {
-    const size_t lds = mq_i8_lds_bytes(row_bits, a.r16, nb);
+    const size_t lds = mq_i8_lds_bytes(row_bits, a.r16, nb, a.n_groups > 0 ? a.n_groups : 1);
     if (row_bits == 8) return launch_mq_score_i8_rows8(a, nb, grid, lds, stream);
     if (row_bits == 4) return launch_mq_score_i8_rows4(a, nb, grid, lds, stream);
     return hipErrorInvalidValue;

@@ -333,6 +333,7 @@ struct szg_index {
     int coalesce = 1;         // concurrent single-query calls share sweeps (see Combiner)
     int mq_fused = 1;         // shared sweep: threshold-collect selection instead of a score matrix
     int mq_i8 = 1;            // 8-bit rows: exact integer shared sweep (v_mfma_i32_16x16x64_i8)
+    int mq_i8_groups = 2;     // int8 sweeps: query groups of 48 one launch walks (1 or 2)
     int mq_bf16 = 1;          // 32-bit rows: shared sweep on bfloat16 roundings (v_mfma_f32_16x16x32_bf16), certified
                               // against its own bound and re-ranked in float64 like every other path
     int mq_overlap = 1;       // bfloat16 sweeps: a batch's threshold pass and its post-processing run on the context's
@@ -962,8 +963,11 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
     const int r16 = ix->map.r16;
     const bool i8 = mq_uses_i8(ix);
     const bool bf16 = mq_uses_bf16(ix);
+    // int8 sweeps: up to two groups of 16 * nb queries per launch (the kernel walks their passes back to back)
+    const int groups = i8 ? (nq + 16 * nb - 1) / (16 * nb) : 1;
+    const size_t group_stride = i8 ? ((szg::mq_i8_lds_bytes(ix->bits, r16, nb) + 255) & ~(size_t)255) : 0;
     const size_t img = bf16 ? szg::mq_bf16_image_bytes(r16, nb)
-                            : i8 ? szg::mq_i8_lds_bytes(ix->bits, r16, nb) : szg::mq_lds_bytes(ix->bits, r16, nb);
+                            : i8 ? group_stride * groups : szg::mq_lds_bytes(ix->bits, r16, nb);
     int rc = ensure_host(&c->h_mq, &c->h_mq_cap, img);
     if (rc) return rc;
     rc = ensure_dev(&c->d_mq, &c->d_mq_cap, img);
@@ -993,11 +997,12 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
         // (+1 for the odd half); the operand is the nibble x and n = 2x - 15.
         const int NP = szg::kMqPlanes, T = ix->bits == 4 ? 2 : 1;
         const int epp = ix->bits == 4 ? 32 : 16;  // elements per 16-byte piece
-        uint8_t *im8 = c->h_mq;
         const size_t plane = (size_t)T * nb * 64 * 16;  // bytes between digit planes of a step
         for (int q = 0; q < nq; q++) {
             const int32_t *Qv = c->h_mqQ + (size_t)q * ix->dim;
-            const int b = q / 16, qi = q % 16;
+            const int ql = q % (16 * nb);  // position inside its group
+            uint8_t *im8 = c->h_mq + (size_t)(q / (16 * nb)) * group_stride;
+            const int b = ql / 16, qi = ql % 16;
             for (int e = 0; e < ix->dim; e++) {
                 int Q = Qv[e];
                 const int j = e / epp, i = e % epp;
@@ -1012,11 +1017,13 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
                 dst[0] = (uint8_t)(int8_t)Q;         // plane 0 = the top digit
             }
         }
-        float *tab = reinterpret_cast<float *>(c->h_mq + szg::mq_i8_image_bytes(ix->bits, r16, nb));
-        for (int q = 0; q < nq && q < 48; q++) {
-            tab[q] = (float)c->meta[q].mq_qscale;
-            tab[48 + q] = (float)((ix->bits == 4 ? -15.0 : 1.0) * c->meta[q].mq_qconst);
-            tab[96 + q] = (float)c->meta[q].qnorm2;
+        for (int q = 0; q < nq; q++) {
+            const int ql = q % (16 * nb);
+            float *tab = reinterpret_cast<float *>(c->h_mq + (size_t)(q / (16 * nb)) * group_stride +
+                                                   szg::mq_i8_image_bytes(ix->bits, r16, nb));
+            tab[ql] = (float)c->meta[q].mq_qscale;
+            tab[48 + ql] = (float)((ix->bits == 4 ? -15.0 : 1.0) * c->meta[q].mq_qconst);
+            tab[96 + ql] = (float)c->meta[q].qnorm2;
         }
     } else {
     // LDS image [piece j][query block][group of 4 elements][query 16][4 floats].  Cosine:
@@ -1110,6 +1117,8 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
     a.dim = ix->dim;
     a.queries = c->d_mq;
     a.n_queries = nq;
+    a.n_groups = groups;
+    a.group_stride = (uint32_t)group_stride;
     a.metric = ix->metric;
     for (int q = 0; q < nq && q < szg::kMqMaxQueries; q++) a.qnorm2[q] = (float)c->meta[q].qnorm2;
     a.keys = c->d_keys;
@@ -1180,7 +1189,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
         if (ix->timing) {
             HIPCHK(hipEventRecord(c->ev_scan1, st));
             c->timed_scan = true;
-            c->timed_n = 1;
+            c->timed_n = groups;  // (passes: an int8 launch may walk two)
         }
         // The selection, merges, rerank and copy-back of this batch either follow on the scan
         // stream (default) or, with "mq_tail_overlap", on the context's stream, where they run
@@ -1215,9 +1224,9 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
     }
     {
         std::lock_guard<std::mutex> lk(ix->stats_mu);
-        ix->stats.scan_launches += 1;
-        ix->stats.scan_bytes += sh->n_rows * (uint64_t)ix->row_bytes;  // ONE pass for the batch
-        ix->stats.mq_launches += 1;
+        ix->stats.scan_launches += (uint64_t)groups;
+        ix->stats.scan_bytes += (uint64_t)groups * sh->n_rows * (uint64_t)ix->row_bytes;  // ONE pass per group of the batch
+        ix->stats.mq_launches += (uint64_t)groups;
         ix->stats.mq_queries += (uint64_t)nq;
         ix->stats.mq_bf16_sweeps += bf16 ? 1 : 0;
     }
@@ -1561,7 +1570,7 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
                 if (overflow) {
                     {
                         std::lock_guard<std::mutex> lk(ix->stats_mu);
-                        ix->stats.mq_launches -= 1;  // counted again by the rerun
+                        ix->stats.mq_launches -= (uint64_t)((t.nq + 16 * c->mq_nb - 1) / (16 * c->mq_nb));  // counted again by the rerun
                         ix->stats.mq_queries -= (uint64_t)t.nq;
                         ix->stats.mq_bf16_sweeps -= (c->mq_stage2 || c->mq_bf16_used) ? 1 : 0;
                         ix->stats.mq_fallbacks += 1;
@@ -1717,7 +1726,11 @@ int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k,
         // batches of up to 32 share one sweep when the multi-query path applies
         const int left = n_queries - q0;
         const int nb = replay_all ? 0 : mq_blocks(ix, left);
-        t.nq = nb ? std::min(left, 16 * nb) : std::min(B1, left);
+        // (int8 sweeps: two groups of 48 per launch when that many queries are waiting)
+        const int groups = nb == 3 && mq_uses_i8(ix) && ix->mq_i8_groups > 1 && left > 48 &&
+                                   szg::mq_i8_lds_bytes(ix->bits, ix->map.r16, 3, 2) <= 160u * 1024u   // both images in LDS
+                               ? 2 : 1;
+        t.nq = nb ? std::min(left, 16 * nb * groups) : std::min(B1, left);
         const bool bf16_sweep = nb > 0 && mq_uses_bf16(ix);
         t.kp = kp;
         // lists of bfloat16-sweep keys (matrix form): the error band holds more rows than the
@@ -3288,6 +3301,9 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
         ix->mq_fused = value != 0;
     } else if (n == "mq_i8") {
         ix->mq_i8 = value != 0;
+    } else if (n == "mq_i8_groups") {
+        if (value < 1 || value > 2) return fail(SZG_E_INVALID, "mq_i8_groups must be 1 or 2");
+        ix->mq_i8_groups = (int)value;
     } else if (n == "mq_bf16") {
         ix->mq_bf16 = value != 0;
     } else if (n == "mq_overlap") {

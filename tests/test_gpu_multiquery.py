@@ -279,3 +279,26 @@ def test_bf16_sweep_masks_and_k_beyond_the_slack():
             assert (d[qi, : c[qi]] == o_dist).all()
         if DEFAULT_TUNABLES:
             assert ix.stats()["mq_bf16_sweeps"] == 1
+
+
+@pytest.mark.parametrize("bits", [8, 4])
+@pytest.mark.parametrize("metric", [SZG_COSINE, SZG_EUCLIDEAN])
+def test_int8_sweep_two_query_groups_per_launch(bits, metric):
+    """More than 48 queries on 8- / 4-bit rows: one launch walks the passes of two groups of 48 back to back
+    (hits, thresholds and score-matrix rows indexed by 48 * group + query); answers unchanged."""
+    dim, n = 128, 6000
+    rows = orc.synth_rows(990 + bits, 0, n, dim, bits)
+    Q = orc.synth_vectors(991, 0, 70, dim)
+    allow = np.arange(n) % 5 != 3
+    with ScanIndex(dim, bits, metric) as ix:
+        ix.load(rows)
+        check(ix, rows, dim, Q, 10, bits=bits, metric=metric)
+        check(ix, rows, dim, Q, 10, allow=allow, bits=bits, metric=metric)
+        st = ix.stats()
+        if DEFAULT_TUNABLES:
+            assert st["mq_queries"] == 140 and st["mq_launches"] == 4   # 2 calls x (48 + 22)
+        ix.set_option("mq_fused", 0)                                    # the score-matrix form
+        check(ix, rows, dim, Q, 10, bits=bits, metric=metric)
+        ix.set_option("mq_i8_groups", 1)
+        ix.set_option("mq_fused", 1)
+        check(ix, rows, dim, Q[:60], 10, bits=bits, metric=metric)
