@@ -26,7 +26,9 @@ Rank 0 prints ONE JSON line: metric/value/unit/..., plus
   "batched":      the shared multi-query sweep on the matrix cores (its own fixed query set);
   "sketch_prepass": the optional 8-bit sketch pre-pass on the headline workload (same answers);
   "host_us_per_query", "ranks", "rccl_ranks", "other_workloads" (cfg2/cfg3/cfg4/cfg5 per-GPU
-                  shards: one roofline object each).
+                  shards: queries/s and one short roofline object each, peak 8000 GB/s).
+The printed line is the compact form; the full objects (kernels, launch times, PMC traffic, host time
+breakdown) go to stderr as "bench detail: {...}".
 """
 import argparse
 import json
@@ -68,9 +70,42 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def _rf(r):
+    return {key: r[key] for key in ("bound", "achieved", "unit", "frac") if key in r}
+
+
+def compact(obj):
+    """The printed line keeps the contract's fields in full and one short object per extra leg (a driver may
+    keep only a tail of stdout); everything else goes to stderr as "bench detail"."""
+    o = dict(obj)
+    if "batched" in o:
+        b = o["batched"]
+        o["batched"] = {"value": b["value"], "unit": b["unit"], "queries_per_sweep": b["queries_per_sweep"],
+                        "avg_sweep_ms": b["avg_sweep_ms"], "kernel": b["kernel"].split(" ")[0], "roofline": _rf(b["roofline"]),
+                        "ids_identical_to_single_query_path": b["ids_identical_to_single_query_path"]}
+        if "float32_mfma_form" in b:
+            o["batched"]["float32_mfma_form_TFLOPs"] = b["float32_mfma_form"]["mfma_TFLOPs"]
+    if "sketch_prepass" in o:
+        k = o["sketch_prepass"]
+        o["sketch_prepass"] = {"option": "sketch=1 (off by default; DESIGN.md 4.5)", "value": k["value"], "unit": k["unit"],
+                               "settled_by_the_sketch": "%d/%d" % (k["settled_by_the_sketch"], k["queries"]),
+                               "identical_to_full_precision_path": k["ids_and_distances_identical_to_full_precision_path"],
+                               "roofline": _rf(k["roofline"])}
+    if "other_workloads" in o:
+        o["other_workloads"] = {
+            name: ({"error": w["error"]} if "error" in w else
+                   {"value": w["value"], "roofline": _rf(w["roofline"]),
+                    "identical_to_oracle": "%d/%d" % (w["parity"]["identical_to_oracle"], w["parity"]["queries_checked"])})
+            for name, w in o["other_workloads"].items()}
+    if "host_us_breakdown" in o:
+        del o["host_us_breakdown"]
+    return o
+
+
 def emit(obj):
-    """The ONE JSON line, on the process's real stdout."""
-    _REAL_STDOUT.write(json.dumps(obj) + "\n")
+    """The ONE JSON line, on the process's real stdout (compact form; the full objects go to stderr)."""
+    log("bench detail: " + json.dumps(obj))
+    _REAL_STDOUT.write(json.dumps(compact(obj)) + "\n")
     _REAL_STDOUT.flush()
 
 
@@ -101,8 +136,7 @@ def recorded_traffic(workload, rows, sweeps_per_launch):
         if int(e.get("rows", WORKLOADS[workload][0])) != int(rows):
             return None, None
         return (int(e["hbm_bytes_per_launch"] / float(e.get("sweeps_per_launch", 1)) * sweeps_per_launch),
-                "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
-                "not measured in this run)")
+                "profiles/traffic.json (separate rocprofv3 --pmc passes, not this run)")
     except Exception:
         return None, None
 
@@ -612,11 +646,8 @@ def main():
         sweeps_per_launch = kst["scan_bytes"] / max(kst["scan_launches"], 1) / (n_rows * sk_row_bytes)
         gbps = kst["scan_bytes"] / max(kst["scan_launches"], 1) / (launch_ms * 1e-3) / 1e9 if launch_ms else 0.0
         out["sketch_prepass"] = {
-            "what": "option sketch=1: a sweep of an 8-bit sketch of the rows (dim bytes per row instead of 4 x dim) finds "
-                    "40 candidates per query, the float32 rows decide in float64, and the answer is final when its k-th "
-                    "distance is below (40th sketch distance) - (largest row-to-sketch angle): the reference's cosine "
-                    "distance is the angle, a metric.  Same answers, bit for bit; queries it cannot settle take the "
-                    "full-precision sweep",
+            "what": "option sketch=1 (off by default): 8-bit sketch sweep -> float32/float64 re-rank, certified by the "
+                    "triangle inequality of the angular distance; same answers (DESIGN.md 4.5)",
             "queries": int(len(qs)), "value": round(len(qs) / k_elapsed, 1), "unit": "queries/s",
             "settled_by_the_sketch": int(kst["sketch_queries"]), "handed_to_the_full_sweep": int(kst["sketch_fallbacks"]),
             "ids_and_distances_identical_to_full_precision_path":
@@ -641,18 +672,18 @@ def main():
             # single-thread rate first, to size the all-core sample
             secs1, _ = orc.bench_topk(rows_host, dim, bits, metric, qt[:1], kk, 1)
             per_query = max(secs1, 1e-6)
-            nq = int(max(cores, min(len(qt), cores * args.cpu_seconds / per_query)))
-            nq = min(nq, len(qt))
-            secs, cpu_rows = orc.bench_topk(rows_host, dim, bits, metric, qt[:nq], kk, cores)
+            nq = int(max(cores, cores * args.cpu_seconds / per_query))
+            nq = min(nq, 4096)
+            q_cpu = qt if nq <= len(qt) else np.concatenate([qt, synth_vectors(seed + 5, 0, nq - len(qt), dim)])
+            secs, cpu_rows = orc.bench_topk(rows_host, dim, bits, metric, q_cpu[:nq], kk, cores)
             scale = sample_rows / float(n_rows)
             out["cpu_baseline"] = {
                 "value": round(nq / secs * scale, 3),
                 "unit": "queries/s",
                 "cores": cores,
                 "kind": "port",
-                "sample": "%d queries x first %d of %d rows on %d threads (%.1f s), scaled linearly to "
-                          "%d rows; C port of the reference's Go scan (no Go toolchain here)" % (
-                              nq, sample_rows, n_rows, cores, secs, n_rows),
+                "sample": "%d queries x first %d of %d rows, %d threads, %.1f s, scaled to %d rows; C port of the "
+                          "reference's Go scan" % (nq, sample_rows, n_rows, cores, secs, n_rows),
                 "single_thread": round(1.0 / per_query * scale, 4),
             }
             # the reference also CRCs and re-parses each record's span and allocates a decode

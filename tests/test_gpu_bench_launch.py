@@ -51,5 +51,5 @@ def test_inproc_mode_and_unchanged_single_gpu_form():
     assert one["roofline"]["bound"] == "hbm" and one["cpu_baseline"]["kind"] == "port"
     assert one["batched"]["ids_identical_to_single_query_path"]
     assert one["batched"]["roofline"]["bound"] == "hbm" and one["batched"]["roofline"]["achieved"] > 0   # bfloat16 sweep
-    assert one["batched"]["float32_mfma_form"]["mfma_TFLOPs"] > 0
+    assert one["batched"]["float32_mfma_form_TFLOPs"] > 0
     assert one["parity"]["ids_identical"] == one["parity"]["queries_checked"]
