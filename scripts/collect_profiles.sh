@@ -12,11 +12,13 @@ one() { f=$(find "$1" -name "$2" | head -1); if [ -n "$f" ]; then cp "$f" "$3"; 
 
 echo "[1] unprofiled bench" | tee -a $out/progress.log
 python3 $GRAFT_REPO_ROOT/bench.py > $out/${tag}_bench_n1_unprofiled_stdout.json 2> $out/bench_unprofiled.err
+grep "^bench detail: " $out/bench_unprofiled.err | sed "s/^bench detail: //" > $out/${tag}_bench_n1_unprofiled_detail.json || true
 
 echo "[2] kernel trace + stats over bench.py" | tee -a $out/progress.log
 rm -rf /tmp/prof_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py > $out/${tag}_bench_n1_stdout.json 2> $out/bench_profiled.err
 one /tmp/prof_stats "*kernel_stats.csv" $out/${tag}_bench_n1_kernel_stats.csv
+grep "^bench detail: " $out/bench_profiled.err | sed "s/^bench detail: //" > $out/${tag}_bench_n1_detail.json || true
 
 i=2
 # name rows dim bits metric k queries (one query-major launch of 16 sweeps)
