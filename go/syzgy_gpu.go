@@ -23,6 +23,7 @@ import "C"
 import (
 	"container/heap"
 	"fmt"
+	"os"
 	"sort"
 	"strconv"
 	"sync"
@@ -70,6 +71,13 @@ func newGPUMirror(c *Collection, devices []int) (*gpuMirror, error) {
 	if rc != C.SZG_OK {
 		return nil, fmt.Errorf("szg_index_create: %s (%s)", C.GoString(C.szg_strerror(rc)),
 			C.GoString(C.szg_last_error()))
+	}
+	// Optional: float32 collections can answer lone Searches from an 8-bit sketch of the rows (a quarter of
+	// the bytes per query, +25 % device memory, same answers: DESIGN.md 4.5).  Off unless asked for.
+	if os.Getenv("SYZGY_GPU_SKETCH") == "1" && c.Quantization == 32 {
+		name := C.CString("sketch")
+		C.szg_set_option(m.h, name, 1)
+		C.free(unsafe.Pointer(name))
 	}
 	if err := m.reload(c); err != nil {
 		m.close()

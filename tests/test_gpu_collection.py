@@ -453,3 +453,30 @@ def test_tie_order_follows_sorted_string_ids_after_appends():
         got = c.Search(SearchArgs(Vector=q, K=6, Precision="exact"))
         assert [r.ID for r in got.Results] == [order[int(r)] for r in want_rows]
         c.Close()
+
+
+def test_collection_mirror_with_the_sketch_option():
+    """Collection(..., sketch=True): lone Searches on a float32 collection go through the 8-bit pre-pass;
+    ids, order and distances as without it."""
+    rng = np.random.default_rng(21)
+    dim, n = 32, 6000
+    V = rng.standard_normal((n, dim))
+    a = Collection(CollectionOptions(Name="a", DistanceMethod=Cosine, DimensionCount=dim, Quantization=32))
+    b = Collection(CollectionOptions(Name="b", DistanceMethod=Cosine, DimensionCount=dim, Quantization=32), sketch=True)
+    ids = list(range(1, n + 1))
+    a.AddDocuments(ids, V, [b"m%d" % i for i in ids])
+    b.AddDocuments(ids, V, [b"m%d" % i for i in ids])
+    for qi in range(6):
+        q = rng.standard_normal(dim)
+        ra = a.Search(SearchArgs(Vector=q, K=7, Precision="exact"))
+        rb = b.Search(SearchArgs(Vector=q, K=7, Precision="exact"))
+        assert [(r.ID, r.Distance, r.Metadata) for r in ra.Results] == [(r.ID, r.Distance, r.Metadata) for r in rb.Results]
+    st = b._index.stats()
+    assert st["sketch_queries"] + st["sketch_fallbacks"] == 6
+    b.removeDocument(ra.Results[0].ID)
+    a.removeDocument(ra.Results[0].ID)
+    ra = a.Search(SearchArgs(Vector=q, K=7, Precision="exact"))
+    rb = b.Search(SearchArgs(Vector=q, K=7, Precision="exact"))
+    assert [(r.ID, r.Distance) for r in ra.Results] == [(r.ID, r.Distance) for r in rb.Results]
+    a.Close()
+    b.Close()
