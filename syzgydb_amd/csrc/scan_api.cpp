@@ -686,7 +686,11 @@ LaunchGeom scan_geometry(const szg_index *ix, const Shard *sh, int kp, bool plai
         // (4 waves per CU is another 0.5 % faster on 3 KB rows at 1M rows but 10 % slower
         // on a 125 K-row shard, where the sweep's ramp-up and tail weigh more.)
         (void)plain_topk;
-        if (kp > 64 || (ix->bits >= 32 && ix->row_bytes >= 1024) || (ix->bits == 8 && ix->layout.tiled))
+        // Collect sweeps (kp == 0: radius search, escalation) keep no lists; on short 4-bit rows (cfg5's 192 bytes)
+        // they stream best with 8 (same-box A/B, scripts/ab_opts.sh: 6.2-6.7 -> 6.85-6.91 TB/s; top-k on the same rows
+        // wants its 12: 6.8-6.9 against 6.5).
+        const bool short_collect = kp == 0 && ix->bits == 4 && ix->row_bytes <= 256;
+        if (kp > 64 || short_collect || (ix->bits >= 32 && ix->row_bytes >= 1024) || (ix->bits == 8 && ix->layout.tiled))
             waves_per_cu = 8;
         else
             waves_per_cu = 12;
