@@ -28,8 +28,8 @@ with ScanIndex(dim, 32, metric, devices=[0]) as ix:
     # lone queries, one call each, one after the other (a single goroutine calling Search)
     for sketch in (0, 1):
         ix.set_option("sketch", sketch); ix.set_option("multi_query", 1); ix.set_timing(False)
-        for i in range(20): ix.search_topk(q[i], k)
+        for i in range(20): ix.search_topk(q[i % nq], k)
         t0 = time.perf_counter()
-        for i in range(200): ix.search_topk(q[i], k)
+        for i in range(200): ix.search_topk(q[i % nq], k)
         el = time.perf_counter() - t0
         print("sketch=%d lone queries: %.3f ms per call (%.0f calls/s)" % (sketch, el / 200 * 1e3, 200 / el), flush=True)
