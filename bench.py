@@ -211,13 +211,11 @@ def calibrated_radius(ix, queries, radius, target_hits=500):
     return rad, len(r)
 
 
-def radius_searches(ix, queries, radius, threads=3):
-    """Radius searches as the reference issues them -- one Search per caller, several callers at
-    once under RLock (collection.go:570): a few threads keep the sweeps back to back while the
-    other callers' hits are re-ranked and copied."""
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        return list(ex.map(lambda q: ix.search_radius(q, radius), queries))
+def radius_searches(ix, queries, radius):
+    """Radius searches of a query list: szg_search_radius_batch -- the collect sweeps walked query-major, 16 per
+    launch, up to three launches in flight, the hits re-ranked from the device-side counters (concurrent
+    single-query callers, the reference's Searches under RLock, are coalesced into the same launches)."""
+    return ix.search_radius_batch(queries, radius)
 
 
 def timed_leg(ix, queries, k, radius, n_settle=16):
@@ -227,7 +225,7 @@ def timed_leg(ix, queries, k, radius, n_settle=16):
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < 0.4:   # clocks / TLBs settle (untimed)
         if radius > 0:
-            radius_searches(ix, queries[:6], radius)
+            radius_searches(ix, queries[:16], radius)
         else:
             ix.search_topk(queries[:n_settle], k)
     ix.set_timing(True)
@@ -335,7 +333,7 @@ def main():
     import numpy as np
     from syzgydb_amd import ScanIndex
     from syzgydb_amd.synth import synth_vectors
-    from syzgydb_amd.sharded import ShardedSearcher, shard_range
+    from syzgydb_amd.sharded import Comm, ShardedSearcher, shard_range
 
     n_rows, dim, bits, metric, k, radius = WORKLOADS[args.workload]
     if args.rows:
@@ -401,27 +399,48 @@ def main():
             dist.broadcast(rad, 0)
             radius = float(rad.item())
 
-    # queries per local search call and all-gather: one call (one pipeline fill / drain, one
-    # exchange) for short runs, 256 for long ones so that exchanges overlap the next call's sweeps
-    chunk = args.exchange_every or (args.steps if args.steps <= 128 else
-                                    256 if args.steps >= 1024 else (args.steps // 4 + 15) // 16 * 16)
+    # queries per all-gather: the library answers runs of <= 128 queries with one local call and one exchange and
+    # pipelines longer ones in micro-batches of 256 behind a worker thread (szg_search_topk_sharded)
+    chunk = args.steps if args.steps <= 128 else 256
     searcher = None
+    transport = None
     if dist_path:
-        searcher = ShardedSearcher(lambda q, kk: ix.search_topk(q, kk),
-                                   device=torch.device("cuda", local_rank) if backend == "nccl" else None)
-
-    def local_radius(q, rad):
-        return ix.search_radius(q, rad)
+        # The exchange lives in the library (csrc/scan_comm.cpp): its own RCCL communicator on this rank's card,
+        # the 128-byte id handed round through the process group once.  Should RCCL refuse inside the library on
+        # ANY rank, every rank falls back to the group's own all-gather as host transport (and says so below).
+        comm = None
+        if backend == "nccl":
+            try:
+                comm = Comm.from_process_group(device=local_rank)
+                ok = 1
+            except Exception as e:  # pragma: no cover
+                log("[rank %d] in-library RCCL communicator failed: %s" % (rank, e))
+                ok = 0
+            t = torch.tensor([ok], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 1:
+                transport = "rccl (ncclAllGather inside libsyzgy_scan.so)"
+            else:
+                if comm is not None:
+                    comm.close()
+                comm = Comm.from_process_group(via_torch_device=torch.device("cuda", local_rank))
+                transport = "torch.distributed nccl all-gather as host transport (in-library RCCL init failed)"
+        else:
+            comm = Comm.from_process_group()
+            transport = "%s all-gather on the CPU as host transport (rehearsal)" % backend
+        searcher = ShardedSearcher(index=ix, comm=comm)
+        if k > 0:
+            comm.reserve(min(max(args.steps, args.warmup, 1), 256), k)  # staging of the largest micro-batch, up front
 
     def run(q):
         if radius > 0:
             if dist_path:
-                outs = searcher.search_radius_stream(local_radius, q, radius)
+                outs = searcher.search_radius_batch(q, radius)
             else:
                 outs = radius_searches(ix, q, radius)
             return [o[0] for o in outs], [o[1] for o in outs]
         if dist_path:
-            r, d, _, _ = searcher.search_stream(q, k, chunk)
+            r, d, _, _ = searcher.search_stream(q, k)
             return r, d
         r, d, _ = ix.search_topk(q, k)
         return r, d
@@ -442,10 +461,17 @@ def main():
             ix.search_topk(qt[:64], k)
     if args.warmup:
         run(qw)
+    # First use is not what is measured: two UNTIMED calls with exactly the timed call's shape (K queries: the
+    # same batch boundaries, micro-batches, staging and all-gather sizes; the warm-up queries repeated, so the
+    # timed queries themselves stay unseen), a fixed number on every rank.  Without them a 20-step run at N > 1
+    # paid the allocation of its exchange buffers and the first all-gather of that size inside the timed region.
+    shape_q = np.resize(qw if args.warmup else qt, (len(qt), dim))
+    for _ in range(2):
+        run(shape_q)
     ix.set_timing(True)
     ix.reset_stats()
     if searcher is not None:
-        searcher.reset_timers()
+        searcher.comm.reset_stats()
     sync()
     t0 = time.perf_counter()
     res_rows, res_dist = run(qt)  # returns when every result is on the host
@@ -465,11 +491,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         mine = roofline_of(stats, hi - lo, ix.row_bytes, bits, metric, "")
+        cst = searcher.comm.stats()
         row = {"rank": rank, "device": devices[0], "rows": hi - lo, "elapsed_s": round(my_elapsed, 6),
                "scan_GBps": mine["achieved"], "avg_launch_ms": mine["avg_launch_ms"],
-               "host_us_per_query": round((stats["host_prep_us"] + stats["host_finish_us"] + stats["host_enqueue_us"]) / max(args.steps, 1) +
-                                          1e6 * searcher.exchange_host_s / max(args.steps, 1), 2),
-               "exchange_ms_per_batch": round(1e3 * searcher.exchange_s / max(searcher.exchanges, 1), 3)}
+               "sweeps_ms": round(stats["scan_ms"], 4),
+               # everything in this rank's timed region that is not a sweep: pipeline fill / drain, host work
+               # that did not hide behind sweeps, the exchange
+               "fixed_overhead_ms": round(1e3 * my_elapsed - stats["scan_ms"], 4),
+               "host_us_per_query": round((stats["host_prep_us"] + stats["host_finish_us"] + stats["host_enqueue_us"] +
+                                           cst["host_us"]) / max(args.steps, 1), 2),
+               "exchanges": int(cst["exchanges"]),
+               "exchange_ms_per_batch": round(1e-3 * cst["exchange_us"] / max(cst["exchanges"], 1), 3)}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, row)
 
@@ -485,7 +517,7 @@ def main():
                 rf["traffic_source"] = src
         host_us = (stats["host_prep_us"] + stats["host_finish_us"] + stats["host_enqueue_us"]) / max(args.steps, 1)
         if searcher is not None:
-            host_us += 1e6 * searcher.exchange_host_s / max(args.steps, 1)
+            host_us += searcher.comm.stats()["host_us"] / max(args.steps, 1)
         out = {
             "metric": "queries/sec, exact scan 1M x 768 cosine k=10" if args.workload == "headline"
             else "queries/sec, exact scan (%s)" % args.workload,
@@ -511,7 +543,7 @@ def main():
                 "mode": "inproc" if inproc else ("ranks" if dist_path else "single"),
                 "parallelism": "rows sharded over %d GPU(s)%s" % (
                     n_dev, (", one handle with %d device shards in one process" % n_dev) if inproc else
-                    (", one process per GPU, 1 %s all-gather per %d queries" % (
+                    (", one process per GPU, 1 %s all-gather per %d queries (inside the library)" % (
                         "RCCL" if backend == "nccl" else backend, chunk) if dist_path else "")),
             },
             "roofline": rf,
@@ -519,16 +551,21 @@ def main():
             "host_us_breakdown": {"prepare": round(stats["host_prep_us"] / max(args.steps, 1), 2),
                                   "enqueue_hip_calls": round(stats["host_enqueue_us"] / max(args.steps, 1), 2),
                                   "assemble": round(stats["host_finish_us"] / max(args.steps, 1), 2),
-                                  "exchange_pack_merge": round(1e6 * searcher.exchange_host_s / max(args.steps, 1), 2)
+                                  "exchange_pack_merge": round(searcher.comm.stats()["host_us"] / max(args.steps, 1), 2)
                                   if searcher is not None else 0.0},
             "escalations": int(stats["escalations"]),
             "full_replays": int(stats["full_replays"]),
         }
+        if not dist_path:
+            out["fixed_overhead_ms"] = round(1e3 * elapsed - stats["scan_ms"], 4)  # timed region minus the sweeps
         if hits_per_query is not None:
             out["hits_per_query"] = round(hits_per_query, 1)
         if dist_path:
             out["rccl_ranks"] = rccl_ranks if backend == "nccl" else 0
+            out["rccl_ranks_in_library"] = int(searcher.comm.stats()["rccl_ranks"])  # ncclCommCount of the library's communicator
             out["exchange_backend"] = backend
+            out["exchange_transport"] = transport
+            out["fixed_overhead_ms"] = max(r["fixed_overhead_ms"] for r in per_rank)
             out["ranks"] = per_rank
         if inproc:
             out["roofline"]["note"] = "per device shard; the N shards sweep concurrently"
@@ -709,6 +746,8 @@ def main():
                 log("bench.py: PARITY FAILURE: GPU ids differ from the oracle's")
                 emit(out)
                 sys.exit(1)
+    if searcher is not None:
+        searcher.close()   # detaches the communicator from the handle, then destroys it (ncclCommDestroy)
     ix.close()
 
     # ---- the other BASELINE configs, one roofline object each (N=1) ----------------

@@ -23,6 +23,7 @@ import "C"
 import (
 	"container/heap"
 	"fmt"
+	"math"
 	"os"
 	"sort"
 	"strconv"
@@ -43,6 +44,13 @@ type gpuMirror struct {
 	// need exclusive access) takes mu for writing, every search takes it for reading.
 	mu      sync.RWMutex
 	lastID  string // greatest decimal id string among the loaded rows (visit order = sort.Strings)
+	// Row order only matters where the reference's own answer depends on its visit order: ties at the k
+	// boundary, equal distances in a radius result (collection.go:608, :536-564).  Production iterates a Go map
+	// (random order per run, spanfile.go:525), so there every order is a reference order and rows are simply
+	// appended.  Only the reference's deterministic mode (myRandom.rand != nil: seeded tests, spanfile.go:522)
+	// pins the order to sort.Strings of the ids; there an out-of-order append sets orderStale, and the mirror is
+	// re-paged in order the first time an answer actually contains such a tie -- not on every add.
+	orderStale bool
 	version uint64 // bumped by add / remove: filter verdicts are cached per (key, version)
 	masks   map[string]cachedMask
 }
@@ -123,14 +131,13 @@ func (m *gpuMirror) reload(c *Collection) error {
 		return fmt.Errorf("szg_index_load: %s", C.GoString(C.szg_last_error()))
 	}
 	m.dirty = false
+	m.orderStale = false
 	return nil
 }
 
 // add mirrors AddDocument (collection.go:427-457); called under c.mutex.Lock, so no search
-// is in flight.  Rows are kept in IterateSortedRecords order (sort.Strings of the decimal ids,
-// spanfile.go:540-560) because that order decides ties at the k boundary ("first visited
-// wins", collection.go:608): a new id that sorts after every loaded one is appended in place;
-// any other new id marks the mirror dirty and the next search reloads it in order.
+// is in flight.  A new row is always appended in place (one small H2D copy); see orderStale for
+// what the reference's deterministic visit order asks for on top of that.
 func (m *gpuMirror) add(id uint64, encoded []byte) {
 	m.version++
 	p := (*C.uint8_t)(unsafe.Pointer(&encoded[0]))
@@ -140,10 +147,8 @@ func (m *gpuMirror) add(id uint64, encoded []byte) {
 		}
 		return
 	}
-	rid := strconv.FormatUint(id, 10)
-	if m.dirty || rid < m.lastID {
-		m.dirty = true // out of visit order: reload before the next exact search
-		return
+	if m.dirty {
+		return // a failed call left the mirror behind the file: the next search reloads everything
 	}
 	if C.szg_index_append(m.h, p, 1) != C.SZG_OK {
 		m.dirty = true
@@ -151,7 +156,47 @@ func (m *gpuMirror) add(id uint64, encoded []byte) {
 	}
 	m.rowOf[id] = uint64(len(m.ids))
 	m.ids = append(m.ids, id)
-	m.lastID = rid
+	rid := strconv.FormatUint(id, 10)
+	if rid < m.lastID { // decimal STRING order: "10" < "9"
+		if myRandom.rand != nil {
+			m.orderStale = true
+		}
+	} else {
+		m.lastID = rid
+	}
+}
+
+// addBulk is AddDocument for a block of new documents (bulk ingest): the float64 vectors are quantized and
+// packed on the device exactly as encodeDocument / quantize do (szg_index_append_f64; collection.go:713-743,
+// quantization.go:5-23), one call for the block.  ids must be new and distinct; called under c.mutex.Lock after
+// the records have been written to the spanfile.
+func (m *gpuMirror) addBulk(ids []uint64, vectors []float64, dim int) bool {
+	if m.dirty || len(ids) == 0 || len(vectors) != len(ids)*dim {
+		return false
+	}
+	for _, id := range ids {
+		if _, ok := m.rowOf[id]; ok {
+			return false
+		}
+	}
+	m.version++
+	if C.szg_index_append_f64(m.h, (*C.double)(unsafe.Pointer(&vectors[0])), C.uint64_t(len(ids))) != C.SZG_OK {
+		m.dirty = true
+		return false
+	}
+	for _, id := range ids {
+		m.rowOf[id] = uint64(len(m.ids))
+		m.ids = append(m.ids, id)
+		rid := strconv.FormatUint(id, 10)
+		if rid < m.lastID {
+			if myRandom.rand != nil {
+				m.orderStale = true
+			}
+		} else {
+			m.lastID = rid
+		}
+	}
+	return true
 }
 
 // remove mirrors removeDocument (collection.go:511-521); called under c.mutex.Lock.
@@ -226,31 +271,90 @@ func (m *gpuMirror) searchExact(c *Collection, args SearchArgs) (results []Searc
 	return m.searchExactKeyed(c, args, "")
 }
 
+// ensureFresh reloads the mirror if a mutator could not be applied (dirty).  The caller holds only
+// c.mutex.RLock: other searches may be inside the library right now.  The mirror's own lock makes the
+// reload exclusive; whoever gets it first reloads.
+func (m *gpuMirror) ensureFresh(c *Collection, alsoOrder bool) bool {
+	m.mu.RLock()
+	stale := m.dirty || (alsoOrder && m.orderStale)
+	m.mu.RUnlock()
+	if !stale {
+		return true
+	}
+	m.mu.Lock()
+	defer m.mu.Unlock()
+	if m.dirty || (alsoOrder && m.orderStale) {
+		if err := m.reload(c); err != nil {
+			return false
+		}
+	}
+	return true
+}
+
+// fullReplays reads the library's count of queries it re-answered by the exact replay in ROW order (equal
+// distances or NaN among the best k+1: the reference's answer depends on its visit order there).
+func (m *gpuMirror) fullReplays() uint64 {
+	var st C.szg_stats
+	if C.szg_get_stats(m.h, &st) != C.SZG_OK {
+		return 0
+	}
+	return uint64(st.full_replays)
+}
+
 // searchExactKeyed: filterKey names args.Filter for the bitmask cache ("" = do not cache).
 func (m *gpuMirror) searchExactKeyed(c *Collection, args SearchArgs, filterKey string) (results []SearchResult, ok bool) {
+	if !m.ensureFresh(c, false) {
+		return nil, false
+	}
 	m.mu.RLock()
-	stale := m.dirty
+	orderStale := m.orderStale
+	before := uint64(0)
+	if orderStale {
+		before = m.fullReplays()
+	}
+	rows, dist, ok := m.searchRows(c, args, filterKey)
+	tie := false
+	if ok && orderStale {
+		// deterministic mode with rows out of sort.Strings order: did this answer depend on the visit order?
+		// (a concurrent search's replay can only make this fire needlessly, never hide a tie)
+		tie = m.fullReplays() != before
+		if args.Radius > 0 {
+			seen := make(map[float64]bool, len(dist))
+			for _, d := range dist {
+				if seen[float64(d)] {
+					tie = true
+				}
+				seen[float64(d)] = true
+			}
+		}
+	}
+	if ok && !tie {
+		results, ok = m.resultsOf(c, rows, dist)
+	}
 	m.mu.RUnlock()
-	if stale {
-		// the caller holds only c.mutex.RLock: other searches may be inside the library right
-		// now.  The mirror's own lock makes the reload exclusive; whoever gets it first reloads.
-		m.mu.Lock()
-		var err error
-		if m.dirty {
-			err = m.reload(c)
-		}
-		m.mu.Unlock()
-		if err != nil {
-			return nil, false
-		}
+	if !ok || !tie {
+		return results, ok
+	}
+	if !m.ensureFresh(c, true) { // re-page in sort.Strings order, then answer again
+		return nil, false
 	}
 	m.mu.RLock()
 	defer m.mu.RUnlock()
+	rows, dist, ok = m.searchRows(c, args, filterKey)
+	if !ok {
+		return nil, false
+	}
+	return m.resultsOf(c, rows, dist)
+}
+
+// searchRows runs one exact search in the library: rows (mirror order) and the reference's float64 distances.
+// Called with m.mu read-locked.
+func (m *gpuMirror) searchRows(c *Collection, args SearchArgs, filterKey string) (rows []C.uint64_t, dist []C.double, ok bool) {
 	if len(m.ids) == 0 {
-		return make([]SearchResult, 0), true // empty collection: no results, [] not null (collection_test.go:294-309)
+		return nil, nil, true // empty collection: no results (collection_test.go:294-309)
 	}
 	if len(args.Vector) != c.DimensionCount {
-		return nil, false
+		return nil, nil, false
 	}
 	var allow *C.uint64_t
 	var keep []C.uint64_t
@@ -259,9 +363,6 @@ func (m *gpuMirror) searchExactKeyed(c *Collection, args SearchArgs, filterKey s
 		allow = &keep[0]
 	}
 	q := (*C.double)(unsafe.Pointer(&args.Vector[0]))
-	var rows []C.uint64_t
-	var dist []C.double
-	n := 0
 	if args.Radius > 0 { // K is ignored (collection.go:598-605)
 		capacity := 1 << 16 // a truncated call costs a second sweep
 		for {
@@ -275,33 +376,141 @@ func (m *gpuMirror) searchExactKeyed(c *Collection, args SearchArgs, filterKey s
 				continue
 			}
 			if rc != C.SZG_OK {
-				return nil, false
+				return nil, nil, false
 			}
-			n = int(total)
-			break
+			return rows[:int(total)], dist[:int(total)], true
 		}
-	} else {
-		rows = make([]C.uint64_t, args.K)
-		dist = make([]C.double, args.K)
-		var count C.int32_t
-		rc := C.szg_search_topk(m.h, q, 1, C.int(args.K), allow, &rows[0], &dist[0], &count)
-		if rc != C.SZG_OK {
-			return nil, false
-		}
-		n = int(count)
 	}
-	results = make([]SearchResult, n)
-	for i := 0; i < n; i++ {
+	rows = make([]C.uint64_t, args.K)
+	dist = make([]C.double, args.K)
+	var count C.int32_t
+	rc := C.szg_search_topk(m.h, q, 1, C.int(args.K), allow, &rows[0], &dist[0], &count)
+	_ = keep
+	if rc != C.SZG_OK {
+		return nil, nil, false
+	}
+	return rows[:int(count)], dist[:int(count)], true
+}
+
+// resultsOf turns rows into SearchResults: row -> document id, metadata = the live mmap slice, as in
+// getDocument (collection.go:476); the caller still holds c.mutex.RLock.  Called with m.mu read-locked.
+func (m *gpuMirror) resultsOf(c *Collection, rows []C.uint64_t, dist []C.double) ([]SearchResult, bool) {
+	results := make([]SearchResult, len(rows)) // [] not null when empty
+	for i := range rows {
 		id := m.ids[rows[i]]
 		span, err := c.spanfile.ReadRecord(fmt.Sprintf("%d", id))
 		if err != nil {
 			return nil, false
 		}
-		// Metadata is the live mmap slice, as in getDocument (collection.go:476); the
-		// caller still holds c.mutex.RLock.
 		results[i] = SearchResult{ID: id, Metadata: span.DataStreams[0].Data, Distance: float64(dist[i])}
 	}
-	_ = keep
+	return results, true
+}
+
+// searchExactBatch answers a list of exact top-k Searches with the same K in ONE library call: batches of two or
+// more share a sweep on the matrix cores (up to 96 queries per pass of the corpus), which is how a caller that holds
+// many queries -- a bulk endpoint beside rest.go:371-487, an offline job -- reaches that path directly instead of
+// through coalesced goroutines.  Each query keeps its own Filter (filterKeys optional, parallel to args).  Radius
+// searches (K ignored, collection.go:598-605) go through szg_search_radius_batch with their own radii.  ok ==
+// false: run the Searches one by one.
+func (m *gpuMirror) searchExactBatch(c *Collection, args []SearchArgs, filterKeys []string) (results [][]SearchResult, ok bool) {
+	if len(args) == 0 {
+		return nil, true
+	}
+	radius := args[0].Radius > 0
+	for _, a := range args {
+		if len(a.Vector) != c.DimensionCount || (a.Radius > 0) != radius || (!radius && a.K != args[0].K) {
+			return nil, false
+		}
+	}
+	if !m.ensureFresh(c, true) { // (a batch is not worth the tie bookkeeping: deterministic mode re-pages first)
+		return nil, false
+	}
+	m.mu.RLock()
+	defer m.mu.RUnlock()
+	nq, dim := len(args), c.DimensionCount
+	results = make([][]SearchResult, nq)
+	if len(m.ids) == 0 {
+		for i := range results {
+			results[i] = make([]SearchResult, 0)
+		}
+		return results, true
+	}
+	q := make([]float64, nq*dim)
+	words := (len(m.ids) + 63) / 64
+	var masks []C.uint64_t
+	anyFilter := false
+	for _, a := range args {
+		anyFilter = anyFilter || a.Filter != nil
+	}
+	if anyFilter {
+		masks = make([]C.uint64_t, nq*words)
+	}
+	for i, a := range args {
+		copy(q[i*dim:(i+1)*dim], a.Vector)
+		if !anyFilter {
+			continue
+		}
+		if a.Filter == nil {
+			for w := 0; w < words; w++ {
+				masks[i*words+w] = ^C.uint64_t(0)
+			}
+			continue
+		}
+		key := ""
+		if i < len(filterKeys) {
+			key = filterKeys[i]
+		}
+		copy(masks[i*words:(i+1)*words], m.allowBitsKeyed(c, a.Filter, key))
+	}
+	var allow *C.uint64_t
+	if anyFilter {
+		allow = &masks[0]
+	}
+	qp := (*C.double)(unsafe.Pointer(&q[0]))
+	if radius {
+		radii := make([]C.double, nq)
+		for i, a := range args {
+			radii[i] = C.double(a.Radius)
+		}
+		off := make([]C.uint64_t, nq+1)
+		capacity := 1 << 16
+		var rows []C.uint64_t
+		var dist []C.double
+		for {
+			rows = make([]C.uint64_t, capacity)
+			dist = make([]C.double, capacity)
+			rc := C.szg_search_radius_batch(m.h, qp, C.int(nq), &radii[0], allow, &rows[0], &dist[0],
+				C.uint64_t(capacity), &off[0])
+			if rc == C.SZG_E_TRUNCATED {
+				capacity = int(off[nq])
+				continue
+			}
+			if rc != C.SZG_OK {
+				return nil, false
+			}
+			break
+		}
+		for i := 0; i < nq; i++ {
+			if results[i], ok = m.resultsOf(c, rows[off[i]:off[i+1]], dist[off[i]:off[i+1]]); !ok {
+				return nil, false
+			}
+		}
+		return results, true
+	}
+	k := args[0].K
+	rows := make([]C.uint64_t, nq*k)
+	dist := make([]C.double, nq*k)
+	count := make([]C.int32_t, nq)
+	if C.szg_search_topk(m.h, qp, C.int(nq), C.int(k), allow, &rows[0], &dist[0], &count[0]) != C.SZG_OK {
+		return nil, false
+	}
+	for i := 0; i < nq; i++ {
+		n := int(count[i])
+		if results[i], ok = m.resultsOf(c, rows[i*k:i*k+n], dist[i*k:i*k+n]); !ok {
+			return nil, false
+		}
+	}
 	return results, true
 }
 
@@ -368,11 +577,15 @@ func (m *gpuMirror) searchIndexBulk(c *Collection, tree *lshTree, vector []float
 	considerWith func(docid uint64, distance float64, radius float64) (int, float64)) bool {
 	const window = 2048
 	const search_k = 200
+	if !m.ensureFresh(c, false) { // (row order is irrelevant here: candidates are addressed by id)
+		return false
+	}
 	m.mu.RLock()
 	defer m.mu.RUnlock()
 	if m.dirty {
-		return false // the caller runs the reference's own walk
+		return false // the caller runs the reference's own walk; nothing has been considered yet
 	}
+	considered := false // consider() has run: from here on a CPU re-walk would double-count
 	length := vectorLength(vector)
 	visited := make(map[uint64]bool)
 	k_counter := 0
@@ -417,11 +630,22 @@ func (m *gpuMirror) searchIndexBulk(c *Collection, tree *lshTree, vector []float
 		distOf := make(map[uint64]float64, len(want))
 		if len(want) > 0 {
 			d, ok := m.distancesTo(vector, want)
-			if !ok {
-				return false
+			if !ok && !considered {
+				return false // first window: the caller's closure state is untouched, it may walk on the CPU
 			}
 			for i, id := range want {
-				distOf[id] = d[i]
+				if ok {
+					distOf[id] = d[i]
+					continue
+				}
+				// a later window failed on the device: finish THIS walk in place with the reference's own
+				// c.distance (handing the walk back now would consider the earlier windows' documents twice)
+				doc, err := c.getDocument(id)
+				if err != nil {
+					distOf[id] = math.NaN() // getDocument errors stop the reference's search (collection.go:585-587)
+					continue
+				}
+				distOf[id] = c.distance(vector, doc.Vector)
 			}
 		}
 		// (3) the reference's loop body over the buffered leaves
@@ -437,6 +661,7 @@ func (m *gpuMirror) searchIndexBulk(c *Collection, tree *lshTree, vector []float
 					continue
 				}
 				visited[id] = true
+				considered = true
 				var signal int
 				signal, radius = considerWith(id, distOf[id], radius)
 				switch signal {
@@ -455,4 +680,77 @@ func (m *gpuMirror) searchIndexBulk(c *Collection, tree *lshTree, vector []float
 		}
 	}
 	return true
+}
+
+// ---- one process per GPU (SURVEY.md 8e) ------------------------------------------------------------------------
+//
+// A deployment that shards one collection's rows over the GPUs of a node runs one SyzgyDB process per GPU, each
+// holding a contiguous range of the records (the visit order cut into ranges; szg_index_set_row_base makes rows
+// global) and every query.  The exchange -- ONE ncclAllGather (RCCL over xGMI) of the per-rank top-(k+1) records
+// per batch and the reference's selection replayed over the union -- happens inside the library; the host only
+// hands the 128-byte communicator id from rank 0 to the others (its own RPC, a file, an environment variable).
+
+type gpuComm struct{ h *C.szg_comm }
+
+// commUniqueID is called on rank 0 only.
+func commUniqueID() ([]byte, error) {
+	id := make([]byte, C.SZG_COMM_ID_BYTES)
+	if rc := C.szg_comm_unique_id((*C.uint8_t)(unsafe.Pointer(&id[0]))); rc != C.SZG_OK {
+		return nil, fmt.Errorf("szg_comm_unique_id: %s", C.GoString(C.szg_last_error()))
+	}
+	return id, nil
+}
+
+// newGPUComm is collective: every rank calls it with the same id (ncclCommInitRank on `device`).
+func newGPUComm(id []byte, rank, world, device int) (*gpuComm, error) {
+	if len(id) != C.SZG_COMM_ID_BYTES {
+		return nil, fmt.Errorf("communicator id must be %d bytes", C.SZG_COMM_ID_BYTES)
+	}
+	cm := &gpuComm{}
+	rc := C.szg_comm_create(&cm.h, (*C.uint8_t)(unsafe.Pointer(&id[0])), C.int(rank), C.int(world), C.int(device))
+	if rc != C.SZG_OK {
+		return nil, fmt.Errorf("szg_comm_create: %s", C.GoString(C.szg_last_error()))
+	}
+	return cm, nil
+}
+
+func (cm *gpuComm) close() {
+	if cm.h != nil {
+		C.szg_comm_destroy(cm.h)
+		cm.h = nil
+	}
+}
+
+// attachComm: the mirror holds rows [rowBase, rowBase + len(ids)) of the sharded collection.
+func (m *gpuMirror) attachComm(cm *gpuComm, rowBase uint64) bool {
+	return C.szg_index_set_row_base(m.h, C.uint64_t(rowBase)) == C.SZG_OK &&
+		C.szg_index_attach_comm(m.h, cm.h) == C.SZG_OK
+}
+
+// searchExactSharded is collective: every rank calls it with the same queries and K and gets the
+// single-collection answer as GLOBAL rows (position in the unsharded visit order) with the reference's float64
+// distances; the rank that owns a row resolves it to its document.  historyDependent[i] reports equal distances
+// (or NaN) among the best K+1 of query i: the one case where the reference's order depends on its whole heap
+// history, which no single rank holds.
+func (m *gpuMirror) searchExactSharded(queries []float64, nq, k int) (rows []uint64, dist []float64, count []int32, historyDependent []bool, ok bool) {
+	m.mu.RLock()
+	defer m.mu.RUnlock()
+	if m.dirty || nq <= 0 || k <= 0 || len(queries) == 0 || len(queries)%nq != 0 {
+		return nil, nil, nil, nil, false
+	}
+	rows = make([]uint64, nq*k)
+	dist = make([]float64, nq*k)
+	count = make([]int32, nq)
+	hist := make([]C.uint8_t, nq)
+	rc := C.szg_search_topk_sharded(m.h, (*C.double)(unsafe.Pointer(&queries[0])), C.int(nq), C.int(k), nil,
+		(*C.uint64_t)(unsafe.Pointer(&rows[0])), (*C.double)(unsafe.Pointer(&dist[0])),
+		(*C.int32_t)(unsafe.Pointer(&count[0])), &hist[0])
+	if rc != C.SZG_OK {
+		return nil, nil, nil, nil, false
+	}
+	historyDependent = make([]bool, nq)
+	for i := range hist {
+		historyDependent[i] = hist[i] != 0
+	}
+	return rows, dist, count, historyDependent, true
 }

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SZG_ABI_VERSION 2
+#define SZG_ABI_VERSION 3
 
 /* DistanceMethod, collection.go:186-189 */
 #define SZG_EUCLIDEAN 0
@@ -127,6 +127,19 @@ int szg_search_radius(szg_index *ix, const double *query, double radius,
                       uint64_t capacity, uint64_t *out_total);
 
 /*
+ * Radius searches for a batch of queries, each with its own radius: the collect sweeps of the batch are walked
+ * query-major by one launch per 16 queries, several launches in flight (collection.go:598-605 per query).
+ *   allow_bits   NULL, or n_queries x ceil(rows/64) words
+ *   out_offsets  n_queries + 1 entries: the hits of query i are out_rows / out_dist [out_offsets[i], out_offsets[i+1]),
+ *                ascending distance
+ * When the hits do not fit `capacity` the call returns SZG_E_TRUNCATED with out_offsets complete (so
+ * out_offsets[n_queries] is the capacity to retry with) and the first `capacity` entries written.
+ */
+int szg_search_radius_batch(szg_index *ix, const double *queries, int n_queries, const double *radii,
+                            const uint64_t *allow_bits, uint64_t *out_rows, double *out_dist, uint64_t capacity,
+                            uint64_t *out_offsets);
+
+/*
  * The reference's float64 distance (c.distance, collection.go:596, :812-832) from
  * one query to each listed row, bit-identical to the reference: the gather-by-row
  * primitive for re-ranking candidates of the LSH path (lshtree.go:283-351 calls
@@ -167,6 +180,72 @@ int szg_merge_topk(int k, int n_lists, int list_len, int n_queries, const uint64
 int szg_merge_topk_records(int k, int n_lists, int list_len, int n_queries, const int64_t *records,
                            uint64_t *out_rows, double *out_dist, int32_t *out_count,
                            uint8_t *out_history_dependent);
+
+/* ---- one process per GPU: the exchange inside the library ----------------- */
+
+/*
+ * The loop collection.go:672-684 visits independent records, so the rows shard over the GPUs of a node in
+ * contiguous ranges, one process (and one handle) per GPU; szg_index_set_row_base makes the rows a rank returns
+ * global.  A sharded search runs the rank's own exact search on its range, exchanges the per-rank results with ONE
+ * all-gather per micro-batch -- RCCL (ncclAllGather over xGMI) on the rank's device -- and replays the reference's
+ * selection over the union on every rank, so every rank returns the single-collection answer.
+ *
+ * Set-up: rank 0 calls szg_comm_unique_id and hands the 128 bytes to the other ranks by whatever means the host
+ * has (a file, a socket, its own RPC); then EVERY rank calls szg_comm_create (collective: ncclCommInitRank) and
+ * attaches the communicator to its handle.  All sharded calls are collective too: every rank makes the same
+ * calls, in the same order, with the same queries.  One communicator serves any number of handles of the process.
+ */
+typedef struct szg_comm szg_comm;
+#define SZG_COMM_ID_BYTES 128
+int szg_comm_unique_id(uint8_t *id /* [SZG_COMM_ID_BYTES] */);
+int szg_comm_create(szg_comm **out, const uint8_t *id, int rank, int world, int device);
+/* The same with the host's own transport instead of RCCL: fn all-gathers bytes_per_rank bytes from every rank's
+ * `send` into `recv` ([world][bytes_per_rank], rank order) and returns 0.  Host memory only, no device needed
+ * (hosts with their own fabric; the tests: gloo on CPU, several ranks on one card). */
+typedef int (*szg_allgather_fn)(void *user, const void *send, void *recv, uint64_t bytes_per_rank);
+int szg_comm_create_host(szg_comm **out, szg_allgather_fn fn, void *user, int rank, int world);
+void szg_comm_destroy(szg_comm *c);
+/* Size the exchange staging for micro-batches of up to n_queries queries at this k ahead of time (it grows on
+ * demand otherwise -- a hipHostMalloc inside the first call that needs it). */
+int szg_comm_reserve(szg_comm *c, int n_queries, int k);
+/* The handle's sharded searches go through `c` (borrowed: destroy it after the handle, or attach NULL first). */
+int szg_index_attach_comm(szg_index *ix, szg_comm *c);
+
+/*
+ * szg_search_topk over the sharded collection.  allow_bits covers THIS rank's rows (n_queries x ceil(local rows / 64)
+ * words).  out_history_dependent (nullable, [n_queries]): 1 when two of the best k+1 merged distances are equal or
+ * NaN, i.e. the reference's order depends on its whole heap history, which no single rank holds.  More than 128
+ * queries are pipelined in micro-batches of 256: a worker thread sweeps the next one while this thread exchanges
+ * and merges.
+ */
+int szg_search_topk_sharded(szg_index *ix, const double *queries, int n_queries, int k, const uint64_t *allow_bits,
+                            uint64_t *out_rows, double *out_dist, int32_t *out_count, uint8_t *out_history_dependent);
+/* szg_search_radius_batch over the sharded collection: an all-gather of the hit counts, one padded all-gather of
+ * (row, distance) records, the reference's push-all / pop-all heap over the union in row order. */
+int szg_search_radius_sharded(szg_index *ix, const double *queries, int n_queries, const double *radii,
+                              const uint64_t *allow_bits, uint64_t *out_rows, double *out_dist, uint64_t capacity,
+                              uint64_t *out_offsets);
+/*
+ * The exchange-and-merge halves on their own (what the two calls above do after the rank's own search): the rank's
+ * exact top-(k+1) lists  rows / dist [n_queries][k+1], counts [n_queries]  (rows global)  ->  out_* [n_queries][k];
+ * the rank's radius hits in CSR form (offsets [n_queries + 1], rows global, ascending distance per query) -> the
+ * merged CSR.  Pure host code plus the transport.
+ */
+int szg_comm_merge_topk(szg_comm *c, int k, int n_queries, const uint64_t *rows, const double *dist,
+                        const int32_t *counts, uint64_t *out_rows, double *out_dist, int32_t *out_count,
+                        uint8_t *out_history_dependent);
+int szg_comm_merge_radius(szg_comm *c, int n_queries, const uint64_t *offsets, const uint64_t *rows,
+                          const double *dist, uint64_t *out_rows, double *out_dist, uint64_t capacity,
+                          uint64_t *out_offsets);
+
+typedef struct szg_comm_stats {
+    uint64_t exchanges;   /* all-gathers issued */
+    double exchange_us;   /* wall time inside them (copies + collective + wait) */
+    double host_us;       /* packing the records and merging the gathered lists */
+    int rccl_ranks;       /* ncclCommCount of the communicator (0: host transport) */
+} szg_comm_stats;
+int szg_comm_get_stats(szg_comm *c, szg_comm_stats *out);
+int szg_comm_reset_stats(szg_comm *c);
 
 /* ---- diagnostics -------------------------------------------------------- */
 
@@ -266,7 +345,9 @@ int szg_reset_stats(szg_index *ix);
  *                             batch's sweep (+3-6 % queries/s, the sweep itself 5 % slower)
  *     coalesce            1   concurrent szg_search_topk calls with ONE query each -- the
  *                             reference's Searches under RLock -- are answered together, up to 96
- *                             per shared sweep, by whichever caller finds no batch in flight
+ *                             per shared sweep, by whichever caller finds no batch in flight;
+ *                             concurrent szg_search_radius callers likewise share query-major
+ *                             collect launches (16 sweeps per launch, each with its own radius)
  *   tests / tuning hooks: force_escalate, lanes_per_row
  */
 int szg_set_option(szg_index *ix, const char *name, int64_t value);

@@ -127,7 +127,10 @@ double orc_bench_topk_faithful(const uint8_t *spans, const uint64_t *offsets, ui
  * documented splitmix64 stream in place of Go's math/rand (which cannot be reproduced here):
  * the forest is an input of the search, and parity of the search is defined on a given forest.
  * Documents are identified by their row.  PARITY UNPINNED beyond the restatement: the
- * reference's tests hold no known answers for this path (lshtree_test.go checks recall only).
+ * reference's tests hold no known answers for this path: its one check of it,
+ * TestCosineDistancePrecisionComparison (collection_test.go:23-103), asserts properties only (equal result
+ * counts, distances within 100 % of the exact ones, PercentSearched < 100) -- restated in
+ * tests/test_gpu_lsh.py::test_cosine_distance_precision_comparison_20000x3.
  */
 typedef struct orc_lsh orc_lsh;
 orc_lsh *orc_lsh_build(const uint8_t *rows /* borrowed until orc_lsh_free */, uint64_t n_rows, int dim, int bits,

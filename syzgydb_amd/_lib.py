@@ -31,7 +31,19 @@ EXPORTS = [
     "szg_strerror", "szg_last_error", "szg_abi_version", "szg_set_timing", "szg_get_stats",
     "szg_reset_stats", "szg_set_option", "szg_index_synth", "szg_index_set_row_base",
     "szg_merge_topk", "szg_merge_topk_records", "szg_index_append_f64", "szg_distances", "szg_pair_distances", "szg_index_overwrite_f64",
+    "szg_search_radius_batch", "szg_comm_unique_id", "szg_comm_create", "szg_comm_create_host", "szg_comm_destroy",
+    "szg_comm_reserve", "szg_index_attach_comm", "szg_search_topk_sharded", "szg_search_radius_sharded",
+    "szg_comm_merge_topk", "szg_comm_merge_radius", "szg_comm_get_stats", "szg_comm_reset_stats",
 ]
+SZG_COMM_ID_BYTES = 128
+# int (*szg_allgather_fn)(void *user, const void *send, void *recv, uint64_t bytes_per_rank)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64)
+
+
+class SzgCommStats(ctypes.Structure):
+    _fields_ = [("exchanges", ctypes.c_uint64), ("exchange_us", ctypes.c_double), ("host_us", ctypes.c_double),
+                ("rccl_ranks", ctypes.c_int)]
+
 # include/syzgy_pager.h
 PAGER_EXPORTS = [
     "szg_pager_open", "szg_pager_close", "szg_pager_options", "szg_pager_count", "szg_pager_skipped",
@@ -150,6 +162,32 @@ def load():
     L.szg_distances.argtypes = [vp, f64p, u64p, ctypes.c_uint64, f64p]
     L.szg_pair_distances.restype = ctypes.c_int
     L.szg_pair_distances.argtypes = [vp, u64p, u64p, ctypes.c_uint64, f64p]
+    L.szg_search_radius_batch.restype = ctypes.c_int
+    L.szg_search_radius_batch.argtypes = [vp, f64p, ctypes.c_int, f64p, u64p, u64p, f64p, ctypes.c_uint64, u64p]
+    L.szg_comm_unique_id.restype = ctypes.c_int
+    L.szg_comm_unique_id.argtypes = [u8p]
+    L.szg_comm_create.restype = ctypes.c_int
+    L.szg_comm_create.argtypes = [ctypes.POINTER(vp), u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.szg_comm_create_host.restype = ctypes.c_int
+    L.szg_comm_create_host.argtypes = [ctypes.POINTER(vp), ALLGATHER_FN, vp, ctypes.c_int, ctypes.c_int]
+    L.szg_comm_destroy.restype = None
+    L.szg_comm_destroy.argtypes = [vp]
+    L.szg_comm_reserve.restype = ctypes.c_int
+    L.szg_comm_reserve.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    L.szg_index_attach_comm.restype = ctypes.c_int
+    L.szg_index_attach_comm.argtypes = [vp, vp]
+    L.szg_search_topk_sharded.restype = ctypes.c_int
+    L.szg_search_topk_sharded.argtypes = [vp, f64p, ctypes.c_int, ctypes.c_int, u64p, u64p, f64p, i32p, u8p]
+    L.szg_search_radius_sharded.restype = ctypes.c_int
+    L.szg_search_radius_sharded.argtypes = [vp, f64p, ctypes.c_int, f64p, u64p, u64p, f64p, ctypes.c_uint64, u64p]
+    L.szg_comm_merge_topk.restype = ctypes.c_int
+    L.szg_comm_merge_topk.argtypes = [vp, ctypes.c_int, ctypes.c_int, u64p, f64p, i32p, u64p, f64p, i32p, u8p]
+    L.szg_comm_merge_radius.restype = ctypes.c_int
+    L.szg_comm_merge_radius.argtypes = [vp, ctypes.c_int, u64p, u64p, f64p, u64p, f64p, ctypes.c_uint64, u64p]
+    L.szg_comm_get_stats.restype = ctypes.c_int
+    L.szg_comm_get_stats.argtypes = [vp, ctypes.POINTER(SzgCommStats)]
+    L.szg_comm_reset_stats.restype = ctypes.c_int
+    L.szg_comm_reset_stats.argtypes = [vp]
     L.szg_pager_open.restype = ctypes.c_int
     L.szg_pager_open.argtypes = [ctypes.POINTER(vp), ctypes.c_char_p, ctypes.c_int]
     L.szg_pager_close.restype = None

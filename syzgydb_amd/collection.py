@@ -66,7 +66,7 @@ class SearchArgs:
 
 
 class Collection:
-    def __init__(self, options: CollectionOptions, devices=None, sketch=False):
+    def __init__(self, options: CollectionOptions, devices=None, sketch=False, strict_order=True):
         if options.Quantization == 0:
             options.Quantization = 64  # collection.go:254-256
         if options.DistanceMethod not in (Euclidean, Cosine):
@@ -89,13 +89,18 @@ class Collection:
         # collection does, so they are kept per (filter key, collection version)
         self._version = 0
         self._mask_cache = {}
-        # Rows are kept in the reference's deterministic visit order -- sort.Strings of the
-        # decimal ids (spanfile.go:540-560) -- because that order decides ties at the k boundary
-        # (collection.go:608).  A new id that sorts after every loaded one is appended in place;
-        # any other marks the mirror dirty and the next Search re-pages it in order (the same
-        # rule as go/syzgy_gpu.go).
+        # Row order only matters where the reference's own answer depends on its visit order: ties at the k
+        # boundary, equal distances in a radius result (collection.go:608).  Production iterates a Go map (random
+        # order per run, spanfile.go:525): every order is a reference order, rows are simply appended
+        # (strict_order=False).  The reference's deterministic mode (seeded tests, spanfile.go:522) pins the order
+        # to sort.Strings of the decimal ids; that is what the parity tests compare with, hence the default.  A new
+        # id is ALWAYS appended in place; one that sorts before the last ("10" < "9": ordinary ascending integers
+        # do that) only marks the order stale, and the mirror is re-paged in order the first time an answer
+        # actually contains such a tie -- not on every add (the same rule as go/syzgy_gpu.go).
+        self.strict_order = bool(strict_order)
         self._last_idstr = ""
-        self._dirty = False
+        self._order_stale = False
+        self.resorts = 0
 
     @classmethod
     def from_spanfile(cls, path, devices=None):
@@ -119,7 +124,7 @@ class Collection:
         """Row order bookkeeping for a new id appended at the end of the mirror."""
         s = str(id)
         if s < self._last_idstr:
-            self._dirty = True
+            self._order_stale = self.strict_order
         else:
             self._last_idstr = s
 
@@ -134,7 +139,8 @@ class Collection:
         self._meta = new_meta
         self._row_of = {id: i for i, id in enumerate(self._id_of)}
         self._last_idstr = live[-1][0] if live else ""
-        self._dirty = False
+        self._order_stale = False
+        self.resorts += 1
         self._version += 1  # rows are renumbered: cached filter masks no longer apply
 
     # -- CRUD (host bookkeeping + mirror maintenance) ---------------------------
@@ -279,20 +285,32 @@ class Collection:
                 if args.Limit > 0 and len(results) >= args.Limit:
                     break
         else:
-            if self._dirty:
-                self._resort()
             q = np.asarray(args.Vector, dtype=np.float64).reshape(-1)
             if q.size != self.DimensionCount:
                 # undefined in the reference (collection.go:814, :823); rejected here
                 raise ValueError("query length %d != dimension %d" % (q.size, self.DimensionCount))
-            allow = self._allow_mask(args.Filter, getattr(args, "FilterKey", None)) if n_records else None
-            if n_records == 0:
-                rows, dist = [], []
-            elif args.Radius > 0:  # K is ignored (collection.go:598-605)
-                rows, dist = self._index.search_radius(q, args.Radius, allow=allow)
-            else:
+
+            def scan():
+                allow = self._allow_mask(args.Filter, getattr(args, "FilterKey", None)) if n_records else None
+                if n_records == 0:
+                    return [], []
+                if args.Radius > 0:  # K is ignored (collection.go:598-605)
+                    return self._index.search_radius(q, args.Radius, allow=allow)
                 r, d, c = self._index.search_topk(q, args.K, allow=allow)
-                rows, dist = r[0, : c[0]], d[0, : c[0]]
+                return r[0, : c[0]], d[0, : c[0]]
+            if self._order_stale:
+                # rows out of sort.Strings order: did the answer depend on the visit order?  (the library re-answers
+                # ties among the best k+1 by an exact replay in ROW order and counts it; a radius result depends on
+                # the order when two of its distances are equal)
+                before = self._index.stats()["full_replays"]
+                rows, dist = scan()
+                tie = self._index.stats()["full_replays"] != before or \
+                    (args.Radius > 0 and len(set(float(x) for x in dist)) != len(dist))
+                if tie:
+                    self._resort()
+                    rows, dist = scan()
+            else:
+                rows, dist = scan()
             for row, dd in zip(rows, dist):
                 row = int(row)
                 results.append(SearchResult(ID=self._id_of[row], Metadata=self._meta[row],
@@ -301,3 +319,40 @@ class Collection:
 
         percent = float(points_searched) / float(n_records) * 100 if n_records else 0.0
         return SearchResults(Results=results, PercentSearched=percent)
+
+    def SearchBatch(self, args_list) -> List[SearchResults]:
+        """Exact Searches of a caller that holds many queries (not in the reference, whose REST endpoint is
+        single-query, rest.go:371-487): top-k Searches with one K share ONE szg_search_topk call -- and with it
+        sweeps on the matrix cores --, radius Searches one szg_search_radius_batch; each query keeps its own
+        Filter.  Anything else (listing mode, mixed kinds) is answered Search by Search.  Same results as Search."""
+        args_list = list(args_list)
+        n_records = len(self._row_of)
+        if not args_list:
+            return []
+        radius = args_list[0].Radius > 0
+        same = all((a.Radius > 0) == radius and (radius or (a.K == args_list[0].K and a.K > 0)) for a in args_list)
+        if not same or n_records == 0:
+            return [self.Search(a) for a in args_list]
+        if self._order_stale:
+            self._resort()   # (a batch is not worth the tie bookkeeping: deterministic mode re-pages first)
+        Q = np.stack([np.asarray(a.Vector, dtype=np.float64).reshape(-1) for a in args_list])
+        if Q.shape[1] != self.DimensionCount:
+            raise ValueError("query length %d != dimension %d" % (Q.shape[1], self.DimensionCount))
+        allow = None
+        if any(a.Filter is not None for a in args_list):
+            words = (len(self._id_of) + 63) // 64
+            allow = np.full((len(args_list), words), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+            for i, a in enumerate(args_list):
+                if a.Filter is not None:
+                    allow[i] = self._allow_mask(a.Filter, getattr(a, "FilterKey", None)).reshape(-1)
+        out = []
+        if radius:
+            hits = self._index.search_radius_batch(Q, [a.Radius for a in args_list], allow=allow)
+        else:
+            r, d, c = self._index.search_topk(Q, args_list[0].K, allow=allow)
+            hits = [(r[i, : c[i]], d[i, : c[i]]) for i in range(len(args_list))]
+        for rows, dist in hits:
+            res = [SearchResult(ID=self._id_of[int(row)], Metadata=self._meta[int(row)], Distance=float(dd))
+                   for row, dd in zip(rows, dist)]
+            out.append(SearchResults(Results=res, PercentSearched=100.0))
+        return out

@@ -90,6 +90,11 @@ __host__ __device__ inline size_t query_lds_bytes(int qbits, int r16)
 
 constexpr int kMaxSweepsPerLaunch = 16;
 
+// Hit counters of the fused selection sit one per 128-byte line: the waves claim their slots
+// with returning atomics, mostly at the end of the sweep, and atomics on one line serialise
+// (~12 ns each) -- 48 counters in two lines made a 46 us tail on a 190 us sweep.
+constexpr int kCandCountStride = 32;  // 32-bit words
+
 // Exact integer shared sweep (mq_score_i8_kernel): the query as kMqPlanes balanced int8 digit
 // planes of radix 128.  Every plane costs one MFMA and one 16-byte LDS read per query block
 // and 64-byte row step; 2 planes (|Q| <= 16000, ~14 bits) keep the certification bound at
@@ -128,9 +133,11 @@ struct ScanArgs {
                                 // (most rows pass); 0 = rows are tested before their loads are issued
     int kp;                     // candidates kept per list (top-k mode)
     uint64_t *block_lists;      // [n_queries][grid][kp] sorted ascending (top-k mode)
-    // collect mode (radius search / escalation): every row with key <= thr is appended
+    // collect mode (radius search / escalation): every row of sweep s with key <= thr_ukeys[s] is appended to
+    // collect_buf + s * collect_cap; the sweep's hit counter is collect_count[s * kCandCountStride] (it may
+    // exceed collect_cap: the caller then reruns that query with a larger buffer)
     int collect;
-    uint32_t thr_ukey;
+    uint32_t thr_ukeys[kMaxSweepsPerLaunch];
     uint64_t *collect_buf;
     uint32_t collect_cap;
     uint32_t *collect_count;
@@ -178,10 +185,6 @@ struct MqArgs {
     const uint64_t *allow_bits;  // nullable, per query
     uint32_t allow_stride;
 };
-// Hit counters of the fused selection sit one per 128-byte line: the waves claim their slots
-// with returning atomics, mostly at the end of the sweep, and atomics on one line serialise
-// (~12 ns each) -- 48 counters in two lines made a 46 us tail on a 190 us sweep.
-constexpr int kCandCountStride = 32;  // 32-bit words
 // thr[q] = key of the kp-th entry of query q's sorted list (3.0e38 if the list is shorter)
 hipError_t launch_mq_thr(const uint64_t *lists, int kp, int n_queries, float *thr, hipStream_t stream);
 // per query: the kp best of its candidate buffer, sorted, as one list [n_queries][kp]
@@ -230,9 +233,12 @@ struct RerankOut {
 
 // Exact float64 distances, reference operation order, for n candidates of each of
 // n_queries queries: query_f64 [n_queries][dim], cands/out [n_queries][n_cands_max].
+// n_cands_dev (nullable): the candidate count of query q is min(n_cands_dev[q * n_dev_stride], n_cands_max), read on
+// the device (collect sweeps: the hit counters, no host round trip between the sweep and its re-rank).
 hipError_t launch_rerank(int qbits, int metric, const uint8_t *rows, RowLayout layout, int dim,
                          const double *query_f64, const uint64_t *cands, const uint32_t *n_cands_dev,
-                         uint32_t n_cands_max, int n_queries, RerankOut *out, hipStream_t stream);
+                         uint32_t n_cands_max, int n_queries, RerankOut *out, hipStream_t stream,
+                         uint32_t n_dev_stride = 0);
 
 // The same for pairs of STORED rows (computeAverageDistance, collection.go:372-398): out[i] =
 // c.distance(row left_rows[i], row (uint32)right_cands[i]), both decoded exactly on the device.

@@ -147,7 +147,7 @@ __device__ __forceinline__ double ordered_sum(double s, const double *p, int n)
 template <int QBITS, int METRIC>
 __global__ __launch_bounds__(64) void rerank_kernel(const uint8_t *rows, RowLayout lay, int dim,
                                                     const double *query, const uint64_t *cands,
-                                                    const uint32_t *n_dev, uint32_t n_max,
+                                                    const uint32_t *n_dev, uint32_t n_dev_stride, uint32_t n_max,
                                                     RerankOut *out, const uint32_t *left_rows)
 {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64) void rerank_kernel(const uint8_t *rows, RowLayo
     double *p2 = p1 + CH;                           // y*y
     const int lane = threadIdx.x;
     uint32_t n = n_max;
-    if (n_dev) n = min(*n_dev, n_max);
+    if (n_dev) n = min(n_dev[(size_t)blockIdx.y * n_dev_stride], n_max);
     query += (size_t)blockIdx.y * dim;           // blockIdx.y = query of the batch
     if (cands) cands += (size_t)blockIdx.y * n_max;
     out += (size_t)blockIdx.y * n_max;
@@ -478,17 +478,17 @@ template <int QBITS>
 hipError_t launch_rerank_q(int metric, const uint8_t *rows, RowLayout lay, int dim,
                            const double *q, const uint64_t *cands, const uint32_t *n_dev,
                            uint32_t n_max, int n_queries, RerankOut *out, hipStream_t stream,
-                           const uint32_t *left_rows = nullptr)
+                           const uint32_t *left_rows = nullptr, uint32_t n_dev_stride = 0)
 {
     if (n_max == 0 || n_queries == 0) return hipSuccess;
     const dim3 grid(n_max < 4096u ? n_max : 4096u, n_queries);
     const size_t lds = (size_t)1024 * 3 * sizeof(double);
     if (metric == kCosine)
         hipLaunchKernelGGL((rerank_kernel<QBITS, kCosine>), grid, dim3(64), lds, stream, rows,
-                           lay, dim, q, cands, n_dev, n_max, out, left_rows);
+                           lay, dim, q, cands, n_dev, n_dev_stride, n_max, out, left_rows);
     else
         hipLaunchKernelGGL((rerank_kernel<QBITS, kEuclidean>), grid, dim3(64), lds, stream,
-                           rows, lay, dim, q, cands, n_dev, n_max, out, left_rows);
+                           rows, lay, dim, q, cands, n_dev, n_dev_stride, n_max, out, left_rows);
     return hipGetLastError();
 }
 
@@ -496,14 +496,14 @@ hipError_t launch_rerank_q(int metric, const uint8_t *rows, RowLayout lay, int d
 
 hipError_t launch_rerank(int qbits, int metric, const uint8_t *rows, RowLayout pitch, int dim,
                          const double *q, const uint64_t *cands, const uint32_t *n_dev,
-                         uint32_t n_max, int n_queries, RerankOut *out, hipStream_t stream)
+                         uint32_t n_max, int n_queries, RerankOut *out, hipStream_t stream, uint32_t n_dev_stride)
 {
     switch (qbits) {
-    case 4: return launch_rerank_q<4>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream);
-    case 8: return launch_rerank_q<8>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream);
-    case 16: return launch_rerank_q<16>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream);
-    case 32: return launch_rerank_q<32>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream);
-    case 64: return launch_rerank_q<64>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream);
+    case 4: return launch_rerank_q<4>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream, nullptr, n_dev_stride);
+    case 8: return launch_rerank_q<8>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream, nullptr, n_dev_stride);
+    case 16: return launch_rerank_q<16>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream, nullptr, n_dev_stride);
+    case 32: return launch_rerank_q<32>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream, nullptr, n_dev_stride);
+    case 64: return launch_rerank_q<64>(metric, rows, pitch, dim, q, cands, n_dev, n_max, n_queries, out, stream, nullptr, n_dev_stride);
     default: return hipErrorInvalidValue;
     }
 }

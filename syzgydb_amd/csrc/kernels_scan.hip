@@ -451,7 +451,10 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
     // The common case after warm-up -- no row of the step can enter the list -- costs one float
     // compare and one wave-uniform branch; clamping, the ordered 64-bit candidate and the exact
     // comparison happen only behind it.
-    [[maybe_unused]] const float thr_key = COLLECT ? key_from_ordered(a.thr_ukey) : 0.0f;
+    [[maybe_unused]] const uint32_t thr_ukey = COLLECT ? a.thr_ukeys[qi] : 0u;  // per sweep: radius / escalation threshold
+    [[maybe_unused]] const float thr_key = COLLECT ? key_from_ordered(thr_ukey) : 0.0f;
+    [[maybe_unused]] uint64_t *const cbuf = COLLECT ? a.collect_buf + (size_t)qi * a.collect_cap : nullptr;
+    [[maybe_unused]] uint32_t *const ccount = COLLECT ? a.collect_count + (size_t)qi * kCandCountStride : nullptr;
     auto finish_row = [&](uint64_t row0, bool valid, RowAcc<QBITS, METRIC> &acc) {
         float key;
         if constexpr (QBITS == 4 && LL != 0 && PP <= 12)
@@ -466,16 +469,16 @@ __global__ __launch_bounds__(256, SZG_MIN_BLOCKS) void scan_kernel(const ScanArg
         const uint64_t c = ((uint64_t)ordered_key(key) << 32) | row;
 
         if (COLLECT) {
-            const bool hit = maybe && (uint32_t)(c >> 32) <= a.thr_ukey;
+            const bool hit = maybe && (uint32_t)(c >> 32) <= thr_ukey;
             const uint64_t m = __ballot(hit);
             if (m) {
                 const int first = __ffsll((long long)m) - 1;
                 uint32_t base = 0;
-                if (lane == first) base = atomicAdd(a.collect_count, (uint32_t)__popcll(m));
+                if (lane == first) base = atomicAdd(ccount, (uint32_t)__popcll(m));
                 base = __shfl(base, first);
                 if (hit) {
                     const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (idx < a.collect_cap) a.collect_buf[idx] = c;
+                    if (idx < a.collect_cap) cbuf[idx] = c;
                 }
             }
         } else {

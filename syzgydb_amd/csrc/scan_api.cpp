@@ -160,6 +160,140 @@ int szg_pair_distances(szg_index *ix, const uint64_t *rows_a, const uint64_t *ro
     SZG_CATCH
 }
 
+}  // extern "C"
+
+namespace {
+
+// min(total, capacity) closest hits of a radius search into the caller's buffers (global rows)
+int radius_output(const szg_index *ix, const std::vector<HeapItem> &hits, uint64_t *out_rows, double *out_dist,
+                  uint64_t capacity, uint64_t *out_total)
+{
+    const uint64_t total = hits.size();
+    *out_total = total;
+    for (uint64_t i = 0; i < total && i < capacity; i++) {
+        out_rows[i] = hits[i].row + ix->row_base;
+        out_dist[i] = hits[i].priority;
+    }
+    if (total > capacity) return fail(SZG_E_TRUNCATED, "radius search: capacity too small");
+    return SZG_OK;
+}
+
+// One batch of coalesced single-query callers of the same kind (top-k with the same k, or radius searches -- each
+// with its own radius): answered through one call of the batch path, results handed to every caller's own buffers.
+struct BatchScratch {
+    std::vector<double> q, dist, radii;
+    std::vector<uint64_t> rows;
+    std::vector<int32_t> count;
+    std::vector<const uint64_t *> masks;
+    std::vector<std::vector<HeapItem>> hits;
+};
+
+void serve_batch(szg_index *ix, const std::vector<PendingSearch *> &batch, BatchScratch &w)
+{
+    const int nq = (int)batch.size();
+    const bool radius = batch[0]->radius > 0;
+    int rc = SZG_OK;
+    try {
+        w.q.resize((size_t)nq * ix->dim);
+        w.masks.resize(nq);
+        bool any = false;
+        for (int i = 0; i < nq; i++) {
+            memcpy(&w.q[(size_t)i * ix->dim], batch[i]->query, sizeof(double) * ix->dim);
+            w.masks[i] = batch[i]->allow;  // each caller's own filter, if it has one
+            any |= w.masks[i] != nullptr;
+        }
+        if (radius) {
+            w.radii.resize(nq);
+            for (int i = 0; i < nq; i++) w.radii[i] = batch[i]->radius;
+            rc = search_radius_impl(ix, w.q.data(), nq, w.radii.data(), any ? w.masks.data() : nullptr, &w.hits);
+            for (int i = 0; i < nq; i++) {
+                PendingSearch *p = batch[i];
+                p->rc = rc ? rc : radius_output(ix, w.hits[i], p->out_rows, p->out_dist, p->capacity, p->out_total);
+            }
+            return;
+        }
+        const int kk = batch[0]->k;
+        if (nq == 1) {
+            PendingSearch *p = batch[0];
+            rc = search_topk_any(ix, p->query, 1, kk, p->allow, p->out_rows, p->out_dist, p->out_count);
+        } else {
+            w.rows.resize((size_t)nq * kk);
+            w.dist.resize((size_t)nq * kk);
+            w.count.resize(nq);
+            rc = search_topk_any(ix, w.q.data(), nq, kk, nullptr, w.rows.data(), w.dist.data(), w.count.data(),
+                                 any ? w.masks.data() : nullptr);
+            for (int i = 0; i < nq && rc == SZG_OK; i++) {
+                memcpy(batch[i]->out_rows, &w.rows[(size_t)i * kk], sizeof(uint64_t) * kk);
+                memcpy(batch[i]->out_dist, &w.dist[(size_t)i * kk], sizeof(double) * kk);
+                if (batch[i]->out_count) *batch[i]->out_count = w.count[i];
+            }
+        }
+    } catch (const std::bad_alloc &) {
+        rc = fail(SZG_E_NOMEM, "out of memory (host)");
+    } catch (...) {
+        rc = fail(SZG_E_DEVICE, "unexpected exception");
+    }
+    for (PendingSearch *p : batch) p->rc = rc;
+}
+
+// Search holds only RLock in the reference (collection.go:570), so many goroutines call in at once, each with ONE
+// query.  Whoever finds no batch in flight becomes the leader: it answers everything that is waiting and is of one
+// kind as one batch (one shared sweep, or one query-major collect launch, instead of one launch per caller), then
+// hands the lead to a waiter once its own answer has arrived.  A lone caller is its own batch of one and pays
+// nothing for this.
+int combine(szg_index *ix, PendingSearch &me)
+{
+    std::vector<PendingSearch *> batch;
+    std::unique_lock<std::mutex> lk(ix->comb_mu);
+    try {
+        batch.reserve(kMaxBatch);  // nothing below that touches the combiner's state may throw
+        ix->comb_waiting.push_back(&me);
+    } catch (...) {
+        return fail(SZG_E_NOMEM, "out of memory (host)");
+    }
+    if (ix->comb_leader) {
+        me.cv.wait(lk, [&] { return me.done || me.lead; });
+        if (me.done) {
+            if (me.rc) (void)fail(me.rc, szg_strerror(me.rc));  // (the error text lives on the leader's thread)
+            return me.rc;
+        }
+    }
+    ix->comb_leader = true;
+    BatchScratch scratch;
+    while (!me.done) {
+        batch.clear();
+        const PendingSearch *head = ix->comb_waiting.front();  // never empty here: `me` is in it until done
+        const bool radius = head->radius > 0;
+        for (auto it = ix->comb_waiting.begin(); it != ix->comb_waiting.end() && batch.size() < (size_t)kMaxBatch;) {
+            const bool same = radius ? (*it)->radius > 0 : ((*it)->radius == 0 && (*it)->k == head->k);
+            if (same) {
+                batch.push_back(*it);  // within the reserved capacity
+                it = ix->comb_waiting.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        lk.unlock();
+        serve_batch(ix, batch, scratch);
+        lk.lock();
+        for (PendingSearch *p : batch) {
+            p->done = true;
+            if (p != &me) p->cv.notify_one();
+        }
+    }
+    if (!ix->comb_waiting.empty()) {
+        ix->comb_waiting.front()->lead = true;  // it stays queued and forms the next batch itself
+        ix->comb_waiting.front()->cv.notify_one();
+    } else {
+        ix->comb_leader = false;
+    }
+    return me.rc;
+}
+
+}  // namespace
+
+extern "C" {
+
 int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
                     const uint64_t *allow_bits, uint64_t *out_rows, double *out_dist,
                     int32_t *out_count)
@@ -180,12 +314,6 @@ int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
         return search_topk_any(ix, queries, n_queries, k, allow_bits, out_rows, out_dist, out_count);
         SZG_CATCH
     }
-
-    // Search holds only RLock in the reference (collection.go:570), so many goroutines call in
-    // at once, each with ONE query.  Whoever finds no batch in flight becomes the leader: it
-    // answers everything that is waiting with the same k as one batch (one shared sweep instead
-    // of one sweep per caller), then hands the lead to a waiter if its own answer has arrived.
-    // A lone caller is its own batch of one and pays nothing for this.
     PendingSearch me;
     me.query = queries;
     me.allow = allow_bits;
@@ -193,148 +321,74 @@ int szg_search_topk(szg_index *ix, const double *queries, int n_queries, int k,
     me.out_rows = out_rows;
     me.out_dist = out_dist;
     me.out_count = out_count;
-    std::vector<PendingSearch *> batch;
-    std::unique_lock<std::mutex> lk(ix->comb_mu);
-    try {
-        batch.reserve(kMaxBatch);  // nothing below that touches the combiner's state may throw
-        ix->comb_waiting.push_back(&me);
-    } catch (...) {
-        return fail(SZG_E_NOMEM, "out of memory (host)");
-    }
-    if (ix->comb_leader) {
-        me.cv.wait(lk, [&] { return me.done || me.lead; });
-        if (me.done) return me.rc;
-    }
-    ix->comb_leader = true;
-    std::vector<double> q;
-    std::vector<uint64_t> rows;
-    std::vector<double> dist;
-    std::vector<int32_t> count;
-    std::vector<const uint64_t *> masks;
-    while (!me.done) {
-        batch.clear();
-        const int kk = ix->comb_waiting.front()->k;  // never empty here: `me` is in it until done
-        for (auto it = ix->comb_waiting.begin(); it != ix->comb_waiting.end() && batch.size() < (size_t)kMaxBatch;) {
-            if ((*it)->k == kk) {
-                batch.push_back(*it);  // within the reserved capacity
-                it = ix->comb_waiting.erase(it);
-            } else {
-                ++it;
-            }
-        }
-        lk.unlock();
-        const int nq = (int)batch.size();
-        int rc;
-        try {
-            if (nq == 1) {
-                PendingSearch *p = batch[0];
-                rc = search_topk_any(ix, p->query, 1, kk, p->allow, p->out_rows, p->out_dist, p->out_count);
-            } else {
-                q.resize((size_t)nq * ix->dim);
-                rows.resize((size_t)nq * kk);
-                dist.resize((size_t)nq * kk);
-                count.resize(nq);
-                masks.resize(nq);
-                bool any = false;
-                for (int i = 0; i < nq; i++) {
-                    memcpy(&q[(size_t)i * ix->dim], batch[i]->query, sizeof(double) * ix->dim);
-                    masks[i] = batch[i]->allow;  // each caller's own filter, if it has one
-                    any |= masks[i] != nullptr;
-                }
-                rc = search_topk_any(ix, q.data(), nq, kk, nullptr, rows.data(), dist.data(), count.data(),
-                                      any ? masks.data() : nullptr);
-                for (int i = 0; i < nq && rc == SZG_OK; i++) {
-                    memcpy(batch[i]->out_rows, &rows[(size_t)i * kk], sizeof(uint64_t) * kk);
-                    memcpy(batch[i]->out_dist, &dist[(size_t)i * kk], sizeof(double) * kk);
-                    if (batch[i]->out_count) *batch[i]->out_count = count[i];
-                }
-            }
-        } catch (const std::bad_alloc &) {
-            rc = fail(SZG_E_NOMEM, "out of memory (host)");
-        } catch (...) {
-            rc = fail(SZG_E_DEVICE, "unexpected exception");
-        }
-        lk.lock();
-        for (PendingSearch *p : batch) {
-            p->rc = rc;
-            p->done = true;
-            if (p != &me) p->cv.notify_one();
-        }
-    }
-    if (!ix->comb_waiting.empty()) {
-        ix->comb_waiting.front()->lead = true;  // it stays queued and forms the next batch itself
-        ix->comb_waiting.front()->cv.notify_one();
-    } else {
-        ix->comb_leader = false;
-    }
-    return me.rc;
+    return combine(ix, me);
 }
 
 int szg_search_radius(szg_index *ix, const double *query, double radius,
                       const uint64_t *allow_bits, uint64_t *out_rows, double *out_dist,
                       uint64_t capacity, uint64_t *out_total)
 {
-    SZG_TRY
     if (!ix || !query || !out_total) return fail(SZG_E_INVALID, "null argument");
     if (!(radius > 0)) return fail(SZG_E_INVALID, "radius must be > 0 (collection.go:598)");
     if (capacity && (!out_rows || !out_dist)) return fail(SZG_E_INVALID, "null output buffer");
     *out_total = 0;
+    if (szg_index_rows(ix) == 0) return SZG_OK;
+    if (!ix->coalesce) {
+        SZG_TRY
+        std::vector<std::vector<HeapItem>> hits;
+        const int rc = search_radius_impl(ix, query, 1, &radius, allow_bits ? &allow_bits : nullptr, &hits);
+        if (rc) return rc;
+        return radius_output(ix, hits[0], out_rows, out_dist, capacity, out_total);
+        SZG_CATCH
+    }
+    // concurrent callers (the reference's Searches under RLock) share query-major collect launches
+    PendingSearch me;
+    me.query = query;
+    me.allow = allow_bits;
+    me.k = 0;
+    me.radius = radius;
+    me.out_rows = out_rows;
+    me.out_dist = out_dist;
+    me.capacity = capacity;
+    me.out_total = out_total;
+    return combine(ix, me);
+}
+
+int szg_search_radius_batch(szg_index *ix, const double *queries, int n_queries, const double *radii,
+                            const uint64_t *allow_bits, uint64_t *out_rows, double *out_dist, uint64_t capacity,
+                            uint64_t *out_offsets)
+{
+    SZG_TRY
+    if (!ix || !queries || !radii || !out_offsets) return fail(SZG_E_INVALID, "null argument");
+    if (n_queries < 0) return fail(SZG_E_INVALID, "n_queries < 0");
+    if (capacity && (!out_rows || !out_dist)) return fail(SZG_E_INVALID, "null output buffer");
+    for (int i = 0; i < n_queries; i++)
+        if (!(radii[i] > 0)) return fail(SZG_E_INVALID, "radius must be > 0 (collection.go:598)");
+    for (int i = 0; i <= n_queries; i++) out_offsets[i] = 0;
     const uint64_t total_rows = szg_index_rows(ix);
-    if (total_rows == 0) return SZG_OK;
-
-    // key threshold that surely contains every row with distance <= radius
-    QMeta meta;
-    std::vector<uint8_t> tmp(ix->qsw_bytes);
-    prep_query(ix, query, tmp.data(), &meta);
-    const double m1 = meta.m1;
-    float thr_f;
-    if (ix->metric == SZG_COSINE) {
-        if (radius >= 1.0 || m1 == 0) {
-            thr_f = 3.0e38f;  // acos(c)/pi <= 1 always; zero query -> all 1.0
-        } else {
-            const double t = -std::cos(M_PI * radius) + 2.0 * key_eps(ix, 1.0, meta) + 1e-12;
-            thr_f = std::nextafter((float)t, INFINITY);
-        }
-    } else {
-        const double scale = ix->bits <= 16 ? (double)((1u << ix->bits) - 1u) : 1.0;
-        const double kk = (radius * scale) * (radius * scale);
-        const double t = kk * (1.0 + 1e-12) + 2.0 * key_eps(ix, kk, meta);
-        // (an infinite radius with a zero query makes t = inf + 0 * inf = NaN: everything, as for any t beyond the floats)
-        thr_f = !(t < 3.0e38) ? 3.0e38f : std::nextafter((float)t, INFINITY);
+    if (n_queries == 0 || total_rows == 0) return SZG_OK;
+    const size_t words = (size_t)((total_rows + 63) / 64);
+    std::vector<const uint64_t *> masks;
+    if (allow_bits) {
+        masks.resize(n_queries);
+        for (int i = 0; i < n_queries; i++) masks[i] = allow_bits + (size_t)i * words;
     }
-
-    std::vector<Cand> cands;
-    int rc = SZG_OK;
-    for (size_t s = 0; s < ix->shards.size() && rc == SZG_OK; s++) {
-        Shard *sh = ix->shards[s];
-        if (sh->n_rows == 0) continue;
-        Ctx *c = ctx_acquire(sh);
-        CtxGuard guard{sh, c};
-        memcpy(c->h_qsw, tmp.data(), ix->qsw_bytes);
-        c->meta[0] = meta;
-        rc = enqueue_queries(ix, sh, c, query, 1, allow_bits ? &allow_bits : nullptr);
-        if (rc == SZG_OK) rc = run_collect(ix, sh, c, 0, thr_f, allow_bits != nullptr, &cands);
-    }
+    std::vector<std::vector<HeapItem>> hits;
+    const int rc = search_radius_impl(ix, queries, n_queries, radii, allow_bits ? masks.data() : nullptr, &hits);
     if (rc) return rc;
-    // consider()'s radius branch (collection.go:598-605) in visit order, then the pop loop
-    std::sort(cands.begin(), cands.end(), [](const Cand &x, const Cand &y) { return x.row < y.row; });
-    GoHeap h;
-    for (const Cand &c : cands)
-        if (c.dist <= radius) h.push(HeapItem{c.row, c.dist});
-    const uint64_t total = h.a.size();
-    *out_total = total;
-    for (uint64_t i = total; i-- > 0;) {
-        const HeapItem it = h.pop();
-        if (i < capacity) {
-            out_rows[i] = it.row + ix->row_base;
-            out_dist[i] = it.priority;
+    uint64_t off = 0;
+    for (int i = 0; i < n_queries; i++) {
+        out_offsets[i] = off;
+        for (const HeapItem &h : hits[i]) {
+            if (off < capacity) {
+                out_rows[off] = h.row + ix->row_base;
+                out_dist[off] = h.priority;
+            }
+            off++;
         }
     }
-    {
-        std::lock_guard<std::mutex> lk(ix->stats_mu);
-        ix->stats.queries++;
-    }
-    if (total > capacity) return fail(SZG_E_TRUNCATED, "radius search: capacity too small");
+    out_offsets[n_queries] = off;
+    if (off > capacity) return fail(SZG_E_TRUNCATED, "radius search: capacity too small");
     return SZG_OK;
     SZG_CATCH
 }

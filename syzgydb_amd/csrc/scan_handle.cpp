@@ -18,10 +18,12 @@ int ctx_alloc(szg_index *ix, Shard *sh, Ctx **out)
     const size_t B = kMaxBatch;
     HIPCHK(hipHostMalloc((void **)&c->h_qsw, B * ix->qsw_bytes, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_q64, B * sizeof(double) * ix->dim, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&c->h_count, sizeof(uint32_t) * 4, hipHostMallocDefault));
+    // hit counters of the collect sweeps, one 128-byte line per sweep of a launch
+    const size_t n_count = (size_t)szg::kMaxSweepsPerLaunch * szg::kCandCountStride;
+    HIPCHK(hipHostMalloc((void **)&c->h_count, sizeof(uint32_t) * n_count, hipHostMallocDefault));
     HIPCHK(hipMalloc((void **)&c->d_qsw, B * ix->qsw_bytes));
     HIPCHK(hipMalloc((void **)&c->d_q64, B * sizeof(double) * ix->dim));
-    HIPCHK(hipMalloc((void **)&c->d_count, sizeof(uint32_t) * 4));
+    HIPCHK(hipMalloc((void **)&c->d_count, sizeof(uint32_t) * n_count));
     return SZG_OK;
 }
 

@@ -186,7 +186,8 @@ struct Ctx {
     size_t allow_cap = 0;          // words
     uint64_t *d_collect = nullptr;
     size_t collect_cap = 0;        // entries
-    uint32_t *d_count = nullptr;
+    uint32_t *d_count = nullptr;   // hit counters of collect sweeps, one 128-byte line per sweep of a launch
+    size_t radius_cap = 0;         // radius batches: entries per sweep the next batch's buffers get (follows the hit counts seen)
     // multi-query sweep: LDS image of the batch, score matrix
     uint8_t *h_mq = nullptr, *d_mq = nullptr;
     int32_t *h_mqQ = nullptr;      // 4-bit int8 sweep: the queries as integers (kMaxBatch x dim)
@@ -257,14 +258,17 @@ struct Shard {
 
 }  // namespace szgi
 
-// One caller of szg_search_topk(n_queries == 1) waiting to be answered as part of a batch.
+// One caller of szg_search_topk(n_queries == 1) or szg_search_radius waiting to be answered as part of a batch.
 struct PendingSearch {
     const double *query;
     const uint64_t *allow;  // the caller's filter mask, or nullptr
-    int k;
+    int k;                  // top-k search (radius == 0)
+    double radius = 0;      // > 0: radius search (k ignored, collection.go:598-605)
     uint64_t *out_rows;
     double *out_dist;
-    int32_t *out_count;
+    int32_t *out_count = nullptr;   // top-k
+    uint64_t capacity = 0;          // radius: room in out_rows / out_dist
+    uint64_t *out_total = nullptr;  // radius: the full hit count
     int rc = 0;
     bool done = false;
     bool lead = false;  // told to take over as the batch leader
@@ -333,6 +337,7 @@ struct szg_index {
     std::deque<struct PendingSearch *> comb_waiting;
     bool comb_leader = false;
     szg_stats stats{};
+    szg_comm *comm = nullptr;    // one process per GPU: the attached communicator (borrowed; scan_comm.cpp)
 };
 
 namespace szgi {
@@ -386,10 +391,17 @@ int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg
 int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allow);
 int finish_timing(szg_index *ix, Ctx *c);
 int run_collect(szg_index *ix, Shard *sh, Ctx *c, int slot, float thr_key, bool has_allow, std::vector<Cand> *cands);
+// fraction of the shard's rows that staged query `slot` may visit (tombstones, and a sample of its filter mask's words)
+double mask_pass_rate(const Shard *sh, const Ctx *c, bool has_allow, int slot);
 void first_eligible_rows(const szg_index *ix, const uint64_t *allow, int k, std::vector<uint64_t> *rows_out);
 int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k, const uint64_t *allow_bits,
                      uint64_t *out_rows, double *out_dist, int32_t *out_count,
                      const uint64_t *const *allow_ptrs = nullptr);
+
+// ---- scan_radius.cpp
+// radius searches for a batch of queries (own radius and filter mask each): results[i] = the hits of query i, ascending
+int search_radius_impl(szg_index *ix, const double *queries, int n_queries, const double *radii,
+                       const uint64_t *const *masks, std::vector<std::vector<HeapItem>> *results);
 
 // ---- scan_mq.cpp
 int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int nq, int nb, bool has_allow,

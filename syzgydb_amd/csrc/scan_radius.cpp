@@ -1,0 +1,300 @@
+// scan_radius.cpp -- radius search, Search{Precision:"exact", Radius > 0} (K is ignored: collection.go:598-605).
+//
+// A radius search is a COLLECT sweep: every row whose scan key is at or below a threshold derived from the radius
+// (plus the key's error bound) is appended to the query's buffer, the hits are re-ranked in float64 and the
+// reference's exact predicate `distance <= Radius` (:598) decides.  The sweeps of a batch are walked query-major by
+// ONE launch (per-sweep threshold, buffer and counter in ScanArgs), the re-rank reads the hit counters on the
+// device, and up to three batches are in flight per shard -- no launch gap and no host round trip between the sweeps
+// of a batch, which is what a single query per launch per caller used to cost (5.7 of 6.9 TB/s on cfg5's shard).
+#include "scan_internal.h"
+
+namespace szgi {
+
+// key threshold that surely contains every row with distance <= radius
+float radius_key_threshold(const szg_index *ix, double radius, const QMeta &meta)
+{
+    if (ix->metric == SZG_COSINE) {
+        if (radius >= 1.0 || meta.m1 == 0) return 3.0e38f;  // acos(c)/pi <= 1 always; zero query -> all 1.0
+        const double t = -std::cos(M_PI * radius) + 2.0 * key_eps(ix, 1.0, meta) + 1e-12;
+        return std::nextafter((float)t, INFINITY);
+    }
+    const double scale = ix->bits <= 16 ? (double)((1u << ix->bits) - 1u) : 1.0;
+    const double kk = (radius * scale) * (radius * scale);
+    const double t = kk * (1.0 + 1e-12) + 2.0 * key_eps(ix, kk, meta);
+    // (an infinite radius with a zero query makes t = inf + 0 * inf = NaN: everything, as for any t beyond the floats)
+    return !(t < 3.0e38) ? 3.0e38f : std::nextafter((float)t, INFINITY);
+}
+
+namespace {
+
+constexpr size_t kRadiusCapMin = 1024;      // entries per sweep a batch's buffers start with
+constexpr size_t kRadiusCapMax = 1u << 20;  // beyond this a query goes through run_collect on its own
+
+struct RadiusCall;
+struct RadiusTicket {
+    int first = 0, nq = 0;
+    std::vector<Ctx *> ctx;       // one per shard
+    std::vector<float> thr;       // key threshold per query
+    std::vector<size_t> cap;      // per shard: entries per sweep of this batch's buffers
+    bool any_mask = false;
+    bool failed = false;
+    RadiusCall *owner = nullptr;
+    RadiusTicket() = default;
+    RadiusTicket(RadiusTicket &&) = default;
+    RadiusTicket(const RadiusTicket &) = delete;
+    RadiusTicket &operator=(const RadiusTicket &) = delete;
+    ~RadiusTicket();  // a ticket dropped with contexts attached (error return, exception) drains and returns them
+};
+
+struct RadiusCall {
+    szg_index *ix;
+    const double *queries;
+    int n_queries;
+    const double *radii;
+    const uint64_t *const *masks;  // nullable; null entries unfiltered
+    std::vector<std::vector<HeapItem>> *results;
+    size_t n_sh = 0;
+
+    void release(RadiusTicket &t)
+    {
+        for (size_t s = 0; s < n_sh; s++) {
+            if (!t.ctx[s]) continue;
+            if (t.failed) {
+                (void)hipSetDevice(ix->shards[s]->device);
+                (void)hipStreamSynchronize(t.ctx[s]->stream);
+            }
+            ctx_release(ix->shards[s], t.ctx[s]);
+        }
+        t.ctx.assign(n_sh, nullptr);
+    }
+    bool acquire(RadiusTicket &t, bool may_block)
+    {
+        for (size_t s = 0; s < n_sh; s++) {
+            if (ix->shards[s]->n_rows == 0) continue;
+            Ctx *c = may_block ? ctx_acquire(ix->shards[s]) : ctx_try_acquire(ix->shards[s]);
+            if (!c) {
+                release(t);
+                return false;
+            }
+            t.ctx[s] = c;
+        }
+        return true;
+    }
+    int stage(RadiusTicket &t);
+    int enqueue_shard(RadiusTicket &t, size_t s);
+    int finish(RadiusTicket &t);
+    int run();
+};
+
+RadiusTicket::~RadiusTicket()
+{
+    if (!owner) return;
+    bool any = false;
+    for (Ctx *c : ctx) any |= c != nullptr;
+    if (!any) return;
+    failed = true;  // (release() then waits for the streams first)
+    owner->release(*this);
+}
+
+int RadiusCall::enqueue_shard(RadiusTicket &t, size_t s)
+{
+    Shard *sh = ix->shards[s];
+    Ctx *c = t.ctx[s];
+    HIPCHK(hipSetDevice(sh->device));
+    // buffers: t.nq sweeps x cap entries; cap follows the largest hit count this context has seen
+    size_t cap = std::max(kRadiusCapMin, c->radius_cap);
+    t.cap[s] = cap;
+    int rc = ensure_dev(&c->d_collect, &c->collect_cap, cap * (size_t)t.nq);
+    if (rc) return rc;
+    rc = ensure_dev(&c->d_out, &c->d_out_cap, cap * (size_t)t.nq);
+    if (rc) return rc;
+    const size_t n_count = (size_t)szg::kMaxSweepsPerLaunch * szg::kCandCountStride;
+    HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(uint32_t) * n_count, c->stream));
+    HIPCHK(hipEventRecord(c->ev_up, c->stream));  // the sweeps must see the queries, the masks and the zeroed counters
+    std::vector<szg::ScanArgs> a(1);
+    fill_scan_args(ix, sh, c, t.any_mask, 0, t.nq, &a[0]);
+    a[0].collect = 1;
+    for (int j = 0; j < t.nq; j++) a[0].thr_ukeys[j] = szg::ordered_key(t.thr[j]);
+    a[0].collect_buf = c->d_collect;
+    a[0].collect_cap = (uint32_t)cap;
+    a[0].collect_count = c->d_count;
+    if ((t.any_mask || sh->has_dead) && ix->mask_dense) {  // most rows pass: read every row, masks at the row finish
+        double lowest = 1.0;
+        for (int j = 0; j < t.nq; j++) lowest = std::min(lowest, mask_pass_rate(sh, c, t.any_mask, j));
+        a[0].mask_dense = lowest >= 0.5 ? 1 : 0;
+    }
+    rc = launch_scans_chained(ix, sh, c, a, scan_geometry(ix, sh, 0));
+    if (rc) return rc;
+    // float64 distances of the hits: the counts stay on the device
+    HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, c->d_collect, c->d_count,
+                              (uint32_t)cap, t.nq, c->d_out, c->stream, szg::kCandCountStride));
+    HIPCHK(hipMemcpyAsync(c->h_count, c->d_count, sizeof(uint32_t) * n_count, hipMemcpyDeviceToHost, c->stream));
+    return SZG_OK;
+}
+
+int RadiusCall::stage(RadiusTicket &t)
+{
+    int rc = SZG_OK;
+    const double *q = queries + (size_t)t.first * ix->dim;
+    std::vector<const uint64_t *> m(t.nq, nullptr);
+    for (int j = 0; j < t.nq; j++) {
+        m[j] = masks ? masks[t.first + j] : nullptr;
+        t.any_mask |= m[j] != nullptr;
+    }
+    const double t0 = now_us();
+    Ctx *c0 = nullptr;
+    for (size_t s = 0; s < n_sh; s++) {
+        Ctx *c = t.ctx[s];
+        if (!c) continue;
+        if (!c0) {
+            c0 = c;
+            for (int j = 0; j < t.nq; j++) {
+                prep_query(ix, q + (size_t)j * ix->dim, c->h_qsw + (size_t)j * ix->qsw_bytes, &c->meta[j]);
+                t.thr[j] = radius_key_threshold(ix, radii[t.first + j], c->meta[j]);
+            }
+        } else {
+            memcpy(c->h_qsw, c0->h_qsw, ix->qsw_bytes * (size_t)t.nq);
+            for (int j = 0; j < t.nq; j++) c->meta[j] = c0->meta[j];
+        }
+    }
+    const double t1 = now_us();
+    for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
+        if (!t.ctx[s]) continue;
+        rc = enqueue_queries(ix, ix->shards[s], t.ctx[s], q, t.nq, t.any_mask ? m.data() : nullptr);
+        if (rc == SZG_OK) rc = enqueue_shard(t, s);
+    }
+    std::lock_guard<std::mutex> lk(ix->stats_mu);
+    ix->stats.host_prep_us += t1 - t0;
+    ix->stats.host_enqueue_us += now_us() - t1;
+    return rc;
+}
+
+int RadiusCall::finish(RadiusTicket &t)
+{
+    if (t.failed) {
+        release(t);
+        return SZG_OK;
+    }
+    int rc = SZG_OK;
+    std::vector<std::vector<Cand>> cands(t.nq);
+    std::vector<uint8_t> redo(t.nq, 0);  // more hits than the batch's buffers hold: the query is swept again on its own
+    double t_wait = 0;
+    const double t0 = now_us();
+    for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
+        Ctx *c = t.ctx[s];
+        if (!c) continue;
+        Shard *sh = ix->shards[s];
+        const double tw = now_us();
+        hipError_t e = hipSetDevice(sh->device);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return fail(SZG_E_DEVICE, "hipStreamSynchronize", e);
+        rc = finish_timing(ix, c);
+        if (rc) break;
+        // exact-size copies of each sweep's re-ranked hits, back to back in the pinned buffer
+        const size_t cap = t.cap[s];
+        size_t total = 0, most = 0;
+        std::vector<size_t> off(t.nq + 1, 0);
+        for (int j = 0; j < t.nq; j++) {
+            const size_t n = c->h_count[(size_t)j * szg::kCandCountStride];
+            most = std::max(most, n);
+            if (n > cap) redo[j] = 1;
+            off[j + 1] = off[j] + (n > cap ? 0 : n);
+        }
+        total = off[t.nq];
+        // the next batch on this context starts with room for what this one saw (and shrinks again slowly)
+        size_t want = kRadiusCapMin;
+        while (want < most + most / 4 && want < kRadiusCapMax) want <<= 1;
+        c->radius_cap = std::max(want, c->radius_cap - c->radius_cap / 8);
+        if (total) {
+            rc = ensure_host(&c->h_out, &c->h_out_cap, total);
+            if (rc) break;
+            for (int j = 0; j < t.nq; j++) {
+                const size_t n = off[j + 1] - off[j];
+                if (!n) continue;
+                e = hipMemcpyAsync(c->h_out + off[j], c->d_out + (size_t)j * cap, n * sizeof(szg::RerankOut),
+                                   hipMemcpyDeviceToHost, c->stream);
+                if (e != hipSuccess) return fail(SZG_E_DEVICE, "hipMemcpyAsync(radius hits)", e);
+            }
+            e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) return fail(SZG_E_DEVICE, "hipStreamSynchronize", e);
+        }
+        t_wait += now_us() - tw;
+        for (int j = 0; j < t.nq; j++) {
+            if (redo[j]) continue;
+            cands[j].reserve(cands[j].size() + (off[j + 1] - off[j]));
+            for (size_t i = off[j]; i < off[j + 1]; i++) {
+                const szg::RerankOut &r = c->h_out[i];
+                cands[j].push_back(Cand{sh->first + r.row, r.dist, szg::key_from_ordered(r.ukey), 0.0});
+            }
+        }
+    }
+    for (int j = 0; j < t.nq && rc == SZG_OK; j++) {
+        if (redo[j]) {
+            cands[j].clear();
+            const double tw = now_us();
+            for (size_t s = 0; s < n_sh && rc == SZG_OK; s++)
+                if (t.ctx[s]) rc = run_collect(ix, ix->shards[s], t.ctx[s], j, t.thr[j], t.any_mask, &cands[j]);
+            t_wait += now_us() - tw;
+            if (rc) break;
+        }
+        // consider()'s radius branch (collection.go:598-605) in visit order, then the pop loop (:694-697)
+        std::vector<Cand> &cs = cands[j];
+        std::sort(cs.begin(), cs.end(), [](const Cand &x, const Cand &y) { return x.row < y.row; });
+        const double radius = radii[t.first + j];
+        GoHeap h;
+        for (const Cand &c : cs)
+            if (c.dist <= radius) h.push(HeapItem{c.row, c.dist});
+        h.drain(&(*results)[t.first + j]);
+    }
+    {
+        std::lock_guard<std::mutex> lk(ix->stats_mu);
+        ix->stats.host_finish_us += now_us() - t0 - t_wait;
+        if (rc == SZG_OK) ix->stats.queries += t.nq;
+    }
+    release(t);
+    return rc;
+}
+
+int RadiusCall::run()
+{
+    n_sh = ix->shards.size();
+    results->assign(n_queries, {});
+    std::deque<RadiusTicket> inflight;
+    int rc = SZG_OK;
+    const int qpl = std::max(1, std::min(ix->queries_per_launch, szg::kMaxSweepsPerLaunch));
+    for (int q0 = 0; q0 < n_queries && rc == SZG_OK;) {
+        RadiusTicket t;
+        t.owner = this;
+        t.first = q0;
+        t.nq = std::min(qpl, n_queries - q0);
+        t.ctx.assign(n_sh, nullptr);
+        t.cap.assign(n_sh, 0);
+        t.thr.assign(t.nq, 0.0f);
+        if (!acquire(t, inflight.empty())) {
+            rc = finish(inflight.front());
+            inflight.pop_front();
+            continue;
+        }
+        rc = stage(t);
+        t.failed = rc != SZG_OK;
+        inflight.push_back(std::move(t));
+        q0 += inflight.back().nq;
+    }
+    while (!inflight.empty()) {
+        const int r2 = finish(inflight.front());
+        if (rc == SZG_OK) rc = r2;
+        inflight.pop_front();
+    }
+    return rc;
+}
+
+}  // namespace
+
+int search_radius_impl(szg_index *ix, const double *queries, int n_queries, const double *radii,
+                       const uint64_t *const *masks, std::vector<std::vector<HeapItem>> *results)
+{
+    RadiusCall call{ix, queries, n_queries, radii, masks, results};
+    return call.run();
+}
+
+}  // namespace szgi

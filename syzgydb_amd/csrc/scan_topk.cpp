@@ -145,6 +145,22 @@ int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg
     return SZG_OK;
 }
 
+// Pass rates are estimated from a sample of each mask's words.
+double mask_pass_rate(const Shard *sh, const Ctx *c, bool has_allow, int slot)
+{
+    const double live = sh->n_rows ? (double)sh->n_live / (double)sh->n_rows : 1.0;
+    if (!has_allow) return live;
+    const size_t words = shard_words(sh);
+    const uint64_t *m = c->h_allow + (size_t)slot * words;
+    const size_t step = std::max<size_t>(1, words / 256);
+    uint64_t ones = 0, seen = 0;
+    for (size_t w = 0; w < words; w += step) {
+        ones += (uint64_t)__builtin_popcountll(m[w]);
+        seen += 64;
+    }
+    return live * (seen ? (double)ones / (double)seen : 1.0);
+}
+
 // top-k pass for the nq staged queries of one shard: scan -> merges -> rerank -> D2H (async)
 int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allow)
 {
@@ -170,21 +186,8 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
 
     // Masked sweeps: when most rows pass (a few tombstones, a mild filter) every row is read and
     // the masks decide at the row finish -- the predicate-free dense phase; a selective filter
-    // keeps the form that tests a row before issuing its loads.  Pass rates are estimated from
-    // a sample of each mask's words.
-    auto pass_rate = [&](int j) -> double {
-        double live = sh->n_rows ? (double)sh->n_live / (double)sh->n_rows : 1.0;
-        if (!has_allow) return live;
-        const size_t words = shard_words(sh);
-        const uint64_t *m = c->h_allow + (size_t)j * words;
-        const size_t step = std::max<size_t>(1, words / 256);
-        uint64_t ones = 0, seen = 0;
-        for (size_t w = 0; w < words; w += step) {
-            ones += (uint64_t)__builtin_popcountll(m[w]);
-            seen += 64;
-        }
-        return live * (seen ? (double)ones / (double)seen : 1.0);
-    };
+    // keeps the form that tests a row before issuing its loads.
+    auto pass_rate = [&](int j) { return mask_pass_rate(sh, c, has_allow, j); };
     const bool masked = has_allow || sh->has_dead;
     const int qpl = std::max(1, ix->queries_per_launch);
     std::vector<szg::ScanArgs> args((nq + qpl - 1) / qpl);
@@ -301,7 +304,7 @@ int run_collect(szg_index *ix, Shard *sh, Ctx *c, int slot, float thr_key, bool 
         std::vector<szg::ScanArgs> a(1);
         fill_scan_args(ix, sh, c, has_allow, slot, 1, &a[0]);
         a[0].collect = 1;
-        a[0].thr_ukey = szg::ordered_key(thr_key);
+        a[0].thr_ukeys[0] = szg::ordered_key(thr_key);
         a[0].collect_buf = c->d_collect;
         a[0].collect_cap = (uint32_t)std::min<size_t>(c->collect_cap, 0xFFFFFFFFu);
         a[0].collect_count = c->d_count;

@@ -62,6 +62,7 @@ class ScanIndex:
         if self._h:
             self._L.szg_index_destroy(self._h)
             self._h = ctypes.c_void_p()
+        self._comm = None
 
     def __del__(self):
         try:
@@ -208,6 +209,63 @@ class ScanIndex:
             if capacity is None:
                 return out_rows[:n], out_dist[:n]
             return out_rows[:n], out_dist[:n], n
+
+    def _radius_csr(self, fn, name, queries, radii, allow):
+        q = np.ascontiguousarray(queries, dtype=np.float64)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        if q.shape[1] != self.dim:
+            raise ValueError("query length %d != dimension %d" % (q.shape[1], self.dim))
+        nq = q.shape[0]
+        rad = np.ascontiguousarray(np.broadcast_to(np.asarray(radii, dtype=np.float64), (nq,)))
+        keep, allow_p = self._allow_arg(allow, nq)
+        cap = 1 << 16
+        while True:
+            out_rows = np.zeros(max(cap, 1), dtype=np.uint64)
+            out_dist = np.zeros(max(cap, 1), dtype=np.float64)
+            off = np.zeros(nq + 1, dtype=np.uint64)
+            rc = fn(self._h, _f64(q), nq, _f64(rad), allow_p, _u64(out_rows), _f64(out_dist), cap, _u64(off))
+            if rc == _lib.SZG_E_TRUNCATED:
+                cap = int(off[nq])
+                continue
+            check(rc, name)
+            del keep
+            return [(out_rows[int(off[i]):int(off[i + 1])], out_dist[int(off[i]):int(off[i + 1])]) for i in range(nq)]
+
+    def search_radius_batch(self, queries, radii, allow=None):
+        """Radius searches for a batch (radii: one value or one per query): a list of (rows, dist) per query,
+        ascending distance.  The collect sweeps of the batch share query-major launches."""
+        return self._radius_csr(self._L.szg_search_radius_batch, "szg_search_radius_batch", queries, radii, allow)
+
+    # -- one process per GPU: the exchange inside the library (syzgydb_amd/sharded.py: Comm) ------------
+    def attach_comm(self, comm):
+        """Sharded searches of this handle go through `comm` (a sharded.Comm; None detaches)."""
+        check(self._L.szg_index_attach_comm(self._h, comm._h if comm is not None else None), "szg_index_attach_comm")
+        self._comm = comm  # keeps it alive as long as the handle uses it
+
+    def search_topk_sharded(self, queries, k, allow=None):
+        """Collective: the single-collection top-k over every rank's rows.
+        Returns (rows uint64[nq,k] GLOBAL, dist float64[nq,k], count int32[nq], history_dependent bool[nq])."""
+        q = np.ascontiguousarray(queries, dtype=np.float64)
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        if q.shape[1] != self.dim:
+            raise ValueError("query length %d != dimension %d" % (q.shape[1], self.dim))
+        nq, k = q.shape[0], int(k)
+        out_rows = np.zeros((nq, max(k, 0)), dtype=np.uint64)
+        out_dist = np.zeros((nq, max(k, 0)), dtype=np.float64)
+        out_count = np.zeros(nq, dtype=np.int32)
+        hist = np.zeros(nq, dtype=np.uint8)
+        keep, allow_p = self._allow_arg(allow, nq)
+        check(self._L.szg_search_topk_sharded(self._h, _f64(q), nq, k, allow_p, _u64(out_rows), _f64(out_dist),
+                                              out_count.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _u8(hist)),
+              "szg_search_topk_sharded")
+        del keep
+        return out_rows, out_dist, out_count, hist.astype(bool)
+
+    def search_radius_sharded(self, queries, radii, allow=None):
+        """Collective: radius searches over every rank's rows; a list of (rows GLOBAL, dist) per query."""
+        return self._radius_csr(self._L.szg_search_radius_sharded, "szg_search_radius_sharded", queries, radii, allow)
 
     # -- diagnostics ----------------------------------------------------------
     def set_timing(self, enabled):

@@ -53,3 +53,36 @@ def test_inproc_mode_and_unchanged_single_gpu_form():
     assert one["batched"]["roofline"]["bound"] == "hbm" and one["batched"]["roofline"]["achieved"] > 0   # bfloat16 sweep
     assert one["batched"]["float32_mfma_form_TFLOPs"] > 0
     assert one["parity"]["ids_identical"] == one["parity"]["queries_checked"]
+
+
+def test_ranks_form_reports_transport_and_fixed_overhead():
+    out = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--rows", "250112", "--settle-seconds", "0.2"],
+                    {"SZG_BENCH_ONE_GPU": "1", "SZG_BENCH_BACKEND": "gloo"})
+    assert "host transport" in out["exchange_transport"]
+    assert out["fixed_overhead_ms"] >= 0
+    for r in out["ranks"]:
+        assert r["exchanges"] == 1                      # 20 queries: one local call, ONE all-gather
+        assert r["fixed_overhead_ms"] >= 0 and r["sweeps_ms"] > 0
+    assert out["parity"]["ids_identical"] == out["parity"]["queries_checked"] > 0
+
+
+def test_rccl_exchange_inside_the_library_single_rank():
+    """The N>1 code path with ONE rank (what a 1-GPU box can run of it): torch.distributed only hands the
+    communicator id round; the all-gather is the library's own ncclAllGather."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.update({"SZG_BENCH_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "300", "--warmup", "8",
+                        "--rows", "100000", "--settle-seconds", "0.2", "--no-extras"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert out["rccl_ranks"] == 1 and out["rccl_ranks_in_library"] == 1
+    assert out["exchange_transport"].startswith("rccl")
+    assert out["ranks"][0]["exchanges"] == 2            # 300 queries: two micro-batches of <= 256, pipelined
+    assert out["parity"]["ids_identical"] == out["parity"]["queries_checked"] > 0

@@ -480,3 +480,79 @@ def test_collection_mirror_with_the_sketch_option():
     assert [(r.ID, r.Distance) for r in ra.Results] == [(r.ID, r.Distance) for r in rb.Results]
     a.Close()
     b.Close()
+
+
+def test_ascending_integer_ids_do_not_repage_the_mirror():
+    """"10" < "9" as strings, so plain ascending ids 1, 2, 3, ... are out of sort.Strings order from
+    the tenth on.  A new document is still appended in place; the mirror is re-paged in the reference's
+    deterministic order only when an answer really depends on the visit order (a tie among the best k+1), and in
+    production mode (strict_order=False: the reference iterates a Go map in random order) never."""
+    dim, bits, metric = 16, 32, Cosine
+    rng = np.random.default_rng(5)
+    V = rng.standard_normal((300, dim))
+    for strict in (True, False):
+        c = Collection(CollectionOptions(Name="asc", DistanceMethod=metric, DimensionCount=dim, Quantization=bits),
+                       strict_order=strict)
+        for i in range(200):
+            c.AddDocument(i + 1, V[i], b"")
+            if i % 20 == 19:   # add / search interleaved
+                q = rng.standard_normal(dim)
+                got = c.Search(SearchArgs(Vector=q, K=5, Precision="exact"))
+                order = sorted(range(1, i + 2), key=str)
+                rows = orc.encode_rows(np.stack([V[j - 1] for j in order]), bits)
+                want_rows, want_d, _ = orc.search_exact(rows, dim, bits, metric, q, k=5)
+                assert [r.ID for r in got.Results] == [order[int(r)] for r in want_rows]   # no ties: any order agrees
+                assert [r.Distance for r in got.Results] == list(want_d)
+        assert c.resorts == 0, c.resorts
+        # now a real tie at the k boundary: ids 150 and 30 hold the same vector, k = 1 -- the reference's
+        # deterministic scan visits "150" before "30" (string order) and keeps the first
+        c.AddDocument(30, V[149], b"")
+        q = V[149] + 1e-3
+        got = c.Search(SearchArgs(Vector=q, K=1, Precision="exact"))
+        if strict:
+            assert c.resorts == 1 and got.Results[0].ID == 150
+            c.AddDocument(201, V[200], b"")          # "201" < "99": stale again, but no tie -> no re-page
+            c.Search(SearchArgs(Vector=rng.standard_normal(dim), K=3, Precision="exact"))
+            assert c.resorts == 1
+        else:
+            assert c.resorts == 0 and got.Results[0].ID in (30, 150)   # either is a reference answer
+        c.Close()
+
+
+def test_search_batch_equals_search_by_search():
+    """Collection.SearchBatch (the Go binding's searchExactBatch): one library call for a list of Searches --
+    top-k with one K through a shared sweep, radius Searches through szg_search_radius_batch -- each with its own
+    Filter; results identical to Search called one by one, and to the oracle."""
+    dim, bits, n = 48, 8, 5000
+    rng = np.random.default_rng(9)
+    V = rng.uniform(-1, 1, (n, dim))
+    for metric in (Cosine, Euclidean):
+        c = Collection(CollectionOptions(Name="batch", DistanceMethod=metric, DimensionCount=dim, Quantization=bits))
+        ids = list(range(1000, 1000 + n))
+        c.AddDocuments(ids, V, [b"m%d" % (i % 7) for i in ids])
+        Q = rng.uniform(-1, 1, (21, dim))
+        flt = [None, (lambda id, meta: meta == b"m3"), (lambda id, meta: id % 2 == 0)]
+        args = [SearchArgs(Vector=Q[i], K=6, Precision="exact", Filter=flt[i % 3]) for i in range(len(Q))]
+        before = c._index.stats()["mq_queries"]
+        got = c.SearchBatch(args)
+        assert c._index.stats()["mq_queries"] - before == len(Q)      # one shared-sweep call for all of them
+        for a, g in zip(args, got):
+            one = c.Search(a)
+            assert [(r.ID, r.Distance, r.Metadata) for r in g.Results] == [(r.ID, r.Distance, r.Metadata) for r in one.Results]
+            assert g.PercentSearched == one.PercentSearched == 100.0
+        # radius: every query its own radius (its 9th neighbour's distance)
+        rad = [c.Search(SearchArgs(Vector=Q[i], K=9, Precision="exact")).Results[-1].Distance for i in range(8)]
+        rargs = [SearchArgs(Vector=Q[i], Radius=rad[i], Precision="exact", Filter=flt[i % 3]) for i in range(8)]
+        for a, g in zip(rargs, c.SearchBatch(rargs)):
+            one = c.Search(a)
+            assert [(r.ID, r.Distance) for r in g.Results] == [(r.ID, r.Distance) for r in one.Results]
+            assert all(r.Distance <= a.Radius for r in g.Results)
+        order = sorted(ids, key=str)                               # the oracle on the reference's visit order
+        rows = orc.encode_rows(np.stack([V[i - 1000] for i in order]), bits)
+        want_rows, want_d, _ = orc.search_exact(rows, dim, bits, metric, Q[0], k=6)
+        assert [r.ID for r in got[0].Results] == [order[int(r)] for r in want_rows]
+        assert [r.Distance for r in got[0].Results] == list(want_d)
+        # mixed kinds fall back to Search by Search
+        mixed = c.SearchBatch([args[0], rargs[0], SearchArgs(Offset=0, Limit=3)])
+        assert len(mixed) == 3 and len(mixed[2].Results) == 3
+        c.Close()

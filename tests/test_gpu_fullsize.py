@@ -99,6 +99,29 @@ def test_headline_full_oracle_scan_one_query():
     assert (rel <= 1e-5).all()   # the contract's tolerance; bit-equality above is stronger
 
 
+@pytest.mark.parametrize("name,n,dim,bits,metric,k", [c for c in CONFIGS if c[0] in ("cfg2", "cfg3")], ids=["cfg2", "cfg3"])
+def test_cfg2_cfg3_full_oracle_scan_one_query(name, n, dim, bits, metric, k):
+    """One complete oracle scan of the million rows (1.5 GB / 0.77 GB: seconds of CPU) per configuration against
+    the HIP answers for the same query: alone (one sweep per query) and inside a batch (the shared sweep on the
+    matrix cores: bfloat16 MFMA for cfg2's float rows, int8 MFMA for cfg3's 8-bit rows)."""
+    seed = 0x53595A4700000400 + bits
+    Q = synth_vectors(seed + 1, 0, 5, dim)
+    with ScanIndex(dim, bits, metric) as ix:
+        ix.synth(n, seed)
+        ix.set_option("multi_query", 0)
+        r1, d1, _ = ix.search_topk(Q[2], k)
+        ix.set_option("multi_query", 1)
+        rb, db, _ = ix.search_topk(Q, k)
+        assert ix.stats()["mq_queries"] == 5
+        rows = ix.read_rows(0, n)
+    o_rows, o_dist, searched = orc.search_exact(rows, dim, bits, metric, Q[2], k=k)
+    assert searched == n
+    for r, d in ((r1[0], d1[0]), (rb[2], db[2])):
+        assert [int(x) for x in r] == [int(x) for x in o_rows]
+        assert (d == o_dist).all()                       # the reference's float64 values bit for bit
+        assert (np.abs(d - o_dist) <= 1e-5 * o_dist).all()   # the contract's tolerance
+
+
 def test_cfg5_full_radius_search():
     """Config #5 as named: 100M x 384 4-bit cosine, radius search (one card holds the
     19.2 GB).  Every hit's distance is the oracle's for that row and <= R; sampled

@@ -46,6 +46,13 @@ for (dim, bits, metric, n, k, radius, seed) in [(96, 32, 1, 20000, 10, 0.44, 31)
     er, ed, _ = orc.search_exact(rows, dim, bits, metric, Q[0], radius=radius)
     assert len(er) > 0 and [int(x) for x in rr] == [int(x) for x in er], (rank, dim, len(rr), len(er))
     assert (dd == ed).all()
+    # the same inside the library: szg_search_topk_sharded / szg_search_radius_sharded on the handle
+    s2 = ShardedSearcher(index=ix, comm=s.comm)
+    r2, d2, c2, h2 = s2.search_stream(Q, k)
+    assert (r2 == r).all() and (d2 == d).all() and (c2 == c).all() and (h2 == hist).all()
+    rr2, dd2 = s2.search_radius(None, Q[0], radius)
+    assert (rr2 == rr).all() and (dd2 == dd).all()
+    ix.attach_comm(None)
     ix.close()
 dist.barrier()
 if rank == 0:
