@@ -25,6 +25,17 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// value of lane `src`, src wave-uniform: v_readlane_b32 through a scalar register -- a few cycles, where
+// __shfl (ds_bpermute_b32 through the LDS crossbar) costs ~100.  The list code broadcasts once per candidate that
+// passes the pre-filter and once per insert; while a list is still filling (every wave's first kp rows; a wave of
+// a 125 K-row shard never sees more than that) these broadcasts were most of the selection's cost.
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // lane i receives lane i-1's value (lane 0 keeps its own)
 __device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v)
 {
@@ -65,7 +76,7 @@ struct WaveList {
             const int pos = __popcll(__ballot(mine < c));  // entries are unique, sorted ascending
             const uint64_t up = wave_shr1_u64(mine);
             mine = lane < pos ? mine : (lane == pos ? c : up);
-            worst = shfl_u64(mine, kp - 1);
+            worst = readlane_u64(mine, kp - 1);
             return;
         }
         int pos = 0;
@@ -98,7 +109,7 @@ struct WaveList {
         while (m) {
             const int src = __ffsll((long long)m) - 1;
             m &= m - 1;
-            const uint64_t cc = shfl_u64(c, src);
+            const uint64_t cc = readlane_u64(c, src);
             if (cc < worst) insert(cc, lane);
         }
         worst_key = worst == kInvalidCand ? __builtin_inff() : key_from_ordered((uint32_t)(worst >> 32));

@@ -191,6 +191,16 @@ hipError_t launch_mq_thr(const uint64_t *lists, int kp, int n_queries, float *th
 hipError_t launch_cand_select(const uint64_t *cand_buf, const uint32_t *cand_count, uint32_t cand_cap,
                               int kp, int n_queries, uint64_t *lists, hipStream_t stream);
 size_t mq_lds_bytes(int qbits, int r16, int nb);
+// The tail of a fused-selection batch in one launch (kernels_mq.hip: cand_refine_kernel): the kp best of each query's
+// collected candidates -- mode 0: by the collected key; 1 / 2 (bfloat16 sweeps, cosine / euclid): the candidates
+// within the sweep's error band of the kp-th best are scored again in float32 first, band_edge[q] tells the host
+// where the band ended -- followed by the query's n_sent sentinel rows: lists [n_queries][kp + n_sent].  A band that
+// does not fit sets cand_count[q] to 0xFFFFFFFF (the batch is redone through the score matrix).
+bool cand_refine_applies(int kp, uint32_t cand_cap, int dim, bool rescore);
+hipError_t launch_cand_refine(int mode, const uint8_t *rows, uint32_t pitch, int dim, const double *q64,
+                              const double *qscale, const double *qnorm2, const uint64_t *cand_buf, uint32_t *cand_count,
+                              uint32_t cand_cap, int kp, int n_queries, const uint64_t *sent, int n_sent,
+                              uint64_t *lists, float *band_edge, hipStream_t stream);
 // float32 re-score of the collected candidates of a bfloat16 sweep (32-bit rows): replaces the key in every
 // candidate word; qscale[q] = 1/|q| (cosine) or 1 (euclid), the float32 query is (float)(q64 * qscale)
 hipError_t launch_cand_rescore(int metric, const uint8_t *rows, uint32_t pitch, int dim, const double *q64,

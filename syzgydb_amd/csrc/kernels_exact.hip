@@ -119,26 +119,49 @@ __device__ __forceinline__ double decode_elem_piece(const uint8_t *rp, int i)
     }
 }
 
-// ordered float64 sum  s = (((0 + p[0]) + p[1]) + ...)  by ONE lane: the order is
-// the reference's, so it cannot be parallelised, but the loads can run ahead.
+// ordered float64 sum  s = (((0 + p[0]) + p[1]) + ...)  by ONE lane: the order is the reference's, so the adds
+// form one dependent chain (768 of them at dim 768) -- what can be taken off that chain is the LDS latency: the
+// next eight values are fetched (two per ds_read_b128) while the current eight are being added.  p is 16-byte
+// aligned.
 __device__ __forceinline__ double ordered_sum(double s, const double *p, int n)
 {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 *p2 = reinterpret_cast<const d2 *>(p);
     int i = 0;
-    for (; i + 8 <= n; i += 8) {
-        const double v0 = p[i], v1 = p[i + 1], v2 = p[i + 2], v3 = p[i + 3];
-        const double v4 = p[i + 4], v5 = p[i + 5], v6 = p[i + 6], v7 = p[i + 7];
-        s = __dadd_rn(s, v0);
-        s = __dadd_rn(s, v1);
-        s = __dadd_rn(s, v2);
-        s = __dadd_rn(s, v3);
-        s = __dadd_rn(s, v4);
-        s = __dadd_rn(s, v5);
-        s = __dadd_rn(s, v6);
-        s = __dadd_rn(s, v7);
+    if (n >= 8) {
+        d2 a0 = p2[0], a1 = p2[1], a2 = p2[2], a3 = p2[3];
+        for (; i + 16 <= n; i += 8) {
+            const d2 b0 = p2[(i >> 1) + 4], b1 = p2[(i >> 1) + 5], b2 = p2[(i >> 1) + 6], b3 = p2[(i >> 1) + 7];
+            s = __dadd_rn(s, a0.x);
+            s = __dadd_rn(s, a0.y);
+            s = __dadd_rn(s, a1.x);
+            s = __dadd_rn(s, a1.y);
+            s = __dadd_rn(s, a2.x);
+            s = __dadd_rn(s, a2.y);
+            s = __dadd_rn(s, a3.x);
+            s = __dadd_rn(s, a3.y);
+            a0 = b0;
+            a1 = b1;
+            a2 = b2;
+            a3 = b3;
+        }
+        s = __dadd_rn(s, a0.x);
+        s = __dadd_rn(s, a0.y);
+        s = __dadd_rn(s, a1.x);
+        s = __dadd_rn(s, a1.y);
+        s = __dadd_rn(s, a2.x);
+        s = __dadd_rn(s, a2.y);
+        s = __dadd_rn(s, a3.x);
+        s = __dadd_rn(s, a3.y);
+        i += 8;
     }
     for (; i < n; i++) s = __dadd_rn(s, p[i]);
     return s;
 }
+
+// elements per LDS chunk of the rerank: at most 384 (9 KiB of products for cosine: 16 candidates per CU at once
+// instead of 6 with whole 768-element rows, and the next chunk's gathers overlap this chunk's adds), in multiples of 8
+__host__ __device__ inline int rerank_chunk(int dim) { return dim >= 384 ? 384 : ((dim + 7) & ~7); }
 
 // One wave per candidate.  All lanes decode the row and form the per-element
 // products (each product is rounded once, exactly as `a*b` in Go); lanes 0..2
@@ -151,9 +174,9 @@ __global__ __launch_bounds__(64) void rerank_kernel(const uint8_t *rows, RowLayo
                                                     RerankOut *out, const uint32_t *left_rows)
 {
     extern __shared__ __align__(16) uint8_t smem[];
-    constexpr int CH = 1024;                        // elements per LDS chunk
+    const int CH = rerank_chunk(dim);               // elements per LDS chunk (the launch sized smem for it)
     double *p0 = reinterpret_cast<double *>(smem);  // x*y   (euclid: diff*diff)
-    double *p1 = p0 + CH;                           // x*x
+    double *p1 = p0 + CH;                           // x*x   (cosine only)
     double *p2 = p1 + CH;                           // y*y
     const int lane = threadIdx.x;
     uint32_t n = n_max;
@@ -180,22 +203,43 @@ __global__ __launch_bounds__(64) void rerank_kernel(const uint8_t *rows, RowLayo
         const bool pair = left_rows != nullptr;
         const uint32_t lrow = pair ? left_rows[ci] : 0u;
         double s = 0.0;
+        // Chunks of CH elements: every lane forms the products of its elements (PER = CH / 64 each), lanes 0..2 add
+        // them up in index order.  The next chunk's elements are fetched from HBM before the current chunk's sums
+        // start, so the gathers' latency hides behind the add chain.
+        constexpr int PER = 6;  // CH <= 384
+        double xv[PER], yv[PER];
+        auto fetch = [&](int base) {
+            const int m = min(CH, dim - base);
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int i = lane + u * 64;
+                if (i < m) {
+                    xv[u] = pair ? decode_elem<QBITS>(rows, lay, lrow, base + i) : query[base + i];
+                    yv[u] = decode_elem<QBITS>(rows, lay, row, base + i);
+                }
+            }
+        };
+        fetch(0);
         for (int base = 0; base < dim; base += CH) {
             const int m = min(CH, dim - base);
             __syncthreads();
-            for (int i = lane; i < m; i += 64) {
-                const double x = pair ? decode_elem<QBITS>(rows, lay, lrow, base + i) : query[base + i];
-                const double y = decode_elem<QBITS>(rows, lay, row, base + i);
-                if (METRIC == kEuclidean) {
-                    const double diff = __dsub_rn(x, y);
-                    p0[i] = __dmul_rn(diff, diff);
-                } else {
-                    p0[i] = __dmul_rn(x, y);
-                    p1[i] = __dmul_rn(x, x);
-                    p2[i] = __dmul_rn(y, y);
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int i = lane + u * 64;
+                if (i < m) {
+                    const double x = xv[u], y = yv[u];
+                    if (METRIC == kEuclidean) {
+                        const double diff = __dsub_rn(x, y);
+                        p0[i] = __dmul_rn(diff, diff);
+                    } else {
+                        p0[i] = __dmul_rn(x, y);
+                        p1[i] = __dmul_rn(x, x);
+                        p2[i] = __dmul_rn(y, y);
+                    }
                 }
             }
             __syncthreads();
+            if (base + CH < dim) fetch(base + CH);
             if (METRIC == kEuclidean) {
                 if (lane == 0) s = ordered_sum(s, p0, m);
             } else {
@@ -482,7 +526,7 @@ hipError_t launch_rerank_q(int metric, const uint8_t *rows, RowLayout lay, int d
 {
     if (n_max == 0 || n_queries == 0) return hipSuccess;
     const dim3 grid(n_max < 4096u ? n_max : 4096u, n_queries);
-    const size_t lds = (size_t)1024 * 3 * sizeof(double);
+    const size_t lds = (size_t)rerank_chunk(dim) * (metric == kCosine ? 3 : 1) * sizeof(double);
     if (metric == kCosine)
         hipLaunchKernelGGL((rerank_kernel<QBITS, kCosine>), grid, dim3(64), lds, stream, rows,
                            lay, dim, q, cands, n_dev, n_dev_stride, n_max, out, left_rows);

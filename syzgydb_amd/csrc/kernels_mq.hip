@@ -44,9 +44,6 @@ namespace {
 #ifndef SZG_MQ8_WAVES
 #define SZG_MQ8_WAVES 12  // waves per block (one block per CU) of the int8 sweep
 #endif
-#ifndef SZG_ABL
-#define SZG_ABL 0  // timing experiments (answers become wrong): bit 0 no tile finish, bit 1 no norm work, bit 2 no MFMA,
-#endif             // bit 3 keys formed but hits dropped
 #ifndef SZG_RESCORE_BLOCKS
 #define SZG_RESCORE_BLOCKS 64  // blocks (of 4 waves) per query of the float32 re-score
 #endif
@@ -74,6 +71,23 @@ __device__ __forceinline__ u32x4 load_stream(const uint8_t *p, bool nt)
 {
     if (nt) return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
     return *reinterpret_cast<const u32x4 *>(p);
+}
+
+// Stage n16 16-byte words of a query image into LDS.  Written as load-all / store-all groups of six: with the plain
+// `dst[i] = src[i]` loop every iteration waited for its own load, i.e. 18 L2 round trips back to back for a 147 KiB
+// image (~20 us at the head of EVERY sweep launch, the prefix pass included, with HBM idle).
+__device__ __forceinline__ void stage_image(uint4 *dst, const uint4 *src, int n16, int tid, int nthreads)
+{
+    constexpr int U = 6;
+    int i = tid;
+    for (; i + (U - 1) * nthreads < n16; i += U * nthreads) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = src[i + u * nthreads];
+#pragma unroll
+        for (int u = 0; u < U; u++) dst[i + u * nthreads] = v[u];
+    }
+    for (; i < n16; i += nthreads) dst[i] = src[i];
 }
 
 // Elements of one 16-byte piece as exact float32 values.  Float rows as they are;
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         const int n = r16 * NB * G4 * 16;
-        for (int i = tid; i < n; i += blockDim.x) dst[i] = src[i];
+        stage_image(dst, src, n, tid, blockDim.x);
         if (COLLECT && tid < 48)
             reinterpret_cast<float *>(smem + (size_t)n * 16)[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
     }
@@ -280,9 +294,7 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
         float x_[E];                                                                     \
         _Pragma("unroll") for (int d = 0; d < 4; d++)                                    \
             decode_dword<QBITS, false>(w_[d], 0, 0, x_ + d * N);                         \
-        if (SZG_ABL & 2) nrm = fmaf(x_[0], x_[0], nrm); /* 1 of E terms: same statistics, a quarter of the work */ \
-        else                                                                             \
-            _Pragma("unroll") for (int i = 0; i < E; i++) nrm = fmaf(x_[i], x_[i], nrm); \
+        _Pragma("unroll") for (int i = 0; i < E; i++) nrm = fmaf(x_[i], x_[i], nrm);     \
         const int qcur_ = qbase + cs * qstep;                                            \
         const int qnext_ = qbase + (cs + 1 == steps ? 0 : cs + 1) * qstep;               \
         _Pragma("unroll") for (int g = 0; g < G4; g++)                                   \
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
             _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
                 acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc_[b].w, x_[4 * g + 3], acc[b], 0, 0, 0); \
         }                                                                                \
-        if (QBITS == 32 && !(SZG_ABL & 2)) {                                             \
+        if (QBITS == 32) {                                                               \
             nz |= v_.x | v_.y;                                                           \
             nz |= v_.z | v_.w;                                                           \
         }                                                                                \
@@ -528,7 +540,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (int i = tid; i < n16; i += blockDim.x) dst[i] = src[i];
+        stage_image(dst, src, n16, tid, blockDim.x);
         // table: [0, 96) thresholds, [96, 192) |q|^2
         if (COLLECT && tid < kMqMaxQueries)
             reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
@@ -588,8 +600,8 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
 #define MQS_ISSUE(u)                                                                     \
     {                                                                                    \
         const int adj_ = (odd && is == SS - 1) ? back : 0;                               \
-        ring_a[u] = load_stream(iptr_a + adj_, !(SZG_ABL & 32)); /* whole 128-byte lines, used once: non-temporal */ \
-        ring_b[u] = load_stream(iptr_b + adj_, !(SZG_ABL & 32));                         \
+        ring_a[u] = load_stream(iptr_a + adj_, true); /* whole 128-byte lines, used once: non-temporal */ \
+        ring_b[u] = load_stream(iptr_b + adj_, true);                                    \
         if (++is == SS) {                                                                \
             is = 0;                                                                      \
             itile += tile_stride;                                                        \
@@ -608,7 +620,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
                               __uint_as_float(va_.w)};                                   \
         const float xb_[4] = {__uint_as_float(vb_.x), __uint_as_float(vb_.y), __uint_as_float(vb_.z),       \
                               __uint_as_float(vb_.w)};                                   \
-        if (!skip_ && !(SZG_ABL & 2)) {                                                  \
+        if (!skip_) {                                                                    \
             _Pragma("unroll") for (int i = 0; i < 4; i++) nrm_a = fmaf(xa_[i], xa_[i], nrm_a); \
             _Pragma("unroll") for (int i = 0; i < 4; i++) nrm_b = fmaf(xb_[i], xb_[i], nrm_b); \
         }                                                                                \
@@ -629,13 +641,11 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
         _Pragma("unroll") for (int b = 0; b < NB; b++)                                   \
         {                                                                                \
             const v4i32b qc_ = qn[b];                                                    \
-            if (SZG_ABL & 4) { asm volatile("" :: "v"(bop_)); continue; }                \
             qn[b] = qimg[qnext_ + b * 64];                                               \
             acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qc_),              \
                                                              __builtin_bit_cast(bf16x8, bop_), acc[b], 0, 0, 0); \
         }                                                                                \
         if (++cs == SS) {                                                                \
-            if (SZG_ABL & 1) { asm volatile("" :: "v"(acc[0]), "v"(nrm_a), "v"(nrm_b), "v"(nz_a), "v"(nz_b)); } else \
             finish_tile(ctile);                                                          \
             cs = 0;                                                                      \
             ctile += tile_stride;                                                        \
@@ -786,7 +796,7 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
                                                            (size_t)g * a.group_stride);
         uint4 *dst = reinterpret_cast<uint4 *>(smem + (size_t)g * grp_lds);
         const int n = n16 + (3 * 48 * 4) / 16;  // + constants table
-        for (int i = tid; i < n; i += blockDim.x) dst[i] = src[i];
+        stage_image(dst, src, n, tid, blockDim.x);
         if (COLLECT && tid < 48)
             reinterpret_cast<float *>(smem + (size_t)g * grp_lds + (size_t)n * 16)[tid] =
                 g * 48 + tid < a.n_queries ? a.thr[g * 48 + tid] : -3.0e38f;
@@ -899,10 +909,8 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
             _Pragma("unroll") for (int p = 0; p < NPL; p++)                               \
                 _Pragma("unroll") for (int b = 0; b < NB; b++)                           \
                 {                                                                        \
-                    if (SZG_ABL & 4) { asm volatile("" :: "v"(qc_[p][t][b]), "v"(bop_[t])); }          \
-                    else acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qc_[p][t][b], bop_[t], acc[p][b], 0, 0, 0); \
+                    acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qc_[p][t][b], bop_[t], acc[p][b], 0, 0, 0); \
                 }                                                                        \
-        if (!(SZG_ABL & 2))                                                              \
         _Pragma("unroll") for (int d = 0; d < 4; d++)                                    \
         {                                                                                \
             if (RB == 8) {                                                               \
@@ -914,8 +922,7 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
             }                                                                            \
         }                                                                                \
         if (++cs == steps) {                                                             \
-            if (SZG_ABL & 1) { asm volatile("" :: "v"(acc[0][0]), "v"(SQ), "v"(SV)); }  \
-            else finish_tile8(ctile);                                                    \
+            finish_tile8(ctile);                                                         \
             cs = 0;                                                                      \
             ctile += tile_stride;                                                        \
         }                                                                                \
@@ -966,8 +973,7 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
                         a.keys[(size_t)(qoff + q) * a.key_stride + row] = key;
                 }
             }
-            if (SZG_ABL & 8) { asm volatile("" :: "v"(hm), "v"(keys[0][0])); }  // timing experiment: keys formed, hits dropped
-            else if (COLLECT) offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row, qoff);
+            if (COLLECT) offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row, qoff);
         }
         if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores (see mq_score_kernel)
 #pragma unroll
@@ -1038,7 +1044,7 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
 
 // grid (blocks per query, queries).  Each lane reads 4 keys at a time (16 bytes);
 // a key that beats the wave's current kp-th best is inserted into the wave's list.
-__global__ __launch_bounds__(256) void mq_select_kernel(const float *keys, size_t key_stride,
+__global__ __launch_bounds__(1024) void mq_select_kernel(const float *keys, size_t key_stride,
                                                         uint32_t n_rows, const uint64_t *live_bits,
                                                         const uint64_t *allow_bits,
                                                         uint32_t allow_stride, int kp,
@@ -1187,6 +1193,237 @@ __global__ __launch_bounds__(256) void cand_rescore_kernel(const uint8_t *rows, 
     }
 }
 
+
+// ---- thresholds of the fused selection: a radix select, not a sort ----------------------------------------------------
+//
+// The threshold pass only needs ONE number per query: a key thr such that at least kp eligible prefix rows have
+// key <= thr, as small as cheaply possible.  Two histogram rounds over the ordered key's top 12 + 12 bits (LDS
+// atomics, one block of 1024 threads per query) give the kp-th smallest key to 2^-16 relative -- rounded UP, so the
+// kp-th key itself always passes.  The sorted-list selection this replaces (mq_select_kernel, one block per query)
+// spent ~50 us per 96-query batch inserting into lists nobody read.
+__global__ __launch_bounds__(1024) void mq_thr_radix_kernel(const float *keys, size_t key_stride, uint32_t n_rows,
+                                                            const uint64_t *live_bits, const uint64_t *allow_bits,
+                                                            uint32_t allow_stride, int kp, float *thr_out,
+                                                            uint32_t *count_zero)
+{
+    __shared__ uint32_t hist[4096];
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t sel_bin, sel_below;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    const float4 *kq = reinterpret_cast<const float4 *>(keys + (size_t)q * key_stride);
+    const uint64_t *allow = allow_bits ? allow_bits + (size_t)q * allow_stride : nullptr;
+    const uint32_t n4 = (n_rows + 3) / 4;  // key_stride is a multiple of 4
+    uint32_t prefix_bits = 0;              // the bins chosen so far (top bits of the ordered key)
+    uint32_t below = 0;                    // eligible keys below the chosen bins
+    for (int round = 0; round < 2; round++) {
+        for (int i = tid; i < 4096; i += 1024) hist[i] = 0;
+        __syncthreads();
+        const int shift = round == 0 ? 20 : 8;
+        for (uint32_t i = tid; i < n4; i += 1024) {
+            const float4 v = kq[i];
+            const float kk[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t row = i * 4 + e;
+                bool ok = row < n_rows;
+                if (ok && live_bits) ok = (live_bits[row >> 6] >> (row & 63)) & 1;
+                if (ok && allow) ok = (allow[row >> 6] >> (row & 63)) & 1;
+                const uint32_t u = ordered_key(kk[e]);
+                if (ok && (round == 0 || (u >> 20) == prefix_bits)) atomicAdd(&hist[(u >> shift) & 0xFFFu], 1u);
+            }
+        }
+        __syncthreads();
+        // the bin where the running count reaches kp: 4 bins per thread, scan over the wave, then over the 16 waves
+        const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+        const uint32_t mine = h0 + h1 + h2 + h3;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        if (tid == 0) sel_bin = 0xFFFFFFFFu;
+        __syncthreads();
+        uint32_t before = below;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        const uint32_t excl = before + incl - mine;  // eligible keys before this thread's 4 bins (chosen bins included)
+        if (excl < (uint32_t)kp && excl + mine >= (uint32_t)kp) {  // exactly one thread
+            uint32_t acc = excl;
+            const uint32_t hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if (acc < (uint32_t)kp && acc + hh[b] >= (uint32_t)kp) {
+                    sel_bin = 4 * tid + b;
+                    sel_below = acc;
+                }
+                acc += hh[b];
+            }
+        }
+        __syncthreads();
+        if (sel_bin == 0xFFFFFFFFu) break;  // fewer than kp eligible keys: everything passes
+        prefix_bits = round == 0 ? sel_bin : ((prefix_bits << 12) | sel_bin);
+        below = sel_below;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float thr = 3.0e38f;
+        if (sel_bin != 0xFFFFFFFFu) {
+            thr = key_from_ordered((prefix_bits << 8) | 0xFFu);  // the top of the chosen 24-bit bin
+            if (!(thr <= 3.0e38f)) thr = 3.0e38f;                // (NaN patterns sort last: keys are clamped anyway)
+        }
+        thr_out[q] = thr;
+        count_zero[q * kCandCountStride] = 0;
+    }
+}
+
+// ---- the tail of a fused-selection batch in ONE launch ---------------------------------------------------------------
+//
+// One block of 1024 threads per query, the query's collected candidates (<= kRefineMaxCands) in LDS:
+//   1. the kp best by the sweep's key (per-wave lists + block rank-merge, as everywhere);
+//   2. MODE > 0, bfloat16 sweeps: the sweep's key b of a candidate is within eps_b of its real-number key, so only
+//      candidates with b <= t_kp + W (t_kp = the kp-th best sweep key, W = 2 eps_b) can be among the kp best by a
+//      better key.  Those -- a few dozen of the ~1 000 collected -- are scored again in float32 (one wave per
+//      candidate, the float32 query in LDS) and the kp best of THEM by float32 key are the list; the band's edge
+//      E = t_kp + W goes to the host: every collected candidate outside the band has sweep key > E, which
+//      certification needs (scan_topk.cpp: gather_topk).  Re-scoring every candidate, as the first form of this
+//      stage did, cost 64 us per 96-query batch; the band costs a tenth.
+//   3. the query's sentinel rows (its first k eligible rows in visit order, whatever their key: DESIGN.md 2) are
+//      appended behind the list, so ONE rerank launch computes the float64 distances of both.
+// MODE 0: selection only (int8 / float32 sweeps: the collected keys are final).  1: cosine band, 2: euclid band.
+// A band that does not fit kRefineMaxBand (duplicate-heavy corpora) reports overflow through the hit counter, which
+// sends the batch down the score-matrix path like an overflowing candidate buffer.
+constexpr int kRefineThreads = 1024;
+constexpr int kRefineMaxCands = 8192;
+constexpr int kRefineMaxBand = 1024;
+constexpr int kRefineMaxKp = 256;
+
+template <int MODE>
+__global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8_t *rows, uint32_t pitch, int dim,
+                                                                     const double *q64, const double *qscale,
+                                                                     const double *qnorm2, const uint64_t *cand_buf,
+                                                                     uint32_t *cand_count, uint32_t cand_cap, int kp,
+                                                                     const uint64_t *sent, int n_sent, uint64_t *lists,
+                                                                     float *band_edge)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = kRefineThreads / 64;
+    const int q = blockIdx.x;
+    const uint32_t n = min(cand_count[q * kCandCountStride], cand_cap);
+    uint64_t *cand = reinterpret_cast<uint64_t *>(smem);                  // [kRefineMaxCands]
+    uint64_t *wl_lds = cand + kRefineMaxCands;                            // [NW][kp]
+    uint64_t *top = wl_lds + (size_t)NW * kp;                             // [kp]
+    uint64_t *band = top + kp;                                            // [kRefineMaxBand]
+    float *qf = reinterpret_cast<float *>(band + kRefineMaxBand);         // [dim] (MODE > 0)
+    __shared__ uint32_t n_band;
+    const uint64_t *src = cand_buf + (size_t)q * cand_cap;
+    uint64_t *out = lists + (size_t)q * (kp + n_sent);
+
+    for (uint32_t i = tid; i < n; i += kRefineThreads) cand[i] = src[i];
+    if (MODE > 0) {
+        const double sc = qscale[q];
+        for (int i = tid; i < dim; i += kRefineThreads) qf[i] = (float)(q64[(size_t)q * dim + i] * sc);
+    }
+    if (tid == 0) n_band = 0;
+    WaveList wl;
+    wl.init(wl_lds + (size_t)wave * kp, kp, lane);
+    __syncthreads();
+    for (uint32_t i = tid; i < ((n + kRefineThreads - 1) / kRefineThreads) * kRefineThreads; i += kRefineThreads) {
+        const bool ok = i < n;
+        wl.offer(ok, ok ? cand[i] : kInvalidCand, lane);
+    }
+    wl.flush(lane);
+    __syncthreads();
+    block_merge_lists(wl_lds, NW, kp, MODE > 0 ? top : out, tid, kRefineThreads);
+    for (int i = tid; i < n_sent; i += kRefineThreads) out[kp + i] = sent[(size_t)q * n_sent + i];
+    if (MODE == 0) return;
+    __syncthreads();
+
+    // the band: sweep key <= t_kp + W
+    const uint64_t kth = top[kp - 1];
+    float edge = 3.0e38f;  // fewer than kp candidates: everything collected is in the band
+    if (kth != kInvalidCand) {
+        const float t = key_from_ordered((uint32_t)(kth >> 32));
+        const float c = 1.01f * 0x1p-8f, nu = ((float)dim + 16.0f) * 0x1p-24f;
+        float eps;
+        if (MODE == 1) {
+            eps = c + 4.0f * nu + 1e-6f;
+        } else {  // key_eps (scan_query.cpp), bfloat16 euclid branch
+            const float qn = sqrtf((float)qnorm2[q]), rt = sqrtf(fmaxf(t, 0.0f));
+            const float s2 = 2.0f * qn + rt;
+            eps = 2.0f * c * qn * (1.1f * qn + rt) + c * c * qn * qn + 3.0f * nu * s2 * s2;
+        }
+        edge = t + 2.02f * eps;
+        if (!(edge < 3.0e38f)) edge = 3.0e38f;
+    }
+    const uint32_t uedge = ordered_key(edge);
+    for (uint32_t i = tid; i < n; i += kRefineThreads) {
+        if ((uint32_t)(cand[i] >> 32) <= uedge) {
+            const uint32_t at = atomicAdd(&n_band, 1u);
+            if (at < (uint32_t)kRefineMaxBand) band[at] = cand[i];
+        }
+    }
+    __syncthreads();
+    const uint32_t nb = n_band;
+    if (nb > (uint32_t)kRefineMaxBand) {  // (uniform over the block)
+        if (tid == 0) cand_count[q * kCandCountStride] = 0xFFFFFFFFu;  // the host redoes the batch (score matrix)
+        for (int i = tid; i < kp; i += kRefineThreads) out[i] = kInvalidCand;
+        return;
+    }
+    // float32 keys for the band: one wave per candidate
+    const float4 *qf4 = reinterpret_cast<const float4 *>(qf);
+    const int d4 = dim >> 2;
+    for (uint32_t ci = wave; ci < nb; ci += NW) {
+        const uint32_t row = (uint32_t)band[ci];
+        const float4 *rp = reinterpret_cast<const float4 *>(rows + (size_t)row * pitch);
+        float dot = 0.f, nrm = 0.f;
+        uint32_t nz = 0;
+        for (int i = lane; i < d4; i += 64) {
+            const float4 x = rp[i], y = qf4[i];
+            if (MODE == 1) {
+                dot = fmaf(x.x, y.x, dot); dot = fmaf(x.y, y.y, dot); dot = fmaf(x.z, y.z, dot); dot = fmaf(x.w, y.w, dot);
+                nrm = fmaf(x.x, x.x, nrm); nrm = fmaf(x.y, x.y, nrm); nrm = fmaf(x.z, x.z, nrm); nrm = fmaf(x.w, x.w, nrm);
+                nz |= (__float_as_uint(x.x) | __float_as_uint(x.y) | __float_as_uint(x.z) | __float_as_uint(x.w)) & 0x7FFFFFFFu;
+            } else {
+                const float a0 = x.x - y.x, a1 = x.y - y.y, a2 = x.z - y.z, a3 = x.w - y.w;
+                dot = fmaf(a0, a0, dot); dot = fmaf(a1, a1, dot); dot = fmaf(a2, a2, dot); dot = fmaf(a3, a3, dot);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            dot += __shfl_xor(dot, o);
+            if (MODE == 1) {
+                nrm += __shfl_xor(nrm, o);
+                nz |= __shfl_xor(nz, o);
+            }
+        }
+        float key;
+        if (MODE == 1) {  // exactly cand_rescore_kernel's key (the certification bound is the float32 sweeps')
+            key = -dot * __frsqrt_rn(nrm);
+            if (nrm == 0.f) key = nz ? -2.0f : 1.0f;
+            if (!(nrm <= 3.0e38f)) key = -2.0f;  // norm overflow: forced in (see RowAcc::finish)
+        } else {
+            key = dot;
+        }
+        if (!(key == key)) key = 3.0e38f;
+        if (key > 3.0e38f) key = 3.0e38f;
+        if (lane == 0) band[ci] = ((uint64_t)ordered_key(key) << 32) | row;
+    }
+    __syncthreads();
+    // the kp best of the band by float32 key: rank by counting (entries are unique: the row is part of the word)
+    for (int i = tid; i < kp; i += kRefineThreads) out[i] = kInvalidCand;
+    __syncthreads();
+    for (uint32_t i = tid; i < nb; i += kRefineThreads) {
+        const uint64_t mine = band[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < nb; j++) rank += band[j] < mine ? 1u : 0u;
+        if (rank < (uint32_t)kp) out[rank] = mine;
+    }
+    if (tid == 0) band_edge[q] = edge;
+}
+
 #endif  // SZG_MQ_PART == 0
 
 }  // namespace
@@ -1221,6 +1458,31 @@ hipError_t launch_cand_rescore(int metric, const uint8_t *rows, uint32_t pitch, 
         hipLaunchKernelGGL(cand_rescore_kernel<kEuclidean>, grid, dim3(256), lds, stream, rows, pitch, dim, q64,
                            qscale, cand_buf, cand_count, cand_cap);
     return hipGetLastError();
+}
+
+bool cand_refine_applies(int kp, uint32_t cand_cap, int dim, bool rescore)
+{
+    return kp <= kRefineMaxKp && cand_cap <= (uint32_t)kRefineMaxCands && (!rescore || (dim % 4 == 0 && dim <= 4096));
+}
+
+hipError_t launch_cand_refine(int mode, const uint8_t *rows, uint32_t pitch, int dim, const double *q64,
+                              const double *qscale, const double *qnorm2, const uint64_t *cand_buf, uint32_t *cand_count,
+                              uint32_t cand_cap, int kp, int n_queries, const uint64_t *sent, int n_sent,
+                              uint64_t *lists, float *band_edge, hipStream_t stream)
+{
+    if (!cand_refine_applies(kp, cand_cap, dim, mode > 0)) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)kRefineMaxCands + (size_t)(kRefineThreads / 64) * kp + kp + kRefineMaxBand) * sizeof(uint64_t) +
+                       (mode > 0 ? (size_t)dim * sizeof(float) : 0);
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(n_queries), dim3(kRefineThreads), lds, stream, rows, pitch, dim, q64, qscale, qnorm2,
+                           cand_buf, cand_count, cand_cap, kp, sent, n_sent, lists, band_edge);
+        return hipGetLastError();
+    };
+    if (mode == 0) return go(&cand_refine_kernel<0>);
+    if (mode == 1) return go(&cand_refine_kernel<1>);
+    return go(&cand_refine_kernel<2>);
 }
 
 size_t mq_lds_bytes(int qbits, int r16, int nb) { return (size_t)r16 * nb * (128 / qbits) * 16 * 4; }  // image only
@@ -1414,8 +1676,16 @@ hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_row
                             uint64_t *block_lists, hipStream_t stream, float *thr_out, uint32_t *count_zero)
 {
     if (thr_out && blocks_per_query != 1) return hipErrorInvalidValue;
-    const size_t lds = (size_t)4 * kp * sizeof(uint64_t);
-    hipLaunchKernelGGL(mq_select_kernel, dim3(blocks_per_query, n_queries), dim3(256), lds, stream, keys,
+    if (thr_out && kp >= 1) {  // the threshold pass: radix select (no lists)
+        hipLaunchKernelGGL(mq_thr_radix_kernel, dim3(n_queries), dim3(1024), 0, stream, keys, key_stride, n_rows,
+                           live_bits, allow_bits, allow_stride, kp, thr_out, count_zero);
+        return hipGetLastError();
+    }
+    // the threshold pass walks a query's prefix keys with ONE block (it publishes the threshold): latency-bound, so
+    // it gets 16 waves instead of 4 when their lists fit (50 -> ~15 us for a 96-query batch)
+    const int threads = thr_out && (size_t)16 * kp * sizeof(uint64_t) <= 48u * 1024u ? 1024 : 256;
+    const size_t lds = (size_t)(threads / 64) * kp * sizeof(uint64_t);
+    hipLaunchKernelGGL(mq_select_kernel, dim3(blocks_per_query, n_queries), dim3(threads), lds, stream, keys,
                        key_stride, n_rows, live_bits, allow_bits, allow_stride, kp, block_lists, thr_out,
                        count_zero);
     return hipGetLastError();

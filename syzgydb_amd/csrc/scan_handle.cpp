@@ -696,6 +696,9 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
     } else if (n == "query_batch") {
         if (value < 1 || value > kMaxBatch) return fail(SZG_E_INVALID, "query_batch out of range");
         ix->query_batch = (int)value;
+    } else if (n == "first_batch") {
+        if (value < 0 || value > kMaxBatch) return fail(SZG_E_INVALID, "first_batch out of range");
+        ix->first_batch = (int)value;
     } else if (n == "contexts") {
         if (value < 1 || value > ix->n_ctx) return fail(SZG_E_INVALID, "contexts out of range");
         for (Shard *sh : ix->shards) {   // call while no search is in flight
@@ -732,6 +735,8 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
     } else if (n == "mq_i8_groups") {
         if (value < 1 || value > 2) return fail(SZG_E_INVALID, "mq_i8_groups must be 1 or 2");
         ix->mq_i8_groups = (int)value;
+    } else if (n == "mq_refine") {
+        ix->mq_refine = value != 0;
     } else if (n == "mq_bf16") {
         ix->mq_bf16 = value != 0;
     } else if (n == "mq_overlap") {

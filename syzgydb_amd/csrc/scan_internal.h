@@ -199,6 +199,10 @@ struct Ctx {
     float *h_thr = nullptr;        // (pinned) the prefix thresholds of a two-stage batch, for certification
     double *h_qscale = nullptr, *d_qscale = nullptr;  // [128] float32-query scale per staged query (re-score)
     int kp_used = 0;               // candidates per query in h_out for the batch in flight
+    int out_stride = 0;            // entries per query in h_out: kp_used, + sent_n when the sentinels ride along
+    bool sent_deferred = false;    // the sentinel rows are staged (d_sent) but their distances not yet enqueued
+    bool sent_in_out = false;      // their distances are entries [kp_used, out_stride) of each query in h_out
+    bool mq_band_used = false;     // bfloat16 sweep refined by the band form: h_thr[128 + q] = the band's edge
     bool mq_stage2 = false;        // bfloat16 sweep -> float32 re-score of its candidates -> selection
     bool mq_bf16_used = false;     // the list keys of this batch are bfloat16-sweep keys (matrix form)
     uint64_t *d_cand = nullptr;
@@ -307,6 +311,7 @@ struct szg_index {
     int blocks_per_cu = 0;    // 0 = choose from the row format (scan_geometry)
     int block_threads = 256;
     int query_batch = 16;     // queries per scan launch
+    int first_batch = 4;      // ... of a call's first launch (0 = query_batch): the card starts sooner
     int shape_kernels = 1;    // use the row-shape-specialised scan kernels where they exist
     int ring = 0;             // tuning hook: 8 = always the deep piece ring
     int queries_per_launch = 16;  // sweeps one scan launch walks back to back (query-major)
@@ -319,6 +324,7 @@ struct szg_index {
     int mq_fused = 1;         // shared sweep: threshold-collect selection instead of a score matrix
     int mq_i8 = 1;            // 8-bit rows: exact integer shared sweep (v_mfma_i32_16x16x64_i8)
     int mq_i8_groups = 2;     // int8 sweeps: query groups of 48 one launch walks (1 or 2)
+    int mq_refine = 1;        // shared sweeps: the batch's tail is one cand_refine launch + one rerank
     int mq_bf16 = 1;          // 32-bit rows: shared sweep on bfloat16 roundings (v_mfma_f32_16x16x32_bf16), certified
                               // against its own bound and re-ranked in float64 like every other path
     int mq_overlap = 1;       // bfloat16 sweeps: a batch's threshold pass and its post-processing run on the context's
@@ -356,6 +362,7 @@ bool history_dependent(const double *dist, size_t n, int k);
 // ---- scan_query.cpp
 szg::RowMap choose_map(int r16, bool tiled = false);
 void prep_query(const szg_index *ix, const double *q, uint8_t *out_sw, QMeta *meta);
+void prep_query_meta(const szg_index *ix, const double *q, QMeta *meta);  // the constants only (shared sweeps)
 double key_eps(const szg_index *ix, double key, const QMeta &m);
 bool mq_uses_i8(const szg_index *ix);
 bool mq_uses_bf16(const szg_index *ix);
@@ -384,11 +391,14 @@ Shard *append_target(szg_index *ix);
 // ---- scan_topk.cpp
 LaunchGeom scan_geometry(const szg_index *ix, const Shard *sh, int kp, bool plain_topk = false);
 size_t shard_words(const Shard *sh);
-int enqueue_queries(szg_index *ix, Shard *sh, Ctx *c, const double *q, int nq, const uint64_t *const *masks);
+int enqueue_queries(szg_index *ix, Shard *sh, Ctx *c, const double *q, int nq, const uint64_t *const *masks,
+                    bool with_single_form = true);
 void fill_scan_args(const szg_index *ix, const Shard *sh, const Ctx *c, bool has_allow, int slot, int nq,
                     szg::ScanArgs *a);
 int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg::ScanArgs> &a, const LaunchGeom &g);
 int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allow);
+// float64 distances of the staged sentinel rows (d_sent) on `stream`, results to h_sent_out
+int launch_sentinel_rerank(szg_index *ix, Shard *sh, Ctx *c, int nq, hipStream_t stream);
 int finish_timing(szg_index *ix, Ctx *c);
 int run_collect(szg_index *ix, Shard *sh, Ctx *c, int slot, float thr_key, bool has_allow, std::vector<Cand> *cands);
 // fraction of the shard's rows that staged query `slot` may visit (tombstones, and a sample of its filter mask's words)
@@ -406,6 +416,9 @@ int search_radius_impl(szg_index *ix, const double *queries, int n_queries, cons
 // ---- scan_mq.cpp
 int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int nq, int nb, bool has_allow,
                     bool force_matrix = false);
+
+// the batch's tail will compute the sentinel rows' distances itself (stage them, do not launch their own rerank)
+bool mq_tail_takes_sentinels(const szg_index *ix, const Shard *sh, int kp, int kp_wide, int nq, int nb);
 
 // ---- scan_sketch.cpp
 int search_topk_any(szg_index *ix, const double *queries, int n_queries, int k, const uint64_t *allow_bits,
@@ -451,6 +464,7 @@ struct Ticket {
     int kp = 0, kp_wide = 0;
     bool failed = false;         // enqueueing failed part-way: drain and release only
     bool any_mask = false;       // some query of the batch carries a filter mask
+    bool lazy_single = false;    // shared sweep: the queries' single-query form (h_qsw / d_qsw) has not been built
     szg_index *owner = nullptr;
     Ticket() = default;
     Ticket(Ticket &&) = default;

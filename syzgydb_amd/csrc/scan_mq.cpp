@@ -79,54 +79,53 @@ void build_image_f32(const szg_index *ix, Ctx *c, int nq, int nb)
     }
 }
 
-// top-k pass for the nq staged queries through ONE shared sweep:
-// score matrix -> per-query selection -> merges -> rerank -> D2H (async)
-// kp_wide: the list length when the lists hold bfloat16-sweep keys themselves (matrix form: small
-// shards, overflow reruns), whose error band needs more candidates than kp
-int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int nq, int nb, bool has_allow,
-                    bool force_matrix)
+// ---- one batch through ONE shared sweep --------------------------------------------------------------------------
+
+namespace {
+
+// Fused selection: sweep a prefix of the rows into a small score matrix, take each query's kp-th best key there as
+// its threshold, then sweep everything and collect the (query, row) pairs at or below their threshold -- about
+// `hits` per query -- instead of writing and re-reading n_rows x batch keys.  Every row outside a query's buffer
+// has a key above the threshold, which is >= the kp-th kept key: certification is unchanged.
+struct MqPlan {
+    bool i8 = false, bf16 = false;
+    int groups = 1;            // int8 sweeps: query groups of 48 one launch walks
+    size_t group_stride = 0;   // bytes between the groups' images
+    size_t img = 0;            // bytes of the LDS image(s)
+    uint64_t prefix = 0;       // rows of the threshold pass
+    bool fused = false;        // threshold-collect selection (else: score matrix of every row)
+    bool stage2 = false;       // bfloat16 sweep whose collected candidates get float32 keys before the selection
+    bool refine = false;       // the batch's tail is one cand_refine launch + one rerank (sentinels included)
+    uint32_t cand_cap = 0;     // entries per query's candidate buffer
+    size_t key_stride = 0;     // floats per query in the score matrix
+    int kp = 0;                // list length (kp_wide when the lists hold bfloat16 keys themselves)
+};
+
+MqPlan mq_plan(const szg_index *ix, const Shard *sh, int kp, int kp_wide, int nq, int nb, bool force_matrix)
 {
-    HIPCHK(hipSetDevice(sh->device));
+    MqPlan p;
     const int r16 = ix->map.r16;
-    const bool i8 = mq_uses_i8(ix);
-    const bool bf16 = mq_uses_bf16(ix);
-    // int8 sweeps: up to two groups of 16 * nb queries per launch (the kernel walks their passes back to back)
-    const int groups = i8 ? (nq + 16 * nb - 1) / (16 * nb) : 1;
-    // (the kernel indexes thresholds, keys and candidates of group g by 48 g + q: a second group needs full groups)
-    if (groups > 2 || (groups == 2 && nb != 3)) return fail(SZG_E_INVALID, "int8 shared sweep: two groups need 48 queries each");
-    const size_t group_stride =
-        i8 ? ((szg::mq_i8_image_bytes(ix->bits, r16, nb) + 3 * 48 * sizeof(float) + 255) & ~(size_t)255) : 0;
-    const size_t img = bf16 ? szg::mq_bf16_image_bytes(r16, nb)
-                            : i8 ? group_stride * groups : szg::mq_lds_bytes(ix->bits, r16, nb);
-    int rc = ensure_host(&c->h_mq, &c->h_mq_cap, img);
-    if (rc) return rc;
-    rc = ensure_dev(&c->d_mq, &c->d_mq_cap, img);
-    if (rc) return rc;
-    memset(c->h_mq, 0, img);
-    if (bf16) build_image_bf16(ix, c, nq, nb);
-    else if (i8) build_image_i8(ix, c, nq, nb, group_stride);
-    else build_image_f32(ix, c, nq, nb);
-    HIPCHK(hipMemcpyAsync(c->d_mq, c->h_mq, img, hipMemcpyHostToDevice, c->stream));
-
-    // Fused selection: sweep a prefix of the rows into a small score matrix, take each
-    // query's kp-th best key there as its threshold, then sweep everything and collect the
-    // (query, row) pairs at or below their threshold -- about `hits` per query -- instead of
-    // writing and re-reading n_rows x batch keys.  Every row outside a query's buffer has a
-    // key above the threshold, which is >= the kp-th kept key: certification is unchanged.
-    // bfloat16 sweep: the collected candidates are scored again in float32 before the selection
-    // (two stages); rows outside the buffer are bounded by the bfloat16 threshold, rows inside it by
-    // the float32 keys.  In matrix form its lists hold bfloat16 keys and are kp_wide long.
+    p.i8 = mq_uses_i8(ix);
+    p.bf16 = mq_uses_bf16(ix);
+    p.groups = p.i8 ? (nq + 16 * nb - 1) / (16 * nb) : 1;
+    p.group_stride = p.i8 ? ((szg::mq_i8_image_bytes(ix->bits, r16, nb) + 3 * 48 * sizeof(float) + 255) & ~(size_t)255) : 0;
+    p.img = p.bf16 ? szg::mq_bf16_image_bytes(r16, nb) : p.i8 ? p.group_stride * p.groups : szg::mq_lds_bytes(ix->bits, r16, nb);
     const uint64_t hits = std::max<uint64_t>((uint64_t)ix->mq_hits, 16ull * kp);
-    uint64_t prefix = ((sh->n_rows * (uint64_t)kp + hits - 1) / hits + 15) & ~15ull;
-    prefix = std::max<uint64_t>(prefix, 16ull * kp);
-    const bool fused = ix->mq_fused && !force_matrix && prefix * 4 <= sh->n_rows;
-    const bool stage2 = bf16 && fused;
-    if (bf16 && !fused) kp = std::max(kp, kp_wide);
-    const uint32_t cand_cap = (uint32_t)(4 * hits);
-    const size_t key_stride = fused ? (size_t)prefix : (((size_t)sh->n_rows + 3) & ~(size_t)3);
+    p.prefix = ((sh->n_rows * (uint64_t)kp + hits - 1) / hits + 15) & ~15ull;
+    p.prefix = std::max<uint64_t>(p.prefix, 16ull * kp);
+    p.fused = ix->mq_fused && !force_matrix && p.prefix * 4 <= sh->n_rows;
+    p.stage2 = p.bf16 && p.fused;
+    p.kp = p.bf16 && !p.fused ? std::max(kp, kp_wide) : kp;
+    p.cand_cap = (uint32_t)(4 * hits);
+    p.key_stride = p.fused ? (size_t)p.prefix : (((size_t)sh->n_rows + 3) & ~(size_t)3);
+    p.refine = p.fused && ix->mq_refine && szg::cand_refine_applies(p.kp, p.cand_cap, ix->dim, p.stage2);
+    return p;
+}
 
-    const int sb = 16;  // select blocks per query
-    const size_t need = (size_t)nq * sb * kp;
+int mq_buffers(szg_index *ix, Ctx *c, const MqPlan &p, int nq, int n_out)
+{
+    const int sb = 16;  // select blocks per query (score-matrix form)
+    const size_t need = (size_t)nq * std::max<size_t>((size_t)sb * p.kp, (size_t)n_out);
     if (c->lists_cap < need) {
         if (c->d_lists_a) HIPCHK(hipFree(c->d_lists_a));
         if (c->d_lists_b) HIPCHK(hipFree(c->d_lists_b));
@@ -136,37 +135,82 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
         HIPCHK(hipMalloc((void **)&c->d_lists_b, need * sizeof(uint64_t)));
         c->lists_cap = need;
     }
-    rc = ensure_dev(&c->d_out, &c->d_out_cap, (size_t)nq * kp);
+    int rc = ensure_dev(&c->d_out, &c->d_out_cap, (size_t)nq * n_out);
     if (rc) return rc;
-    rc = ensure_host(&c->h_out, &c->h_out_cap, (size_t)nq * kp);
+    rc = ensure_host(&c->h_out, &c->h_out_cap, (size_t)nq * n_out);
     if (rc) return rc;
-    rc = ensure_dev(&c->d_keys, &c->keys_cap, key_stride * nq);
+    rc = ensure_dev(&c->d_keys, &c->keys_cap, p.key_stride * nq);
     if (rc) return rc;
-    if (fused) {
-        if (!c->d_thr) HIPCHK(hipMalloc((void **)&c->d_thr, 128 * sizeof(float)));
+    if (p.fused) {
+        if (!c->d_thr) HIPCHK(hipMalloc((void **)&c->d_thr, 256 * sizeof(float)));  // thresholds | band edges
+        if (!c->h_thr) HIPCHK(hipHostMalloc((void **)&c->h_thr, 256 * sizeof(float), hipHostMallocDefault));
         if (!c->d_cand_count) HIPCHK(hipMalloc((void **)&c->d_cand_count, 128 * szg::kCandCountStride * sizeof(uint32_t)));
         if (!c->h_cand_count)
             HIPCHK(hipHostMalloc((void **)&c->h_cand_count, 128 * szg::kCandCountStride * sizeof(uint32_t), hipHostMallocDefault));
-        rc = ensure_dev(&c->d_cand, &c->cand_cap_total, (size_t)cand_cap * nq);
+        rc = ensure_dev(&c->d_cand, &c->cand_cap_total, (size_t)p.cand_cap * nq);
         if (rc) return rc;
     }
-    if (stage2) {
-        if (!c->h_thr) HIPCHK(hipHostMalloc((void **)&c->h_thr, 128 * sizeof(float), hipHostMallocDefault));
-        if (!c->h_qscale) HIPCHK(hipHostMalloc((void **)&c->h_qscale, 128 * sizeof(double), hipHostMallocDefault));
-        if (!c->d_qscale) HIPCHK(hipMalloc((void **)&c->d_qscale, 128 * sizeof(double)));
+    if (p.stage2) {  // float32 re-score: 1/|q| (cosine) or 1 per query, then |g|^2 (the euclid band's width)
+        if (!c->h_qscale) HIPCHK(hipHostMalloc((void **)&c->h_qscale, 256 * sizeof(double), hipHostMallocDefault));
+        if (!c->d_qscale) HIPCHK(hipMalloc((void **)&c->d_qscale, 256 * sizeof(double)));
         for (int q = 0; q < nq; q++) {
             const double m1 = c->meta[q].m1;
             c->h_qscale[q] = ix->metric == SZG_COSINE ? (m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0) : 1.0;
+            c->h_qscale[128 + q] = c->meta[q].qnorm2;
         }
-        HIPCHK(hipMemcpyAsync(c->d_qscale, c->h_qscale, sizeof(double) * nq, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_qscale, c->h_qscale, sizeof(double) * 256, hipMemcpyHostToDevice, c->stream));
     }
-    c->mq_fused_used = fused;
-    c->mq_cand_cap = cand_cap;
+    return SZG_OK;
+}
+
+}  // namespace
+
+bool mq_tail_takes_sentinels(const szg_index *ix, const Shard *sh, int kp, int kp_wide, int nq, int nb)
+{
+    return mq_plan(ix, sh, kp, kp_wide, nq, nb, false).refine;
+}
+
+// top-k pass for the nq staged queries through ONE shared sweep:
+//   threshold pass (prefix) -> full sweep, collecting -> cand_refine (selection, float32 re-score of the bfloat16
+//   band, sentinel rows appended) -> ONE rerank -> D2H          [fused selection, the default]
+//   full sweep into a score matrix -> per-query selection -> merges -> rerank -> D2H   [small shards, overflow reruns]
+// kp_wide: the list length when the lists hold bfloat16-sweep keys themselves (matrix form), whose error band needs
+// more candidates than kp.
+int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int nq, int nb, bool has_allow,
+                    bool force_matrix)
+{
+    HIPCHK(hipSetDevice(sh->device));
+    const MqPlan p = mq_plan(ix, sh, kp, kp_wide, nq, nb, force_matrix);
+    // (the kernel indexes thresholds, keys and candidates of group g by 48 g + q: a second group needs full groups)
+    if (p.groups > 2 || (p.groups == 2 && nb != 3)) return fail(SZG_E_INVALID, "int8 shared sweep: two groups need 48 queries each");
+    kp = p.kp;
+    int rc = ensure_host(&c->h_mq, &c->h_mq_cap, p.img);
+    if (rc) return rc;
+    rc = ensure_dev(&c->d_mq, &c->d_mq_cap, p.img);
+    if (rc) return rc;
+    memset(c->h_mq, 0, p.img);
+    if (p.bf16) build_image_bf16(ix, c, nq, nb);
+    else if (p.i8) build_image_i8(ix, c, nq, nb, p.group_stride);
+    else build_image_f32(ix, c, nq, nb);
+    HIPCHK(hipMemcpyAsync(c->d_mq, c->h_mq, p.img, hipMemcpyHostToDevice, c->stream));
+
+    // sentinel rows staged by the caller ride in the batch's one rerank when the tail is the refine launch;
+    // otherwise (score-matrix form, an overflow rerun) they get their own
+    const int n_sent = c->sent_deferred ? c->sent_n : 0;
+    const bool merge_sent = p.refine && n_sent > 0;
+    const int n_out = kp + (merge_sent ? n_sent : 0);
+    rc = mq_buffers(ix, c, p, nq, n_out);
+    if (rc) return rc;
+    c->mq_fused_used = p.fused;
+    c->mq_cand_cap = p.cand_cap;
     c->mq_nb = nb;
     c->mq_has_allow = has_allow;
     c->kp_used = kp;
-    c->mq_stage2 = stage2;
-    c->mq_bf16_used = bf16 && !stage2;
+    c->out_stride = n_out;
+    c->sent_in_out = merge_sent;
+    c->mq_stage2 = p.stage2;
+    c->mq_band_used = p.stage2 && p.refine;
+    c->mq_bf16_used = p.bf16 && !p.stage2;
 
     szg::MqArgs a;
     memset(&a, 0, sizeof(a));
@@ -175,72 +219,54 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
     a.pitch = ix->pitch;
     a.tiled = ix->layout.tiled;
     a.steps = ix->layout.steps;
-    a.r16 = r16;
+    a.r16 = ix->map.r16;
     a.dim = ix->dim;
     a.queries = c->d_mq;
     a.n_queries = nq;
-    a.n_groups = groups;
-    a.group_stride = (uint32_t)group_stride;
+    a.n_groups = p.groups;
+    a.group_stride = (uint32_t)p.group_stride;
     a.metric = ix->metric;
     for (int q = 0; q < nq && q < szg::kMqMaxQueries; q++) a.qnorm2[q] = (float)c->meta[q].qnorm2;
     a.keys = c->d_keys;
-    a.key_stride = key_stride;
+    a.key_stride = p.key_stride;
     a.zero16 = sh->zero16;
     a.norm_bias = (float)ix->norm_bias;
-    // The sweep wants every CU to itself (one 1024-thread block and up to 144 KiB of
-    // LDS per CU), so the whole batch -- sweep, selection, merges, rerank, copy --
-    // goes onto the shard's scan stream, one batch after the other; only uploads
-    // overlap on the context's stream.
+    const uint64_t *live = sh->has_dead ? sh->live_bits : nullptr;
+    const uint64_t *allow = has_allow ? c->d_allow : nullptr;
+    const uint32_t words = (uint32_t)shard_words(sh);
+    auto launch_score = [&](const szg::MqArgs &x, hipStream_t s2) -> hipError_t {
+        if (p.bf16) return szg::launch_mq_score_bf16(x, nb, sh->cu_count, s2);
+        return p.i8 ? szg::launch_mq_score_i8(ix->bits, x, nb, sh->cu_count, s2)
+                    : szg::launch_mq_score(ix->bits, x, nb, sh->cu_count, s2);
+    };
+    // The sweep wants every CU to itself (one big block and up to 150 KiB of LDS per CU), so the batch's kernels go
+    // onto the shard's scan stream one after the other; uploads -- and for the HBM-bound sweeps (mq_overlap) the
+    // threshold pass and the tail -- ride on the context's stream beside the neighbouring batches' sweeps.
     {
         std::lock_guard<std::mutex> lk(sh->chain_mu);
         hipStream_t st = ix->serialize_scans ? sh->scan_stream : c->stream;
-        const bool overlap = (bf16 || i8) && ix->mq_overlap && st != c->stream;  // the HBM-bound sweeps
-        // (overlap: the threshold pass goes ahead on the context's stream, the sweep follows on the scan stream)
+        const bool overlap = (p.bf16 || p.i8) && ix->mq_overlap && st != c->stream;
         hipStream_t head = overlap ? c->stream : st;
         if (st != c->stream && !overlap) {
             HIPCHK(hipEventRecord(c->ev_up, c->stream));
             HIPCHK(hipStreamWaitEvent(st, c->ev_up, 0));
         }
-        auto launch_score = [&](const szg::MqArgs &x, hipStream_t s2) -> hipError_t {
-            if (bf16) return szg::launch_mq_score_bf16(x, nb, sh->cu_count, s2);
-            return i8 ? szg::launch_mq_score_i8(ix->bits, x, nb, sh->cu_count, s2)
-                      : szg::launch_mq_score(ix->bits, x, nb, sh->cu_count, s2);
-        };
-        // score matrix of rows [0, n_sel) -> per-query sorted list of kp (returns its buffer)
-        auto select_chain = [&](uint32_t n_sel, size_t kstride, hipStream_t s2, uint64_t **out) -> hipError_t {
-            hipError_t e = szg::launch_mq_select(c->d_keys, kstride, n_sel, sh->has_dead ? sh->live_bits : nullptr,
-                                                 has_allow ? c->d_allow : nullptr, (uint32_t)shard_words(sh),
-                                                 kp, nq, sb, c->d_lists_a, s2);
-            int n_lists = sb;
-            uint64_t *src = c->d_lists_a, *dst = c->d_lists_b;
-            const int fan = szg::merge_fan(kp);
-            while (e == hipSuccess && n_lists > 1) {
-                e = szg::launch_merge(src, n_lists, kp, nq, dst, s2);
-                n_lists = (n_lists + fan - 1) / fan;
-                std::swap(src, dst);
-            }
-            *out = src;
-            return e;
-        };
-        uint64_t *src = nullptr;
-        if (fused) {
+        if (p.fused) {
             szg::MqArgs pa = a;  // the prefix, into the (small) score matrix
-            pa.n_rows = (uint32_t)prefix;
+            pa.n_rows = (uint32_t)p.prefix;
             HIPCHK(launch_score(pa, head));
-            // one block per query selects over the prefix's keys, publishes the query's
-            // threshold and zeroes its hit counter
-            HIPCHK(szg::launch_mq_select(c->d_keys, key_stride, (uint32_t)prefix,
-                                         sh->has_dead ? sh->live_bits : nullptr, has_allow ? c->d_allow : nullptr,
-                                         (uint32_t)shard_words(sh), kp, nq, 1, c->d_lists_a, head, c->d_thr,
-                                         c->d_cand_count));
+            // one block per query selects over the prefix's keys, publishes the query's threshold and zeroes its
+            // hit counter
+            HIPCHK(szg::launch_mq_select(c->d_keys, p.key_stride, (uint32_t)p.prefix, live, allow, words, kp, nq, 1,
+                                         c->d_lists_a, head, c->d_thr, c->d_cand_count));
             a.collect = 1;
             a.thr = c->d_thr;
             a.cand_buf = c->d_cand;
             a.cand_count = c->d_cand_count;
-            a.cand_cap = cand_cap;
-            a.live_bits = sh->has_dead ? sh->live_bits : nullptr;
-            a.allow_bits = has_allow ? c->d_allow : nullptr;
-            a.allow_stride = (uint32_t)shard_words(sh);
+            a.cand_cap = p.cand_cap;
+            a.live_bits = live;
+            a.allow_bits = allow;
+            a.allow_stride = words;
         }
         if (overlap) {
             HIPCHK(hipEventRecord(c->ev_up, c->stream));
@@ -251,34 +277,51 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
         if (ix->timing) {
             HIPCHK(hipEventRecord(c->ev_scan1, st));
             c->timed_scan = true;
-            c->timed_n = groups;  // (passes: an int8 launch may walk two)
+            c->timed_n = p.groups;  // (passes: an int8 launch may walk two)
         }
-        // The selection, merges, rerank and copy-back of this batch either follow on the scan
-        // stream (default) or, with "mq_tail_overlap", on the context's stream, where they run
-        // beside the NEXT batch's sweep (the sweep is MFMA-bound and leaves wave slots free).
         hipStream_t tail = st;
         if ((ix->mq_tail_overlap || overlap) && st != c->stream) {
             HIPCHK(hipEventRecord(c->ev_scan_done, st));
             HIPCHK(hipStreamWaitEvent(c->stream, c->ev_scan_done, 0));
             tail = c->stream;
         }
-        if (stage2) {
-            HIPCHK(szg::launch_cand_rescore(ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64, c->d_qscale, c->d_cand,
-                                            c->d_cand_count, cand_cap, nq, tail));
-            HIPCHK(hipMemcpyAsync(c->h_thr, c->d_thr, 128 * sizeof(float), hipMemcpyDeviceToHost, tail));
+        uint64_t *src = c->d_lists_a;
+        if (p.refine) {
+            const int mode = !p.stage2 ? 0 : (ix->metric == SZG_COSINE ? 1 : 2);
+            HIPCHK(szg::launch_cand_refine(mode, sh->rows, ix->pitch, ix->dim, c->d_q64, c->d_qscale,
+                                           c->d_qscale ? c->d_qscale + 128 : nullptr, c->d_cand, c->d_cand_count,
+                                           p.cand_cap, kp, nq, merge_sent ? c->d_sent : nullptr, merge_sent ? n_sent : 0,
+                                           c->d_lists_a, c->d_thr + 128, tail));
+        } else if (p.fused) {
+            if (p.stage2)
+                HIPCHK(szg::launch_cand_rescore(ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64, c->d_qscale, c->d_cand,
+                                                c->d_cand_count, p.cand_cap, nq, tail));
+            HIPCHK(szg::launch_cand_select(c->d_cand, c->d_cand_count, p.cand_cap, kp, nq, c->d_lists_a, tail));
+        } else {
+            // score matrix of every row -> per-query sorted lists of kp -> merged
+            HIPCHK(szg::launch_mq_select(c->d_keys, p.key_stride, (uint32_t)sh->n_rows, live, allow, words, kp, nq, 16,
+                                         c->d_lists_a, tail));
+            int n_lists = 16;
+            uint64_t *dst = c->d_lists_b;
+            const int fan = szg::merge_fan(kp);
+            while (n_lists > 1) {
+                HIPCHK(szg::launch_merge(src, n_lists, kp, nq, dst, tail));
+                n_lists = (n_lists + fan - 1) / fan;
+                std::swap(src, dst);
+            }
         }
-        if (fused) {
-            HIPCHK(szg::launch_cand_select(c->d_cand, c->d_cand_count, cand_cap, kp, nq, c->d_lists_a, tail));
-            src = c->d_lists_a;
+        if (p.fused) {
+            HIPCHK(hipMemcpyAsync(c->h_thr, c->d_thr, 256 * sizeof(float), hipMemcpyDeviceToHost, tail));
             HIPCHK(hipMemcpyAsync(c->h_cand_count, c->d_cand_count, 128 * szg::kCandCountStride * sizeof(uint32_t),
                                   hipMemcpyDeviceToHost, tail));
-        } else {
-            HIPCHK(select_chain((uint32_t)sh->n_rows, key_stride, tail, &src));
         }
-        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, src,
-                                  nullptr, (uint32_t)kp, nq, c->d_out, tail));
-        HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp * nq,
-                              hipMemcpyDeviceToHost, tail));
+        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, src, nullptr,
+                                  (uint32_t)n_out, nq, c->d_out, tail));
+        HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * n_out * nq, hipMemcpyDeviceToHost, tail));
+        if (n_sent > 0 && !merge_sent) {  // deferred sentinels the tail could not take along
+            rc = launch_sentinel_rerank(ix, sh, c, nq, tail);
+            if (rc) return rc;
+        }
         if (tail != c->stream) {
             HIPCHK(hipEventRecord(c->ev_scan_done, st));
             HIPCHK(hipStreamWaitEvent(c->stream, c->ev_scan_done, 0));
@@ -286,11 +329,11 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
     }
     {
         std::lock_guard<std::mutex> lk(ix->stats_mu);
-        ix->stats.scan_launches += (uint64_t)groups;
-        ix->stats.scan_bytes += (uint64_t)groups * sh->n_rows * (uint64_t)ix->row_bytes;  // ONE pass per group of the batch
-        ix->stats.mq_launches += (uint64_t)groups;
+        ix->stats.scan_launches += (uint64_t)p.groups;
+        ix->stats.scan_bytes += (uint64_t)p.groups * sh->n_rows * (uint64_t)ix->row_bytes;  // ONE pass per group of the batch
+        ix->stats.mq_launches += (uint64_t)p.groups;
         ix->stats.mq_queries += (uint64_t)nq;
-        ix->stats.mq_bf16_sweeps += bf16 ? 1 : 0;
+        ix->stats.mq_bf16_sweeps += p.bf16 ? 1 : 0;
     }
     if (ix->timing >= 2) HIPCHK(hipEventRecord(c->ev_all1, c->stream));
     return SZG_OK;

@@ -56,12 +56,11 @@ inline long long round_clamp(double t, double lim)
 //    euclid) quantized to integers Q_i = round(v_i / qscale) and split into
 //    balanced digit planes (3 x int8 radix 128, or 5 x int4 radix 16), one
 //    16-byte plane word per 16-byte piece of the row.
-void prep_query(const szg_index *ix, const double *q, uint8_t *out_sw, QMeta *meta)
+// The constants every path needs (norms of the caller's and of the prepared query); returns the largest
+// |prepared element| and the scale q -> prepared query.
+static double prep_query_norms(const szg_index *ix, const double *q, QMeta *meta, double *scale_out)
 {
     const int dim = ix->dim, bits = ix->bits;
-    const int E = 128 / bits;
-    const int r16 = ix->map.r16;
-    memset(out_sw, 0, ix->qsw_bytes);
     *meta = QMeta{};
     double m1 = 0.0;
     for (int i = 0; i < dim; i++) m1 += q[i] * q[i];
@@ -80,6 +79,26 @@ void prep_query(const szg_index *ix, const double *q, uint8_t *out_sw, QMeta *me
     }
     meta->qnorm = std::sqrt(nrm);
     meta->qnorm2 = nrm;
+    *scale_out = scale;
+    return vmax;
+}
+
+// Shared sweeps stage their own image of the batch; the single-query form below is only needed if a query of the
+// batch escalates (a collect sweep), so a batch prepares just the constants and builds that form on demand.
+void prep_query_meta(const szg_index *ix, const double *q, QMeta *meta)
+{
+    double scale;
+    (void)prep_query_norms(ix, q, meta, &scale);
+}
+
+void prep_query(const szg_index *ix, const double *q, uint8_t *out_sw, QMeta *meta)
+{
+    const int dim = ix->dim, bits = ix->bits;
+    const int E = 128 / bits;
+    const int r16 = ix->map.r16;
+    memset(out_sw, 0, ix->qsw_bytes);
+    double scale;
+    const double vmax = prep_query_norms(ix, q, meta, &scale);
     if (bits == 8 || bits == 4) {
         const double Qmax = bits == 8 ? 1000000.0 : szg::kQmax4;
         const double qs = (vmax > 0 && std::isfinite(vmax)) ? vmax / Qmax : 1.0;

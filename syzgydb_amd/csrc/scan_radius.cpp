@@ -29,6 +29,33 @@ namespace {
 
 constexpr size_t kRadiusCapMin = 1024;      // entries per sweep a batch's buffers start with
 constexpr size_t kRadiusCapMax = 1u << 20;  // beyond this a query goes through run_collect on its own
+constexpr size_t kRadiusBlockCopyBytes = 2u << 20;  // a batch's re-ranked hits travel as one block up to this size
+
+// consider()'s radius branch (collection.go:598-605) over the candidates in visit order -- every record with
+// distance <= Radius is pushed onto the max-heap -- then the pop loop (:694-697).  Popping a heap of pairwise
+// distinct priorities yields them in descending order whatever the push order was, so the result is simply the hits
+// sorted by distance; only when two hits share a distance (or one is NaN, which `<=` never admits anyway) does the
+// order inside the tie depend on the heap's history, and only then is the heap replayed (three times the work).
+void radius_assemble(std::vector<Cand> &cs, double radius, std::vector<HeapItem> *out)
+{
+    size_t n = 0;
+    for (size_t i = 0; i < cs.size(); i++)
+        if (cs[i].dist <= radius) cs[n++] = cs[i];
+    cs.resize(n);
+    std::sort(cs.begin(), cs.end(), [](const Cand &x, const Cand &y) { return x.dist < y.dist; });
+    bool tie = false;
+    for (size_t i = 1; i < n && !tie; i++) tie = cs[i].dist == cs[i - 1].dist;
+    if (!tie) {
+        out->resize(n);
+        for (size_t i = 0; i < n; i++) (*out)[i] = HeapItem{cs[i].row, cs[i].dist};
+        return;
+    }
+    std::sort(cs.begin(), cs.end(), [](const Cand &x, const Cand &y) { return x.row < y.row; });
+    GoHeap h;
+    h.a.reserve(n);
+    for (const Cand &c : cs) h.push(HeapItem{c.row, c.dist});
+    h.drain(out);
+}
 
 struct RadiusCall;
 struct RadiusTicket {
@@ -36,6 +63,7 @@ struct RadiusTicket {
     std::vector<Ctx *> ctx;       // one per shard
     std::vector<float> thr;       // key threshold per query
     std::vector<size_t> cap;      // per shard: entries per sweep of this batch's buffers
+    std::vector<uint8_t> copied;  // per shard: the block of re-ranked hits was copied back at enqueue time
     bool any_mask = false;
     bool failed = false;
     RadiusCall *owner = nullptr;
@@ -129,6 +157,16 @@ int RadiusCall::enqueue_shard(RadiusTicket &t, size_t s)
     HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, c->d_collect, c->d_count,
                               (uint32_t)cap, t.nq, c->d_out, c->stream, szg::kCandCountStride));
     HIPCHK(hipMemcpyAsync(c->h_count, c->d_count, sizeof(uint32_t) * n_count, hipMemcpyDeviceToHost, c->stream));
+    // the re-ranked hits: while the batch's buffers are small (the usual hundreds of hits per query) the whole block
+    // follows in ONE copy right here -- finish() then needs a single wait; larger ones are copied hit list by hit
+    // list once the counts are known
+    t.copied[s] = cap * (size_t)t.nq * sizeof(szg::RerankOut) <= kRadiusBlockCopyBytes;
+    if (t.copied[s]) {
+        rc = ensure_host(&c->h_out, &c->h_out_cap, cap * (size_t)t.nq);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, cap * (size_t)t.nq * sizeof(szg::RerankOut), hipMemcpyDeviceToHost,
+                              c->stream));
+    }
     return SZG_OK;
 }
 
@@ -190,28 +228,29 @@ int RadiusCall::finish(RadiusTicket &t)
         if (e != hipSuccess) return fail(SZG_E_DEVICE, "hipStreamSynchronize", e);
         rc = finish_timing(ix, c);
         if (rc) break;
-        // exact-size copies of each sweep's re-ranked hits, back to back in the pinned buffer
         const size_t cap = t.cap[s];
-        size_t total = 0, most = 0;
-        std::vector<size_t> off(t.nq + 1, 0);
+        size_t most = 0;
+        std::vector<size_t> cnt(t.nq, 0), off(t.nq + 1, 0);
         for (int j = 0; j < t.nq; j++) {
             const size_t n = c->h_count[(size_t)j * szg::kCandCountStride];
             most = std::max(most, n);
             if (n > cap) redo[j] = 1;
-            off[j + 1] = off[j] + (n > cap ? 0 : n);
+            cnt[j] = n > cap ? 0 : n;
+            off[j + 1] = off[j] + cnt[j];
         }
-        total = off[t.nq];
         // the next batch on this context starts with room for what this one saw (and shrinks again slowly)
         size_t want = kRadiusCapMin;
         while (want < most + most / 4 && want < kRadiusCapMax) want <<= 1;
         c->radius_cap = std::max(want, c->radius_cap - c->radius_cap / 8);
-        if (total) {
-            rc = ensure_host(&c->h_out, &c->h_out_cap, total);
+        if (t.copied[s]) {  // hits of sweep j at h_out + j * cap
+            for (int j = 0; j < t.nq; j++) off[j] = (size_t)j * cap;
+        } else if (off[t.nq]) {
+            // exact-size copies of each sweep's re-ranked hits, back to back in the pinned buffer
+            rc = ensure_host(&c->h_out, &c->h_out_cap, off[t.nq]);
             if (rc) break;
             for (int j = 0; j < t.nq; j++) {
-                const size_t n = off[j + 1] - off[j];
-                if (!n) continue;
-                e = hipMemcpyAsync(c->h_out + off[j], c->d_out + (size_t)j * cap, n * sizeof(szg::RerankOut),
+                if (!cnt[j]) continue;
+                e = hipMemcpyAsync(c->h_out + off[j], c->d_out + (size_t)j * cap, cnt[j] * sizeof(szg::RerankOut),
                                    hipMemcpyDeviceToHost, c->stream);
                 if (e != hipSuccess) return fail(SZG_E_DEVICE, "hipMemcpyAsync(radius hits)", e);
             }
@@ -221,8 +260,8 @@ int RadiusCall::finish(RadiusTicket &t)
         t_wait += now_us() - tw;
         for (int j = 0; j < t.nq; j++) {
             if (redo[j]) continue;
-            cands[j].reserve(cands[j].size() + (off[j + 1] - off[j]));
-            for (size_t i = off[j]; i < off[j + 1]; i++) {
+            cands[j].reserve(cands[j].size() + cnt[j]);
+            for (size_t i = off[j]; i < off[j] + cnt[j]; i++) {
                 const szg::RerankOut &r = c->h_out[i];
                 cands[j].push_back(Cand{sh->first + r.row, r.dist, szg::key_from_ordered(r.ukey), 0.0});
             }
@@ -237,14 +276,7 @@ int RadiusCall::finish(RadiusTicket &t)
             t_wait += now_us() - tw;
             if (rc) break;
         }
-        // consider()'s radius branch (collection.go:598-605) in visit order, then the pop loop (:694-697)
-        std::vector<Cand> &cs = cands[j];
-        std::sort(cs.begin(), cs.end(), [](const Cand &x, const Cand &y) { return x.row < y.row; });
-        const double radius = radii[t.first + j];
-        GoHeap h;
-        for (const Cand &c : cs)
-            if (c.dist <= radius) h.push(HeapItem{c.row, c.dist});
-        h.drain(&(*results)[t.first + j]);
+        radius_assemble(cands[j], radii[t.first + j], &(*results)[t.first + j]);
     }
     {
         std::lock_guard<std::mutex> lk(ix->stats_mu);
@@ -266,9 +298,16 @@ int RadiusCall::run()
         RadiusTicket t;
         t.owner = this;
         t.first = q0;
-        t.nq = std::min(qpl, n_queries - q0);
+        // a small first batch (the card starts sweeping after a few queries' preparation) and a small last one
+        // (what is left to do once the last sweep has ended is that batch's result assembly)
+        const int left = n_queries - q0;
+        const int edge = std::max(1, std::min(qpl, ix->first_batch > 0 ? ix->first_batch : qpl));
+        t.nq = std::min(qpl, left);
+        if (q0 == 0 && left > edge) t.nq = edge;
+        else if (left > edge && left <= qpl + edge) t.nq = left - edge;
         t.ctx.assign(n_sh, nullptr);
         t.cap.assign(n_sh, 0);
+        t.copied.assign(n_sh, 0);
         t.thr.assign(t.nq, 0.0f);
         if (!acquire(t, inflight.empty())) {
             rc = finish(inflight.front());

@@ -40,7 +40,8 @@ size_t shard_words(const Shard *sh) { return (size_t)((sh->n_rows + 63) / 64); }
 // Enqueue H2D of nq prepared queries (+ their masks) on the ctx stream.
 // masks: nullptr (no query of the batch is filtered), or nq pointers to index-level masks
 // ((total_rows + 63) / 64 words each); a null entry allows every row.
-int enqueue_queries(szg_index *ix, Shard *sh, Ctx *c, const double *q, int nq, const uint64_t *const *masks)
+int enqueue_queries(szg_index *ix, Shard *sh, Ctx *c, const double *q, int nq, const uint64_t *const *masks,
+                    bool with_single_form)
 {
     HIPCHK(hipSetDevice(sh->device));
     memcpy(c->h_q64, q, sizeof(double) * ix->dim * nq);
@@ -50,7 +51,8 @@ int enqueue_queries(szg_index *ix, Shard *sh, Ctx *c, const double *q, int nq, c
     }
     {
         SiteScope t_(0);
-        HIPCHK(hipMemcpyAsync(c->d_qsw, c->h_qsw, ix->qsw_bytes * nq, hipMemcpyHostToDevice, c->stream));
+        if (with_single_form)
+            HIPCHK(hipMemcpyAsync(c->d_qsw, c->h_qsw, ix->qsw_bytes * nq, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_q64, c->h_q64, sizeof(double) * ix->dim * nq, hipMemcpyHostToDevice,
                               c->stream));
     }
@@ -165,7 +167,10 @@ double mask_pass_rate(const Shard *sh, const Ctx *c, bool has_allow, int slot)
 int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allow)
 {
     c->kp_used = kp;
+    c->out_stride = kp;
+    c->sent_in_out = false;
     c->mq_stage2 = false;
+    c->mq_band_used = false;
     c->mq_bf16_used = false;
     HIPCHK(hipSetDevice(sh->device));
     const LaunchGeom g = scan_geometry(ix, sh, kp, !has_allow && !sh->has_dead);
@@ -263,7 +268,7 @@ void gather_topk(const szg_index *ix, const Shard *sh, const Ctx *c, const QMeta
     int valid = 0;
     float worst = -INFINITY;
     for (int i = 0; i < kp; i++) {
-        const szg::RerankOut &r = c->h_out[(size_t)slot * kp + i];
+        const szg::RerankOut &r = c->h_out[(size_t)slot * c->out_stride + i];
         if (r.row == 0xFFFFFFFFu) continue;
         valid++;
         const float key = szg::key_from_ordered(r.ukey);
@@ -277,11 +282,14 @@ void gather_topk(const szg_index *ix, const Shard *sh, const Ctx *c, const QMeta
     *lb = valid == kp ? (double)worst - key_eps(ix, worst, lm) : INFINITY;
     if (c->mq_stage2) {
         // rows the bfloat16 sweep did not collect: bfloat16 key above the prefix threshold
+        QMeta bm = m;
+        bm.mq_bf16 = true;
         const float thr = c->h_thr[slot];
-        if (thr < 3.0e38f) {
-            QMeta bm = m;
-            bm.mq_bf16 = true;
-            *lb = std::min(*lb, (double)thr - key_eps(ix, thr, bm));
+        if (thr < 3.0e38f) *lb = std::min(*lb, (double)thr - key_eps(ix, thr, bm));
+        // collected, but outside the band that was scored again in float32: bfloat16 key above the band's edge
+        if (c->mq_band_used) {
+            const float edge = c->h_thr[128 + slot];
+            if (edge < 3.0e38f) *lb = std::min(*lb, (double)edge - key_eps(ix, edge, bm));
         }
     }
 }
@@ -416,9 +424,26 @@ void first_eligible_rows(const szg_index *ix, const uint64_t *allow, int k, std:
 
 // Stage the sentinel rows of the batch that fall into this shard and enqueue their float64
 // distances on the ctx stream (lists: one vector of index-level rows per staged query).
-int enqueue_sentinels(szg_index *ix, Shard *sh, Ctx *c, const std::vector<std::vector<uint64_t>> &lists, int nq)
+int launch_sentinel_rerank(szg_index *ix, Shard *sh, Ctx *c, int nq, hipStream_t stream)
+{
+    const size_t total = (size_t)c->sent_n * (size_t)nq;
+    if (!total) return SZG_OK;
+    int rc = ensure_host(&c->h_sent_out, &c->h_sent_out_cap, total);
+    if (rc) return rc;
+    rc = ensure_dev(&c->d_sent_out, &c->d_sent_out_cap, total);
+    if (rc) return rc;
+    HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, c->d_sent, nullptr,
+                              (uint32_t)c->sent_n, nq, c->d_sent_out, stream));
+    HIPCHK(hipMemcpyAsync(c->h_sent_out, c->d_sent_out, total * sizeof(szg::RerankOut), hipMemcpyDeviceToHost, stream));
+    c->sent_deferred = false;
+    return SZG_OK;
+}
+
+// defer: only stage the rows (the batch's tail computes their distances in its one rerank launch)
+int enqueue_sentinels(szg_index *ix, Shard *sh, Ctx *c, const std::vector<std::vector<uint64_t>> &lists, int nq, bool defer)
 {
     c->sent_n = 0;
+    c->sent_deferred = false;
     size_t most = 0;
     for (int j = 0; j < nq; j++) {
         size_t n = 0;
@@ -433,10 +458,6 @@ int enqueue_sentinels(szg_index *ix, Shard *sh, Ctx *c, const std::vector<std::v
     if (rc) return rc;
     rc = ensure_dev(&c->d_sent, &c->d_sent_cap, total);
     if (rc) return rc;
-    rc = ensure_host(&c->h_sent_out, &c->h_sent_out_cap, total);
-    if (rc) return rc;
-    rc = ensure_dev(&c->d_sent_out, &c->d_sent_out_cap, total);
-    if (rc) return rc;
     for (int j = 0; j < nq; j++) {
         size_t n = 0;
         for (uint64_t r : lists[j])
@@ -444,12 +465,10 @@ int enqueue_sentinels(szg_index *ix, Shard *sh, Ctx *c, const std::vector<std::v
         for (; n < most; n++) c->h_sent[(size_t)j * most + n] = szg::kInvalidCand;
     }
     HIPCHK(hipMemcpyAsync(c->d_sent, c->h_sent, total * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, c->d_sent, nullptr,
-                              (uint32_t)most, nq, c->d_sent_out, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_sent_out, c->d_sent_out, total * sizeof(szg::RerankOut), hipMemcpyDeviceToHost,
-                          c->stream));
     c->sent_n = (int)most;
-    return SZG_OK;
+    c->sent_deferred = true;
+    if (defer) return SZG_OK;
+    return launch_sentinel_rerank(ix, sh, c, nq, c->stream);
 }
 
 // ---- one szg_search_topk call -------------------------------------------------------------------------------------
@@ -487,6 +506,7 @@ struct TopkCall {
     bool acquire(Ticket &t, bool may_block);
     int stage(Ticket &t, int nb, bool bf16_sweep);
     int wait_shards(Ticket &t);
+    int stage_single_form(Ticket &t, int j);
     void gather(Ticket &t, std::vector<std::vector<Cand>> *all, std::vector<double> *thr_min,
                 std::vector<uint8_t> *nan_first);
     int settle(Ticket &t, int j, std::vector<Cand> &cands, double thr_min, bool nan_first, double *t_dev,
@@ -524,6 +544,7 @@ int TopkCall::stage(Ticket &t, int nb, bool bf16_sweep)
     const double t_prep0 = now_us();
     Ctx *c0 = nullptr;
     const bool int_planes = nb > 0 && mq_uses_i8(ix);
+    t.lazy_single = nb > 0 && !replay_all;
     for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
         if (ix->shards[s]->n_rows == 0) continue;
         Ctx *cx = t.ctx[s];
@@ -537,14 +558,16 @@ int TopkCall::stage(Ticket &t, int nb, bool bf16_sweep)
         if (!c0) {
             c0 = cx;
             for (int j = 0; j < t.nq; j++) {
-                prep_query(ix, q + (size_t)j * ix->dim, cx->h_qsw + (size_t)j * ix->qsw_bytes, &t.meta[j]);
+                // (a shared sweep stages its own image; the single-query form is built if a query escalates)
+                if (t.lazy_single) prep_query_meta(ix, q + (size_t)j * ix->dim, &t.meta[j]);
+                else prep_query(ix, q + (size_t)j * ix->dim, cx->h_qsw + (size_t)j * ix->qsw_bytes, &t.meta[j]);
                 t.meta[j].mq = nb > 0 && !mq_uses_i8(ix);  // the integer sweeps keep the integer bound
                 t.meta[j].mq_bf16 = bf16_sweep;
                 if (int_planes) prep_mq_int(ix, q + (size_t)j * ix->dim, &t.meta[j], cx->h_mqQ + (size_t)j * ix->dim);
                 cx->meta[j] = t.meta[j];
             }
         } else {
-            memcpy(cx->h_qsw, c0->h_qsw, ix->qsw_bytes * (size_t)t.nq);
+            if (!t.lazy_single) memcpy(cx->h_qsw, c0->h_qsw, ix->qsw_bytes * (size_t)t.nq);
             if (int_planes) memcpy(cx->h_mqQ, c0->h_mqQ, sizeof(int32_t) * (size_t)t.nq * ix->dim);
             for (int j = 0; j < t.nq; j++) cx->meta[j] = t.meta[j];
         }
@@ -563,9 +586,13 @@ int TopkCall::stage(Ticket &t, int nb, bool bf16_sweep)
         Shard *sh = ix->shards[s];
         if (sh->n_rows == 0) continue;
         t.ctx[s]->sent_n = 0;
-        rc = enqueue_queries(ix, sh, t.ctx[s], q, t.nq, mptr);
-        // (before the sweeps: on the context's stream this runs while the scan stream sweeps)
-        if (rc == SZG_OK && !sent.empty()) rc = enqueue_sentinels(ix, sh, t.ctx[s], sent, t.nq);
+        t.ctx[s]->sent_deferred = false;
+        rc = enqueue_queries(ix, sh, t.ctx[s], q, t.nq, mptr, !t.lazy_single);
+        // (before the sweeps: on the context's stream this runs while the scan stream sweeps; a shared sweep whose
+        // tail is the refine launch takes the rows along in its one rerank instead)
+        if (rc == SZG_OK && !sent.empty())
+            rc = enqueue_sentinels(ix, sh, t.ctx[s], sent, t.nq,
+                                   nb > 0 && mq_tail_takes_sentinels(ix, sh, t.kp, t.kp_wide, t.nq, nb));
         if (rc == SZG_OK && !replay_all)
             rc = nb ? enqueue_topk_mq(ix, sh, t.ctx[s], t.kp, t.kp_wide, t.nq, nb, t.any_mask)
                     : enqueue_topk(ix, sh, t.ctx[s], kp, t.nq, t.any_mask);
@@ -579,6 +606,25 @@ int TopkCall::stage(Ticket &t, int nb, bool bf16_sweep)
     ix->stats.host_prep_us += t_enq0 - t_prep0;
     ix->stats.host_enqueue_us += t_end - t_enq0;
     return rc;
+}
+
+// query j of a shared-sweep batch in the single-query kernels' form (swizzled floats / digit planes + their
+// constants), on every shard: built only when the query escalates
+int TopkCall::stage_single_form(Ticket &t, int j)
+{
+    const double *q = queries + (size_t)(t.first + j) * ix->dim;
+    for (size_t s = 0; s < n_sh; s++) {
+        Ctx *c = t.ctx[s];
+        if (!c) continue;
+        QMeta m;
+        prep_query(ix, q, c->h_qsw + (size_t)j * ix->qsw_bytes, &m);
+        t.meta[j].qscale = c->meta[j].qscale = m.qscale;
+        t.meta[j].qconst = c->meta[j].qconst = m.qconst;
+        HIPCHK(hipSetDevice(ix->shards[s]->device));
+        HIPCHK(hipMemcpyAsync(c->d_qsw + (size_t)j * ix->qsw_bytes, c->h_qsw + (size_t)j * ix->qsw_bytes, ix->qsw_bytes,
+                              hipMemcpyHostToDevice, c->stream));
+    }
+    return SZG_OK;
 }
 
 // wait for the ticket's device work; a shared sweep whose candidate buffer overflowed (threshold from the prefix too
@@ -630,7 +676,8 @@ void TopkCall::gather(Ticket &t, std::vector<std::vector<Cand>> *all, std::vecto
             (*thr_min)[j] = std::min((*thr_min)[j], lb);
             const Ctx *c = t.ctx[s];
             for (int i = 0; i < c->sent_n; i++) {
-                const szg::RerankOut &r = c->h_sent_out[(size_t)j * c->sent_n + i];
+                const szg::RerankOut &r = c->sent_in_out ? c->h_out[(size_t)j * c->out_stride + c->kp_used + i]
+                                                         : c->h_sent_out[(size_t)j * c->sent_n + i];
                 if (r.row != 0xFFFFFFFFu && std::isnan(r.dist)) (*nan_first)[j] = 1;
             }
         }
@@ -677,11 +724,17 @@ int TopkCall::settle(Ticket &t, int j, std::vector<Cand> &cands, double thr_min,
             std::lock_guard<std::mutex> lk(ix->stats_mu);
             ix->stats.escalations++;
         }
+        // kmax bounds the worst result's real-number key; the collect sweep (always the single-query kernel) adds
+        // its own error on the rows it tests
         double thr = INFINITY;
+        cands.clear();
+        const double td = now_us();
+        if (t.lazy_single) {  // the escalation sweep is the single-query kernel: it wants the query in ITS form
+            rc = stage_single_form(t, j);
+            if (rc) return rc;
+        }
         if ((int)res->size() == k && std::isfinite(kmax) && !zero_query) {
-            // kmax bounds the worst result's real-number key; the collect sweep (always the single-query kernel)
-            // adds its own error on the rows it tests
-            QMeta single = t.meta[j];
+            QMeta single = t.meta[j];  // (now with the single-query path's quantization step)
             single.mq = false;
             single.mq_int = false;
             single.mq_bf16 = false;
@@ -689,8 +742,6 @@ int TopkCall::settle(Ticket &t, int j, std::vector<Cand> &cands, double thr_min,
             thr = kmax + 1.05 * e2 + 0.05 * std::fabs(kmax) * 0x1p-20;
         }
         const float thr_f = !(thr < 3.0e38) ? 3.0e38f : std::nextafter((float)thr, INFINITY);
-        cands.clear();
-        const double td = now_us();
         for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
             Shard *sh = ix->shards[s];
             if (sh->n_rows == 0) continue;
@@ -799,6 +850,9 @@ int TopkCall::run()
                                    szg::mq_i8_lds_bytes(ix->bits, ix->map.r16, 3, 2) <= 160u * 1024u
                                ? 2 : 1;
         t.nq = nb ? std::min(left, 16 * nb * groups) : std::min(B1, left);
+        // one sweep per query: the call's FIRST batch is small, so that the card starts sweeping after a few
+        // microseconds of preparation instead of a whole batch's (the next batch is prepared while it sweeps)
+        if (!nb && q0 == 0 && ix->first_batch > 0 && left > ix->first_batch) t.nq = std::min(t.nq, ix->first_batch);
         const bool bf16_sweep = nb > 0 && mq_uses_bf16(ix);
         t.kp = kp;
         // lists of bfloat16-sweep keys (matrix form): the error band holds more rows than the float32 one's, keep

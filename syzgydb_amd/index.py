@@ -219,10 +219,10 @@ class ScanIndex:
         nq = q.shape[0]
         rad = np.ascontiguousarray(np.broadcast_to(np.asarray(radii, dtype=np.float64), (nq,)))
         keep, allow_p = self._allow_arg(allow, nq)
-        cap = 1 << 16
+        cap = max(1 << 16, nq << 12)  # (a truncated call is answered again from scratch: start generous)
         while True:
-            out_rows = np.zeros(max(cap, 1), dtype=np.uint64)
-            out_dist = np.zeros(max(cap, 1), dtype=np.float64)
+            out_rows = np.empty(max(cap, 1), dtype=np.uint64)
+            out_dist = np.empty(max(cap, 1), dtype=np.float64)
             off = np.zeros(nq + 1, dtype=np.uint64)
             rc = fn(self._h, _f64(q), nq, _f64(rad), allow_p, _u64(out_rows), _f64(out_dist), cap, _u64(off))
             if rc == _lib.SZG_E_TRUNCATED:
