@@ -1037,6 +1037,7 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
 #undef MQ8_CONSUME
 }
 
+
 #endif  // SZG_MQ_PART == 1 || 2
 
 #if SZG_MQ_PART == 0
