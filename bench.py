@@ -133,7 +133,7 @@ def recorded_traffic(workload, rows, sweeps_per_launch):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             e = json.load(f)[workload]
-        if int(e.get("rows", WORKLOADS[workload][0])) != int(rows):
+        if int(e.get("rows", WORKLOADS.get(workload, (0,))[0])) != int(rows):
             return None, None
         return (int(e["hbm_bytes_per_launch"] / float(e.get("sweeps_per_launch", 1)) * sweeps_per_launch),
                 "profiles/traffic.json (separate rocprofv3 --pmc passes, not this run)")
@@ -259,10 +259,9 @@ def side_workload(name, n_queries, devices):
             radius, _ = calibrated_radius(ix, q, radius)
         qps, st, hits = timed_leg(ix, q[:n_queries], k, radius)
         rf = roofline_of(st, rows, ix.row_bytes, bits, metric, "collect" if radius > 0 else "topk")
-        if radius == 0:
-            rf["traffic"], src = recorded_traffic(name, rows, rf["sweeps_per_launch"])
-            if src:
-                rf["traffic_source"] = src
+        rf["traffic"], src = recorded_traffic(name if radius == 0 else name + "_radius", rows, rf["sweeps_per_launch"])
+        if src:
+            rf["traffic_source"] = src
         out = {
             "workload": "%s%s: %d x %d, %d-bit, %s, %s, 1 query per sweep" % (
                 name, " (per-GPU shard of %d rows / 8)" % n_rows if name in SHARD_ROWS else "", rows, dim, bits,

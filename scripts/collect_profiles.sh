@@ -35,6 +35,15 @@ for cfg in "headline 1000000 768 32 1 10 16" "cfg2 1000000 384 32 1 10 16" "cfg3
   done
 done
 
+# the radius (collect) form of cfg5's shard: one query-major launch of 16 collect sweeps, ~500 hits per query
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  echo "[pmc] $ctr cfg5shard radius" | tee -a $out/progress.log
+  rm -rf /tmp/prof_rad_$ctr
+  SZG_RADIUS_HITS=500 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/prof_rad_$ctr -- python3 $GRAFT_REPO_ROOT/scripts/dev_one.py 12500000 384 4 1 10 16 > /tmp/pmc.log 2>&1
+  lc=$(echo $ctr | tr A-Z a-z)
+  one /tmp/prof_rad_$ctr "*counter_collection.csv" $out/${tag}_pmc_cfg5radius_$lc.csv
+done
+
 echo "[mq] shared sweeps: kernel stats + counters" | tee -a $out/progress.log
 for b in 32 8 4; do
   rm -rf /tmp/prof_mq$b
@@ -46,6 +55,7 @@ rm -rf /tmp/prof_mqf
 SZG_BITS=32 SZG_OPTS=mq_bf16=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mqf -- python3 $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /tmp/mq.log 2>&1
 one /tmp/prof_mqf "*kernel_stats.csv" $out/${tag}_mq_32bit_f32mfma_kernel_stats.csv
 SZG_BITS=8 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_i8_kernel<3, 1, true" $out/${tag}_pmc_mq_i8_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
+SZG_BITS=4 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_i8_kernel<3, 1, true" $out/${tag}_pmc_mq_i8_4bit_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
 SZG_BITS=32 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_bf16s_kernel<6, 1, true" $out/${tag}_pmc_mq_bf16_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
 SZG_BITS=32 SZG_OPTS=mq_bf16=0 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_kernel<3, 32, 1, true" $out/${tag}_pmc_mq_f32_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
 python3 $GRAFT_REPO_ROOT/scripts/make_traffic.py $out $tag > $out/traffic.json || true

@@ -19,7 +19,8 @@ OPTS = [("queries_per_launch", [1, 3, 16]), ("multi_query", [0, 1]), ("mq_fused"
         ("serialize_scans", [0, 1]), ("shape_kernels", [0, 1]), ("blocks_per_cu", [0, 1, 3]),
         ("mq_min", [2, 8]), ("mq_blocks", [1, 2, 3]), ("slack", [0, 16, 40]), ("mq_bf16", [0, 1, 1]),
         ("mq_overlap", [0, 1]), ("mq_bf16_slack", [0, 118]), ("mq_hits", [64, 1024]), ("sketch", [0, 1, 1]),
-        ("sketch_extra", [0, 30]), ("sketch_min_rows", [1, 1, 4096]), ("mq_i8_groups", [1, 2])]
+        ("sketch_extra", [0, 30]), ("sketch_min_rows", [1, 1, 4096]), ("mq_i8_groups", [1, 2]),
+        ("mq_refine", [0, 1, 1]), ("first_batch", [0, 1, 4]), ("mask_dense", [0, 1]), ("coalesce", [0, 1])]
 
 
 def same(got_r, got_d, want_r, want_d):
@@ -125,6 +126,22 @@ while time.time() < t_end:
                 if not same(rr, dd, w_rows, w_dist):
                     fails += 1
                     print("MISMATCH radius", desc, "query", qi, radius, len(rr), len(w_rows), flush=True)
+            # a BATCH of radius searches, each query its own radius (query-major collect launches, szg_search_radius_batch)
+            nb_ = min(nq, int(rng.choice([1, 3, 17, 40])))
+            radii = []
+            for qj in range(nb_):
+                mj = live if allow is None else (live & allow[qj])
+                od = orc.search_exact(rows, dim, bits, metric, Q[qj], k=int(rng.choice([1, 5, 60])), allow=mj.astype(np.uint8))[1]
+                fin = [x for x in od if x == x and x > 0]
+                radii.append(float(fin[-1]) if fin else 0.5)
+            hits = ix.search_radius_batch(Q[:nb_], radii, allow=None if allow is None else allow[:nb_])
+            for qj in range(nb_):
+                mj = live if allow is None else (live & allow[qj])
+                w_r, w_d, _ = orc.search_exact(rows, dim, bits, metric, Q[qj], radius=radii[qj], allow=mj.astype(np.uint8))
+                if not same(hits[qj][0], hits[qj][1], w_r, w_d):
+                    fails += 1
+                    print("MISMATCH radius batch", desc, "query", qj, radii[qj], len(hits[qj][0]), len(w_r), flush=True)
+                    break
             # the candidate re-rank primitives: float64 distances for row lists and row pairs
             pick = rng.integers(0, n, min(n, 40)).astype(np.uint64)
             got = ix.distances(Q[0], pick)

@@ -5,8 +5,8 @@ reads at 64 bytes, MI355X_MICROARCH.md, HBM) + WRITE_SIZE, both reported in KB.
 import csv, glob, json, os, sys
 d, tag = sys.argv[1], sys.argv[2]
 ALG = {"headline": (1000000, 3072), "cfg2": (1000000, 1536), "cfg3": (1000000, 768), "cfg4shard": (1250000, 3072),
-       "cfg5shard": (12500000, 192)}
-alias = {"cfg4shard": "cfg4", "cfg5shard": "cfg5"}
+       "cfg5shard": (12500000, 192), "cfg5radius": (12500000, 192)}
+alias = {"cfg4shard": "cfg4", "cfg5shard": "cfg5", "cfg5radius": "cfg5_radius"}
 out = {}
 for name, (rows, rb) in ALG.items():
     vals = {}

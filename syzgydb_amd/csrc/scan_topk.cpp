@@ -852,7 +852,12 @@ int TopkCall::run()
         t.nq = nb ? std::min(left, 16 * nb * groups) : std::min(B1, left);
         // one sweep per query: the call's FIRST batch is small, so that the card starts sweeping after a few
         // microseconds of preparation instead of a whole batch's (the next batch is prepared while it sweeps)
-        if (!nb && q0 == 0 && ix->first_batch > 0 && left > ix->first_batch) t.nq = std::min(t.nq, ix->first_batch);
+        // ... and its LAST one too: what is left to do once the last sweep has ended is that batch's merges,
+        // re-rank, copy-back and result assembly
+        if (!nb && ix->first_batch > 0 && left > ix->first_batch) {
+            if (q0 == 0) t.nq = std::min(t.nq, ix->first_batch);
+            else if (left <= B1 + ix->first_batch) t.nq = left - ix->first_batch;
+        }
         const bool bf16_sweep = nb > 0 && mq_uses_bf16(ix);
         t.kp = kp;
         // lists of bfloat16-sweep keys (matrix form): the error band holds more rows than the float32 one's, keep
