@@ -19,7 +19,7 @@ int ctx_alloc(szg_index *ix, Shard *sh, Ctx **out)
     HIPCHK(hipHostMalloc((void **)&c->h_qsw, B * ix->qsw_bytes, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&c->h_q64, B * sizeof(double) * ix->dim, hipHostMallocDefault));
     // hit counters of the collect sweeps, one 128-byte line per sweep of a launch
-    const size_t n_count = (size_t)szg::kMaxSweepsPerLaunch * szg::kCandCountStride;
+    const size_t n_count = (size_t)kMaxBatch * szg::kCandCountStride;  // (a batch may hold kMaxBatch sweeps)
     HIPCHK(hipHostMalloc((void **)&c->h_count, sizeof(uint32_t) * n_count, hipHostMallocDefault));
     HIPCHK(hipMalloc((void **)&c->d_qsw, B * ix->qsw_bytes));
     HIPCHK(hipMalloc((void **)&c->d_q64, B * sizeof(double) * ix->dim));
@@ -70,6 +70,7 @@ Ctx *ctx_acquire(Shard *sh)
     sh->cv.wait(lk, [&] { return !sh->free_ctx.empty(); });
     Ctx *c = sh->free_ctx.back();
     sh->free_ctx.pop_back();
+    c->work = c->stream;
     return c;
 }
 Ctx *ctx_try_acquire(Shard *sh)
@@ -78,6 +79,7 @@ Ctx *ctx_try_acquire(Shard *sh)
     if (sh->free_ctx.empty()) return nullptr;
     Ctx *c = sh->free_ctx.back();
     sh->free_ctx.pop_back();
+    c->work = c->stream;
     return c;
 }
 void ctx_release(Shard *sh, Ctx *c)
@@ -696,6 +698,9 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
     } else if (n == "query_batch") {
         if (value < 1 || value > kMaxBatch) return fail(SZG_E_INVALID, "query_batch out of range");
         ix->query_batch = (int)value;
+    } else if (n == "short_call") {
+        if (value < 0 || value > kMaxBatch) return fail(SZG_E_INVALID, "short_call out of range");
+        ix->short_call = (int)value;
     } else if (n == "first_batch") {
         if (value < 0 || value > kMaxBatch) return fail(SZG_E_INVALID, "first_batch out of range");
         ix->first_batch = (int)value;

@@ -164,6 +164,8 @@ struct Cand {
 // ---- one in-flight batch of queries on one shard --------------------------------
 struct Ctx {
     hipStream_t stream = nullptr;
+    hipStream_t work = nullptr;    // where this batch's uploads and post-processing go: `stream`, or the shard's scan
+                                   // stream for a call that is a single batch (set at acquire time)
     hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr, ev_all0 = nullptr, ev_all1 = nullptr;
     hipEvent_t ev_scan_done = nullptr;   // this batch's scans have finished (scan stream)
     hipEvent_t ev_up = nullptr;          // this batch's uploads have finished (ctx stream)
@@ -202,6 +204,7 @@ struct Ctx {
     int out_stride = 0;            // entries per query in h_out: kp_used, + sent_n when the sentinels ride along
     bool sent_deferred = false;    // the sentinel rows are staged (d_sent) but their distances not yet enqueued
     bool sent_in_out = false;      // their distances are entries [kp_used, out_stride) of each query in h_out
+    bool sent_own_stream = false;  // their re-rank runs on `stream` while the batch runs on the scan stream (`work`)
     bool mq_band_used = false;     // bfloat16 sweep refined by the band form: h_thr[128 + q] = the band's edge
     bool mq_stage2 = false;        // bfloat16 sweep -> float32 re-score of its candidates -> selection
     bool mq_bf16_used = false;     // the list keys of this batch are bfloat16-sweep keys (matrix form)
@@ -312,6 +315,7 @@ struct szg_index {
     int block_threads = 256;
     int query_batch = 16;     // queries per scan launch
     int first_batch = 4;      // ... of a call's first launch (0 = query_batch): the card starts sooner
+    int short_call = 32;      // calls of up to this many one-sweep queries are ONE batch on the scan stream (0 = off)
     int shape_kernels = 1;    // use the row-shape-specialised scan kernels where they exist
     int ring = 0;             // tuning hook: 8 = always the deep piece ring
     int queries_per_launch = 16;  // sweeps one scan launch walks back to back (query-major)
@@ -478,6 +482,7 @@ struct Ticket {
         for (size_t s = 0; s < ctx.size(); s++) {
             if (!ctx[s]) continue;
             (void)hipSetDevice(owner->shards[s]->device);
+            (void)hipStreamSynchronize(ctx[s]->work);
             (void)hipStreamSynchronize(ctx[s]->stream);
             ctx[s]->mq_fused_used = false;
             ctx_release(owner->shards[s], ctx[s]);

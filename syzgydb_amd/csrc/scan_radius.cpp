@@ -82,6 +82,7 @@ struct RadiusCall {
     const uint64_t *const *masks;  // nullable; null entries unfiltered
     std::vector<std::vector<HeapItem>> *results;
     size_t n_sh = 0;
+    bool single_batch = false;  // the whole call is one batch (a short call)
 
     void release(RadiusTicket &t)
     {
@@ -89,7 +90,7 @@ struct RadiusCall {
             if (!t.ctx[s]) continue;
             if (t.failed) {
                 (void)hipSetDevice(ix->shards[s]->device);
-                (void)hipStreamSynchronize(t.ctx[s]->stream);
+                (void)hipStreamSynchronize(t.ctx[s]->work);
             }
             ctx_release(ix->shards[s], t.ctx[s]);
         }
@@ -104,6 +105,8 @@ struct RadiusCall {
                 release(t);
                 return false;
             }
+            // (a call that is one batch runs on the scan stream from upload to copy-back: scan_topk.cpp, acquire)
+            if (single_batch && ix->serialize_scans) c->work = ix->shards[s]->scan_stream;
             t.ctx[s] = c;
         }
         return true;
@@ -136,27 +139,32 @@ int RadiusCall::enqueue_shard(RadiusTicket &t, size_t s)
     if (rc) return rc;
     rc = ensure_dev(&c->d_out, &c->d_out_cap, cap * (size_t)t.nq);
     if (rc) return rc;
-    const size_t n_count = (size_t)szg::kMaxSweepsPerLaunch * szg::kCandCountStride;
-    HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(uint32_t) * n_count, c->stream));
-    HIPCHK(hipEventRecord(c->ev_up, c->stream));  // the sweeps must see the queries, the masks and the zeroed counters
-    std::vector<szg::ScanArgs> a(1);
-    fill_scan_args(ix, sh, c, t.any_mask, 0, t.nq, &a[0]);
-    a[0].collect = 1;
-    for (int j = 0; j < t.nq; j++) a[0].thr_ukeys[j] = szg::ordered_key(t.thr[j]);
-    a[0].collect_buf = c->d_collect;
-    a[0].collect_cap = (uint32_t)cap;
-    a[0].collect_count = c->d_count;
-    if ((t.any_mask || sh->has_dead) && ix->mask_dense) {  // most rows pass: read every row, masks at the row finish
-        double lowest = 1.0;
-        for (int j = 0; j < t.nq; j++) lowest = std::min(lowest, mask_pass_rate(sh, c, t.any_mask, j));
-        a[0].mask_dense = lowest >= 0.5 ? 1 : 0;
+    HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(uint32_t) * (size_t)t.nq * szg::kCandCountStride, c->work));
+    HIPCHK(hipEventRecord(c->ev_up, c->work));  // the sweeps must see the queries, the masks and the zeroed counters
+    const int qpl = std::max(1, std::min(ix->queries_per_launch, szg::kMaxSweepsPerLaunch));
+    std::vector<szg::ScanArgs> a((t.nq + qpl - 1) / qpl);
+    for (int j0 = 0; j0 < t.nq; j0 += qpl) {  // launches of <= 16 sweeps, back to back
+        szg::ScanArgs &x = a[j0 / qpl];
+        const int m = std::min(qpl, t.nq - j0);
+        fill_scan_args(ix, sh, c, t.any_mask, j0, m, &x);
+        x.collect = 1;
+        for (int j = 0; j < m; j++) x.thr_ukeys[j] = szg::ordered_key(t.thr[j0 + j]);
+        x.collect_buf = c->d_collect + (size_t)j0 * cap;
+        x.collect_cap = (uint32_t)cap;
+        x.collect_count = c->d_count + (size_t)j0 * szg::kCandCountStride;
+        if ((t.any_mask || sh->has_dead) && ix->mask_dense) {  // most rows pass: read every row, masks at the row finish
+            double lowest = 1.0;
+            for (int j = 0; j < m; j++) lowest = std::min(lowest, mask_pass_rate(sh, c, t.any_mask, j0 + j));
+            x.mask_dense = lowest >= 0.5 ? 1 : 0;
+        }
     }
     rc = launch_scans_chained(ix, sh, c, a, scan_geometry(ix, sh, 0));
     if (rc) return rc;
     // float64 distances of the hits: the counts stay on the device
     HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, c->d_collect, c->d_count,
-                              (uint32_t)cap, t.nq, c->d_out, c->stream, szg::kCandCountStride));
-    HIPCHK(hipMemcpyAsync(c->h_count, c->d_count, sizeof(uint32_t) * n_count, hipMemcpyDeviceToHost, c->stream));
+                              (uint32_t)cap, t.nq, c->d_out, c->work, szg::kCandCountStride));
+    HIPCHK(hipMemcpyAsync(c->h_count, c->d_count, sizeof(uint32_t) * (size_t)t.nq * szg::kCandCountStride, hipMemcpyDeviceToHost,
+                          c->work));
     // the re-ranked hits: while the batch's buffers are small (the usual hundreds of hits per query) the whole block
     // follows in ONE copy right here -- finish() then needs a single wait; larger ones are copied hit list by hit
     // list once the counts are known
@@ -165,7 +173,7 @@ int RadiusCall::enqueue_shard(RadiusTicket &t, size_t s)
         rc = ensure_host(&c->h_out, &c->h_out_cap, cap * (size_t)t.nq);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, cap * (size_t)t.nq * sizeof(szg::RerankOut), hipMemcpyDeviceToHost,
-                              c->stream));
+                              c->work));
     }
     return SZG_OK;
 }
@@ -224,7 +232,7 @@ int RadiusCall::finish(RadiusTicket &t)
         Shard *sh = ix->shards[s];
         const double tw = now_us();
         hipError_t e = hipSetDevice(sh->device);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->work);
         if (e != hipSuccess) return fail(SZG_E_DEVICE, "hipStreamSynchronize", e);
         rc = finish_timing(ix, c);
         if (rc) break;
@@ -251,10 +259,10 @@ int RadiusCall::finish(RadiusTicket &t)
             for (int j = 0; j < t.nq; j++) {
                 if (!cnt[j]) continue;
                 e = hipMemcpyAsync(c->h_out + off[j], c->d_out + (size_t)j * cap, cnt[j] * sizeof(szg::RerankOut),
-                                   hipMemcpyDeviceToHost, c->stream);
+                                   hipMemcpyDeviceToHost, c->work);
                 if (e != hipSuccess) return fail(SZG_E_DEVICE, "hipMemcpyAsync(radius hits)", e);
             }
-            e = hipStreamSynchronize(c->stream);
+            e = hipStreamSynchronize(c->work);
             if (e != hipSuccess) return fail(SZG_E_DEVICE, "hipStreamSynchronize", e);
         }
         t_wait += now_us() - tw;
@@ -303,7 +311,11 @@ int RadiusCall::run()
         const int left = n_queries - q0;
         const int edge = std::max(1, std::min(qpl, ix->first_batch > 0 ? ix->first_batch : qpl));
         t.nq = std::min(qpl, left);
-        if (q0 == 0 && left > edge) t.nq = edge;
+        // (only the smallest calls are ONE batch here: a radius query's result assembly -- hundreds of hits to sort --
+        // takes the host ~15 us, which a longer call hides behind the next batch's sweeps)
+        single_batch = q0 == 0 && ix->short_call > 0 && n_queries <= std::min(edge, ix->short_call);
+        if (single_batch) t.nq = n_queries;
+        else if (q0 == 0 && left > edge) t.nq = edge;
         else if (left > edge && left <= qpl + edge) t.nq = left - edge;
         t.ctx.assign(n_sh, nullptr);
         t.cap.assign(n_sh, 0);

@@ -47,14 +47,14 @@ int enqueue_queries(szg_index *ix, Shard *sh, Ctx *c, const double *q, int nq, c
     memcpy(c->h_q64, q, sizeof(double) * ix->dim * nq);
     if (ix->timing >= 2) {
         SiteScope t_(10);
-        HIPCHK(hipEventRecord(c->ev_all0, c->stream));
+        HIPCHK(hipEventRecord(c->ev_all0, c->work));
     }
     {
         SiteScope t_(0);
         if (with_single_form)
-            HIPCHK(hipMemcpyAsync(c->d_qsw, c->h_qsw, ix->qsw_bytes * nq, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(c->d_qsw, c->h_qsw, ix->qsw_bytes * nq, hipMemcpyHostToDevice, c->work));
         HIPCHK(hipMemcpyAsync(c->d_q64, c->h_q64, sizeof(double) * ix->dim * nq, hipMemcpyHostToDevice,
-                              c->stream));
+                              c->work));
     }
     if (masks) {
         const size_t words = shard_words(sh);
@@ -69,11 +69,11 @@ int enqueue_queries(szg_index *ix, Shard *sh, Ctx *c, const double *q, int nq, c
                 memset(c->h_allow + (size_t)i * words, 0xFF, words * sizeof(uint64_t));
         }
         HIPCHK(hipMemcpyAsync(c->d_allow, c->h_allow, words * nq * sizeof(uint64_t),
-                              hipMemcpyHostToDevice, c->stream));
+                              hipMemcpyHostToDevice, c->work));
     }
     // what the sweeps wait for ends here: work enqueued on this stream afterwards (the first-k
     // rows' distances) runs beside the sweeps
-    HIPCHK(hipEventRecord(c->ev_up, c->stream));
+    HIPCHK(hipEventRecord(c->ev_up, c->work));
     return SZG_OK;
 }
 
@@ -113,8 +113,8 @@ int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg
     const int n = (int)a.size();
     {
         std::lock_guard<std::mutex> lk(sh->chain_mu);
-        hipStream_t st = ix->serialize_scans ? sh->scan_stream : c->stream;
-        if (st != c->stream) {
+        hipStream_t st = ix->serialize_scans ? sh->scan_stream : c->work;
+        if (st != c->work) {
             SiteScope t_(1);
             HIPCHK(hipStreamWaitEvent(st, c->ev_up, 0));  // recorded by enqueue_queries
         }
@@ -133,10 +133,10 @@ int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg
             c->timed_scan = true;
             c->timed_n = n;
         }
-        if (st != c->stream) {
+        if (st != c->work) {
             SiteScope t_(5);
             HIPCHK(hipEventRecord(c->ev_scan_done, st));
-            HIPCHK(hipStreamWaitEvent(c->stream, c->ev_scan_done, 0));
+            HIPCHK(hipStreamWaitEvent(c->work, c->ev_scan_done, 0));
         }
     }
     std::lock_guard<std::mutex> lk(ix->stats_mu);
@@ -216,7 +216,7 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
     {
         SiteScope t_(6);
         while (n_lists > 1) {
-            HIPCHK(szg::launch_merge(src, n_lists, kp, nq, dst, c->stream));
+            HIPCHK(szg::launch_merge(src, n_lists, kp, nq, dst, c->work));
             n_lists = (n_lists + fan - 1) / fan;
             std::swap(src, dst);
         }
@@ -224,16 +224,16 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
     {
         SiteScope t_(7);
         HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, src,
-                                  nullptr, (uint32_t)kp, nq, c->d_out, c->stream));
+                                  nullptr, (uint32_t)kp, nq, c->d_out, c->work));
     }
     {
         SiteScope t_(8);
         HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp * nq,
-                              hipMemcpyDeviceToHost, c->stream));
+                              hipMemcpyDeviceToHost, c->work));
     }
     if (ix->timing >= 2) {
         SiteScope t_(10);
-        HIPCHK(hipEventRecord(c->ev_all1, c->stream));
+        HIPCHK(hipEventRecord(c->ev_all1, c->work));
     }
     return SZG_OK;
 }
@@ -306,9 +306,9 @@ int run_collect(szg_index *ix, Shard *sh, Ctx *c, int slot, float thr_key, bool 
     for (;;) {
         int rc = ensure_dev(&c->d_collect, &c->collect_cap, want);
         if (rc) return rc;
-        if (ix->timing >= 2) HIPCHK(hipEventRecord(c->ev_all0, c->stream));
-        HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(uint32_t), c->stream));
-        HIPCHK(hipEventRecord(c->ev_up, c->stream));  // the sweep must see the zeroed counter
+        if (ix->timing >= 2) HIPCHK(hipEventRecord(c->ev_all0, c->work));
+        HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(uint32_t), c->work));
+        HIPCHK(hipEventRecord(c->ev_up, c->work));  // the sweep must see the zeroed counter
         std::vector<szg::ScanArgs> a(1);
         fill_scan_args(ix, sh, c, has_allow, slot, 1, &a[0]);
         a[0].collect = 1;
@@ -320,9 +320,9 @@ int run_collect(szg_index *ix, Shard *sh, Ctx *c, int slot, float thr_key, bool 
         rc = launch_scans_chained(ix, sh, c, a, g);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(c->h_count, c->d_count, sizeof(uint32_t), hipMemcpyDeviceToHost,
-                              c->stream));
-        if (ix->timing >= 2) HIPCHK(hipEventRecord(c->ev_all1, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+                              c->work));
+        if (ix->timing >= 2) HIPCHK(hipEventRecord(c->ev_all1, c->work));
+        HIPCHK(hipStreamSynchronize(c->work));
         rc = finish_timing(ix, c);
         if (rc) return rc;
         const uint32_t count = c->h_count[0];
@@ -337,10 +337,10 @@ int run_collect(szg_index *ix, Shard *sh, Ctx *c, int slot, float thr_key, bool 
         if (rc) return rc;
         HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim,
                                   c->d_q64 + (size_t)slot * ix->dim, c->d_collect, nullptr, count, 1,
-                                  c->d_out, c->stream));
+                                  c->d_out, c->work));
         HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * count,
-                              hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+                              hipMemcpyDeviceToHost, c->work));
+        HIPCHK(hipStreamSynchronize(c->work));
         cands->reserve(cands->size() + count);
         for (uint32_t i = 0; i < count; i++) {
             const szg::RerankOut &r = c->h_out[i];
@@ -370,14 +370,14 @@ int run_full_replay(szg_index *ix, std::vector<Ctx *> &ctx, int slot, const uint
         if (rc) return rc;
         HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim,
                                   c->d_q64 + (size_t)slot * ix->dim, nullptr, nullptr, (uint32_t)n, 1,
-                                  c->d_out, c->stream));
+                                  c->d_out, c->work));
         HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * n, hipMemcpyDeviceToHost,
-                              c->stream));
+                              c->work));
         std::vector<uint64_t> live((n + 63) / 64, ~0ull);
         if (sh->has_dead)
             HIPCHK(hipMemcpyAsync(live.data(), sh->live_bits, live.size() * sizeof(uint64_t),
-                                  hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+                                  hipMemcpyDeviceToHost, c->work));
+        HIPCHK(hipStreamSynchronize(c->work));
         const uint64_t *aw = allow ? allow + sh->first / 64 : nullptr;
         for (size_t r = 0; r < n; r++) {
             if (!((live[r >> 6] >> (r & 63)) & 1)) continue;       // removed record
@@ -439,11 +439,15 @@ int launch_sentinel_rerank(szg_index *ix, Shard *sh, Ctx *c, int nq, hipStream_t
     return SZG_OK;
 }
 
-// defer: only stage the rows (the batch's tail computes their distances in its one rerank launch)
+// defer: only stage the rows (the batch's tail computes their distances in its one rerank launch).
+// The sentinels always ride on the context's OWN stream: they have the whole batch's sweeps to finish in, so when
+// the batch itself runs on the scan stream (a short call) they wait for its uploads through an event and stay off
+// the critical path.
 int enqueue_sentinels(szg_index *ix, Shard *sh, Ctx *c, const std::vector<std::vector<uint64_t>> &lists, int nq, bool defer)
 {
     c->sent_n = 0;
     c->sent_deferred = false;
+    c->sent_own_stream = false;
     size_t most = 0;
     for (int j = 0; j < nq; j++) {
         size_t n = 0;
@@ -464,11 +468,17 @@ int enqueue_sentinels(szg_index *ix, Shard *sh, Ctx *c, const std::vector<std::v
             if (r >= sh->first && r < sh->first + sh->n_rows) c->h_sent[(size_t)j * most + n++] = r - sh->first;
         for (; n < most; n++) c->h_sent[(size_t)j * most + n] = szg::kInvalidCand;
     }
-    HIPCHK(hipMemcpyAsync(c->d_sent, c->h_sent, total * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    hipStream_t st = c->work;
+    if (!defer && c->work != c->stream) {
+        st = c->stream;
+        c->sent_own_stream = true;
+        HIPCHK(hipStreamWaitEvent(st, c->ev_up, 0));  // the queries are up (recorded by enqueue_queries on c->work)
+    }
+    HIPCHK(hipMemcpyAsync(c->d_sent, c->h_sent, total * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     c->sent_n = (int)most;
     c->sent_deferred = true;
     if (defer) return SZG_OK;
-    return launch_sentinel_rerank(ix, sh, c, nq, c->stream);
+    return launch_sentinel_rerank(ix, sh, c, nq, st);
 }
 
 // ---- one szg_search_topk call -------------------------------------------------------------------------------------
@@ -489,6 +499,7 @@ struct TopkCall {
     size_t n_sh = 0, allow_stride = 0;
     int kp = 0;
     bool replay_all = false;  // K beyond the fused selection: every query takes the exact replay
+    bool single_batch = false;  // the whole call is one batch of sweeps (a short call)
 
     const uint64_t *mask_of(int qi) const
     {
@@ -524,6 +535,11 @@ bool TopkCall::acquire(Ticket &t, bool may_block)
             release(t);
             return false;
         }
+        // A call that is ONE batch has nothing to overlap with: uploads, sweeps, merges, re-rank and copy-back go
+        // onto the shard's scan stream in order.  On the context's own stream every hand-over to and from the scan
+        // stream is a cross-queue event wait, and those cost 20-100 us each on this platform (rocprofv3 timeline of
+        // 20-query calls on a 125 K-row shard: the sweeps of a call's batches sat 24-105 us apart).
+        if (single_batch && ix->serialize_scans) c->work = ix->shards[s]->scan_stream;
         t.ctx[s] = c;
     }
     return true;
@@ -597,7 +613,7 @@ int TopkCall::stage(Ticket &t, int nb, bool bf16_sweep)
             rc = nb ? enqueue_topk_mq(ix, sh, t.ctx[s], t.kp, t.kp_wide, t.nq, nb, t.any_mask)
                     : enqueue_topk(ix, sh, t.ctx[s], kp, t.nq, t.any_mask);
         if (rc == SZG_OK && replay_all && ix->timing >= 2) {
-            const hipError_t e = hipEventRecord(t.ctx[s]->ev_all1, t.ctx[s]->stream);
+            const hipError_t e = hipEventRecord(t.ctx[s]->ev_all1, t.ctx[s]->work);
             if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "hipEventRecord", e);
         }
     }
@@ -622,7 +638,7 @@ int TopkCall::stage_single_form(Ticket &t, int j)
         t.meta[j].qconst = c->meta[j].qconst = m.qconst;
         HIPCHK(hipSetDevice(ix->shards[s]->device));
         HIPCHK(hipMemcpyAsync(c->d_qsw + (size_t)j * ix->qsw_bytes, c->h_qsw + (size_t)j * ix->qsw_bytes, ix->qsw_bytes,
-                              hipMemcpyHostToDevice, c->stream));
+                              hipMemcpyHostToDevice, c->work));
     }
     return SZG_OK;
 }
@@ -636,7 +652,8 @@ int TopkCall::wait_shards(Ticket &t)
         Shard *sh = ix->shards[s];
         if (sh->n_rows == 0) continue;
         hipError_t e = hipSetDevice(sh->device);
-        if (e == hipSuccess) e = hipStreamSynchronize(t.ctx[s]->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(t.ctx[s]->work);
+        if (e == hipSuccess && t.ctx[s]->sent_own_stream) e = hipStreamSynchronize(t.ctx[s]->stream);
         if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "hipStreamSynchronize", e);
         if (rc == SZG_OK) rc = finish_timing(ix, t.ctx[s]);
         Ctx *c = t.ctx[s];
@@ -654,7 +671,7 @@ int TopkCall::wait_shards(Ticket &t)
         }
         rc = enqueue_topk_mq(ix, sh, c, t.kp, t.kp_wide, t.nq, c->mq_nb, c->mq_has_allow, true);
         if (rc == SZG_OK) {
-            e = hipStreamSynchronize(c->stream);
+            e = hipStreamSynchronize(c->work);
             if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "hipStreamSynchronize", e);
         }
         if (rc == SZG_OK) rc = finish_timing(ix, c);
@@ -755,7 +772,9 @@ int TopkCall::settle(Ticket &t, int j, std::vector<Cand> &cands, double thr_min,
     if (ix->tie_mode == 0) {
         std::vector<double> d(cands.size());
         for (size_t i = 0; i < cands.size(); i++) d[i] = cands[i].dist;
-        if (nan_first || history_dependent(d.data(), d.size(), k)) {
+        // (a zero cosine query is at distance exactly 1.0 from every row, collection.go:828-830: one big tie, whether or
+        // not the candidate list is long enough to show two of its members)
+        if (nan_first || zero_query || history_dependent(d.data(), d.size(), k)) {
             {
                 std::lock_guard<std::mutex> lk(ix->stats_mu);
                 ix->stats.full_replays++;
@@ -775,6 +794,7 @@ int TopkCall::finish(Ticket &t)
         for (size_t s = 0; s < n_sh; s++) {
             if (!t.ctx[s]) continue;
             (void)hipSetDevice(ix->shards[s]->device);
+            (void)hipStreamSynchronize(t.ctx[s]->work);
             (void)hipStreamSynchronize(t.ctx[s]->stream);
             t.ctx[s]->mq_fused_used = false;
         }
@@ -850,11 +870,14 @@ int TopkCall::run()
                                    szg::mq_i8_lds_bytes(ix->bits, ix->map.r16, 3, 2) <= 160u * 1024u
                                ? 2 : 1;
         t.nq = nb ? std::min(left, 16 * nb * groups) : std::min(B1, left);
+        // a short call with one sweep per query is ONE batch (its launches of <= 16 sweeps back to back)
+        single_batch = !nb && q0 == 0 && ix->short_call > 0 && n_queries <= std::min(ix->short_call, kMaxBatch);
+        if (single_batch) t.nq = n_queries;
         // one sweep per query: the call's FIRST batch is small, so that the card starts sweeping after a few
         // microseconds of preparation instead of a whole batch's (the next batch is prepared while it sweeps)
         // ... and its LAST one too: what is left to do once the last sweep has ended is that batch's merges,
         // re-rank, copy-back and result assembly
-        if (!nb && ix->first_batch > 0 && left > ix->first_batch) {
+        if (!nb && !single_batch && ix->first_batch > 0 && left > ix->first_batch) {
             if (q0 == 0) t.nq = std::min(t.nq, ix->first_batch);
             else if (left <= B1 + ix->first_batch) t.nq = left - ix->first_batch;
         }

@@ -435,3 +435,26 @@ def test_forced_rows_do_not_hide_the_true_nearest(multi):
             o_rows, o_dist, _ = orc.search_exact(rows, dim, 32, SZG_COSINE, Q[qi], k=1)
             assert [int(x) for x in r[qi, : c[qi]]] == [int(x) for x in o_rows], qi
             assert (d[qi, : c[qi]] == o_dist).all()
+
+
+def test_zero_query_with_a_forced_row_and_no_slack():
+    """Fuzz seed 77, case 1111 (round 3): a zero cosine query is at distance exactly 1.0 from EVERY row
+    (collection.go:828-830), so the reference keeps the first k visited.  With slack = 0 and k = 1 the candidate list
+    holds one row -- a row with a NaN element is forced into it -- and nothing in it shows the tie; a zero query
+    therefore always takes the exact replay."""
+    dim, n = 64, 15
+    rng = np.random.default_rng(3)
+    vec = rng.uniform(-1, 1, (n, dim))
+    vec[7, 5] = np.nan
+    vec[9, 1] = np.inf
+    rows = orc.encode_rows(vec, 32)
+    for slack in (0, 16):
+        with ScanIndex(dim, 32, SZG_COSINE) as ix:
+            ix.load(rows)
+            ix.set_option("slack", slack)
+            ix.set_option("multi_query", 0)
+            for k in (1, 3, 20):
+                r, d, c = ix.search_topk(np.zeros(dim), k)
+                o_rows, o_dist, _ = orc.search_exact(rows, dim, 32, SZG_COSINE, np.zeros(dim), k=k)
+                assert_same(r[0, : c[0]], d[0, : c[0]], o_rows, o_dist)
+            assert ix.stats()["full_replays"] == 3
