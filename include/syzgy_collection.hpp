@@ -278,6 +278,53 @@ public:
         return ret;
     }
 
+    // Exact top-k Searches with one K for a caller that holds many queries (not in the reference, whose REST endpoint
+    // is single-query, rest.go:371-487): ONE szg_search_topk call -- batches of two or more share sweeps of the
+    // corpus on the matrix cores -- each query with its own Filter.  Same results as Search called one by one;
+    // anything else (radius, listing, mixed K) is answered Search by Search.
+    std::vector<SearchResults> SearchBatch(const std::vector<SearchArgs> &args)
+    {
+        std::vector<SearchResults> out;
+        const size_t numRecords = row_of_.size();
+        bool same = !args.empty() && numRecords > 0;
+        for (const SearchArgs &a : args)
+            same = same && a.Radius == 0 && a.K > 0 && a.K == args[0].K && (int)a.Vector.size() == opts_.DimensionCount;
+        if (!same) {
+            for (const SearchArgs &a : args) out.push_back(Search(a));
+            return out;
+        }
+        const int nq = (int)args.size(), k = args[0].K, dim = opts_.DimensionCount;
+        const uint64_t total = szg_index_rows(ix_);
+        const size_t words = (size_t)((total + 63) / 64);
+        std::vector<double> q((size_t)nq * dim);
+        std::vector<uint64_t> allow;
+        bool any = false;
+        for (const SearchArgs &a : args) any = any || (bool)a.Filter;
+        if (any) allow.assign((size_t)nq * words, ~0ull);
+        for (int i = 0; i < nq; i++) {
+            std::copy(args[i].Vector.begin(), args[i].Vector.end(), q.begin() + (size_t)i * dim);
+            if (!args[i].Filter) continue;
+            std::fill(allow.begin() + (size_t)i * words, allow.begin() + (size_t)(i + 1) * words, 0ull);
+            for (const auto &kv : row_of_)
+                if (args[i].Filter(kv.first, meta_[kv.second])) allow[(size_t)i * words + kv.second / 64] |= 1ull << (kv.second % 64);
+        }
+        std::vector<uint64_t> rows((size_t)nq * k);
+        std::vector<double> dist((size_t)nq * k);
+        std::vector<int32_t> count(nq);
+        check(szg_search_topk(ix_, q.data(), nq, k, any ? allow.data() : nullptr, rows.data(), dist.data(), count.data()),
+              "szg_search_topk");
+        for (int i = 0; i < nq; i++) {
+            SearchResults r;
+            for (int j = 0; j < count[i]; j++) {
+                const uint64_t row = rows[(size_t)i * k + j];
+                r.Results.push_back(SearchResult{id_of_[row], meta_[row], dist[(size_t)i * k + j]});
+            }
+            r.PercentSearched = 100;
+            out.push_back(r);
+        }
+        return out;
+    }
+
     void Close()
     {
         if (ix_) {

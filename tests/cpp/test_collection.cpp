@@ -156,8 +156,48 @@ static void TestComputeAverageDistance()  // collection_test.go:105-142
     CHECK(d->computeAverageDistance(3, [&](int) { return 0; }) == 0.0);  // id1 == id2 every time
 }
 
+static void TestSearchBatch()  // the batch surface: same answers as Search by Search
+{
+    CollectionOptions o;
+    o.DistanceMethod = Cosine;
+    o.DimensionCount = 32;
+    o.Quantization = 8;
+    auto c = Collection::NewCollection(o);
+    uint64_t s = 99;
+    auto rnd = [&s]() {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        return (double)(s >> 11) / 9007199254740992.0 * 2 - 1;
+    };
+    for (int i = 0; i < 3000; i++) {
+        std::vector<double> v(32);
+        for (double &x : v) x = rnd();
+        c->AddDocument((uint64_t)(i + 10), v, i % 3 ? "odd" : "three");
+    }
+    std::vector<SearchArgs> batch(20);
+    for (size_t i = 0; i < batch.size(); i++) {
+        batch[i].Vector.resize(32);
+        for (double &x : batch[i].Vector) x = rnd();
+        batch[i].K = 5;
+        batch[i].Precision = "exact";
+        if (i % 2) batch[i].Filter = [](uint64_t, const std::string &m) { return m == "three"; };
+    }
+    const std::vector<SearchResults> got = c->SearchBatch(batch);
+    CHECK(got.size() == batch.size());
+    for (size_t i = 0; i < batch.size(); i++) {
+        const SearchResults one = c->Search(batch[i]);
+        CHECK(one.Results.size() == got[i].Results.size() && got[i].PercentSearched == 100.0);
+        for (size_t j = 0; j < one.Results.size(); j++) {
+            CHECK(one.Results[j].ID == got[i].Results[j].ID && one.Results[j].Distance == got[i].Results[j].Distance);
+            CHECK(!(i % 2) || got[i].Results[j].Metadata == "three");
+        }
+    }
+    szg_stats st;
+    CHECK(szg_get_stats(c->handle(), &st) == SZG_OK && st.mq_queries >= batch.size());  // the batch shared a sweep
+}
+
 int main(int argc, char **argv)
 {
+    TestSearchBatch();
     TestExhaustiveSearch();
     TestComputeAverageDistance();
     TestCollectionSearch();
