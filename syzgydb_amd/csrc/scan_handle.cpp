@@ -248,6 +248,19 @@ int reset_shards(szg_index *ix, const std::vector<uint64_t> &counts)
 // that holds rows can grow -- or the next, still empty one can start, which it does only at
 // a 64-row boundary (every shard's first row must be a multiple of 64: filter and tombstone
 // bitmaps are split between shards by whole words) and once its predecessor holds 4M rows.
+// a row was rewritten in place: the sketch pre-pass (if this index keeps one) re-sketches it at its next sync
+void note_overwritten(szg_index *ix, uint64_t row)
+{
+    ix->gen++;
+    if (!ix->sketch || ix->sk_need_full) return;  // no sketch yet (or a full rebuild pending): nothing to track
+    if (ix->sk_dirty_rows.size() >= 4096) {       // more than a rebuild is worth
+        ix->sk_need_full = true;
+        ix->sk_dirty_rows.clear();
+        return;
+    }
+    ix->sk_dirty_rows.push_back(row);
+}
+
 Shard *append_target(szg_index *ix)
 {
     size_t idx = 0;
@@ -409,7 +422,7 @@ uint64_t szg_index_live_rows(const szg_index *ix)
 int szg_index_load(szg_index *ix, const uint8_t *rows, uint64_t n_rows)
 {
     SZG_TRY
-    if (ix) { ix->gen++; ix->sk_need_full = true; }
+    if (ix) { ix->gen++; ix->sk_need_full = true; ix->sk_disabled = false; }
     if (!ix || (!rows && n_rows)) return fail(SZG_E_INVALID, "null argument");
     std::vector<uint64_t> counts;
     split_rows(ix, n_rows, &counts);
@@ -429,7 +442,7 @@ int szg_index_load(szg_index *ix, const uint8_t *rows, uint64_t n_rows)
 int szg_index_synth(szg_index *ix, uint64_t n_rows, uint64_t seed, uint64_t first_row)
 {
     SZG_TRY
-    if (ix) { ix->gen++; ix->sk_need_full = true; }
+    if (ix) { ix->gen++; ix->sk_need_full = true; ix->sk_disabled = false; }
     if (!ix) return fail(SZG_E_INVALID, "null argument");
     std::vector<uint64_t> counts;
     split_rows(ix, n_rows, &counts);
@@ -510,11 +523,11 @@ int szg_index_append_f64(szg_index *ix, const double *vectors, uint64_t n_rows)
 int szg_index_overwrite_f64(szg_index *ix, uint64_t row, const double *vector)
 {
     SZG_TRY
-    if (ix) { ix->gen++; ix->sk_dirty_rows.push_back(row); }
     if (!ix || !vector) return fail(SZG_E_INVALID, "null argument");
     uint64_t local;
     Shard *sh = shard_of(ix, row, &local);
     if (!sh) return fail(SZG_E_RANGE, "row out of range");
+    note_overwritten(ix, row);
     HIPCHK(hipSetDevice(sh->device));
     HIPCHK(hipDeviceSynchronize());
     uint8_t *stage8 = nullptr;
@@ -534,11 +547,11 @@ int szg_index_overwrite_f64(szg_index *ix, uint64_t row, const double *vector)
 int szg_index_overwrite(szg_index *ix, uint64_t row, const uint8_t *row_bytes)
 {
     SZG_TRY
-    if (ix) { ix->gen++; ix->sk_dirty_rows.push_back(row); }
     if (!ix || !row_bytes) return fail(SZG_E_INVALID, "null argument");
     uint64_t local;
     Shard *sh = shard_of(ix, row, &local);
     if (!sh) return fail(SZG_E_RANGE, "row out of range");
+    note_overwritten(ix, row);
     HIPCHK(hipSetDevice(sh->device));
     HIPCHK(hipDeviceSynchronize());
     return upload_rows(ix, sh, local, row_bytes, 1);
@@ -674,8 +687,6 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
         ix->sketch_extra = (int)value;
         return SZG_OK;
     }
-    ix->opt_log.emplace_back(n, value);  // the sketch index follows the same tunables
-    if (ix->sketch) (void)szg_set_option(ix->sketch, name, value);
     if (n == "slack") {
         if (value < 0 || value > 4096) return fail(SZG_E_INVALID, "slack out of range");
         ix->slack_min = (int)value;
@@ -767,6 +778,15 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
     } else {
         return fail(SZG_E_INVALID, "unknown option");
     }
+    // the sketch index follows the same tunables (the last value of each, replayed when it is created)
+    bool seen = false;
+    for (auto &o : ix->opt_log)
+        if (o.first == n) {
+            o.second = value;
+            seen = true;
+        }
+    if (!seen) ix->opt_log.emplace_back(n, value);
+    if (ix->sketch) (void)szg_set_option(ix->sketch, name, value);
     return SZG_OK;
     SZG_CATCH
 }

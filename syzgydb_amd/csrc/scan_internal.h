@@ -391,6 +391,7 @@ void split_rows(const szg_index *ix, uint64_t n_rows, std::vector<uint64_t> *cou
 Shard *shard_of(szg_index *ix, uint64_t row, uint64_t *local);
 int reset_shards(szg_index *ix, const std::vector<uint64_t> &counts);
 Shard *append_target(szg_index *ix);
+void note_overwritten(szg_index *ix, uint64_t row);
 
 // ---- scan_topk.cpp
 LaunchGeom scan_geometry(const szg_index *ix, const Shard *sh, int kp, bool plain_topk = false);

@@ -111,6 +111,16 @@ int sketch_sync(szg_index *ix)
         if (rc) return rc;
         unsigned long long *d_ang = nullptr;
         uint32_t *d_exc = nullptr, *d_list = nullptr;
+        struct Scratch {  // freed on every exit path
+            unsigned long long *&a;
+            uint32_t *&b, *&c;
+            ~Scratch()
+            {
+                (void)hipFree(a);
+                (void)hipFree(b);
+                (void)hipFree(c);
+            }
+        } scratch{d_ang, d_exc, d_list};
         HIPCHK(hipMalloc((void **)&d_ang, 16));
         HIPCHK(hipMalloc((void **)&d_exc, (exc_cap + 1) * sizeof(uint32_t)));
         HIPCHK(hipMemset(d_ang, 0, 16));
@@ -130,15 +140,18 @@ int sketch_sync(szg_index *ix)
         std::vector<uint32_t> exc(exc_cap + 1, 0);
         if (e == hipSuccess) e = hipMemcpy(&ang_bits, d_ang, sizeof(ang_bits), hipMemcpyDeviceToHost);  // (synchronises)
         if (e == hipSuccess) e = hipMemcpy(exc.data(), d_exc, exc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
-        (void)hipFree(d_ang);
-        (void)hipFree(d_exc);
-        if (d_list) (void)hipFree(d_list);
         if (e != hipSuccess) return fail(SZG_E_DEVICE, "sketch build", e);
         double ang;
         memcpy(&ang, &ang_bits, sizeof(ang));
         ix->sk_max_ang = std::max(ix->sk_max_ang, ang);
         if (exc[0] > exc_cap || ix->sk_exc.size() + exc[0] > exc_cap) {
-            ix->sk_disabled = true;  // a collection of zero / non-finite rows: nothing to gain
+            // a collection of zero / non-finite rows: nothing to gain -- give the second index (+25 % memory) back;
+            // the next load / synth gets a fresh try
+            ix->sk_disabled = true;
+            szg_index_destroy(ix->sketch);
+            ix->sketch = nullptr;
+            ix->sk_need_full = true;
+            ix->sk_dirty_rows.clear();
             return SZG_OK;
         }
         for (uint32_t i = 0; i < exc[0]; i++) {
