@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from syzgydb_amd import ScanIndex
 from syzgydb_amd.synth import synth_vectors
 n, dim, bits, metric, k = int(os.environ.get('SZG_ROWS', '1000000')), int(os.environ.get('SZG_DIM', '768')), int(os.environ.get('SZG_BITS', '32')), int(os.environ.get('SZG_METRIC', '1')), 10
-nq = 960
+nq = int(os.environ.get('SZG_NQ', '960'))
 q = synth_vectors(99, 0, nq, dim)
 with ScanIndex(dim, bits, metric, devices=[0]) as ix:
     ix.synth(n, 1234)

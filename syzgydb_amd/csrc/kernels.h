@@ -176,6 +176,7 @@ struct MqArgs {
     // query's candidate buffer; thr comes from a sweep of a prefix of the rows
     int n_groups;                // int8 sweep: query groups of 48 one launch walks (0 / 1: one); image g at
     uint32_t group_stride;       // queries + g * group_stride bytes, thr / keys / candidates indexed by 48 g + q
+    int shape_kernels;           // int8 sweep: take the row-shape-specialised kernel where one exists
     int collect;
     const float *thr;            // [n_queries]
     uint64_t *cand_buf;          // [n_queries][cand_cap]  (ordered key << 32 | row)

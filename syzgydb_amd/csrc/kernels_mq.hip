@@ -42,7 +42,7 @@ namespace {
 #define SZG_MQ_RING 4  // 16-byte loads per lane in flight (4 vs 6: -1.5 % on the int8 sweeps, no change on f32)
 #endif
 #ifndef SZG_MQ8_WAVES
-#define SZG_MQ8_WAVES 12  // waves per block (one block per CU) of the int8 sweep
+#define SZG_MQ8_WAVES 12  // waves per block (one block per CU) of the int8 sweeps (the 12-step shape kernel: 8)
 #endif
 #ifndef SZG_RESCORE_BLOCKS
 #define SZG_RESCORE_BLOCKS 64  // blocks (of 4 waves) per query of the float32 re-score
@@ -65,12 +65,15 @@ __device__ __forceinline__ u32x4 load_nt(const uint8_t *p)
 {
     return *reinterpret_cast<const u32x4 *>(p);
 }
-// tiled rows (4- and 8-bit): a wave instruction reads one whole KiB that is used once per
-// sweep -- stream it past the caches (measured on the 8-bit sweep: 199 -> 182 us)
-__device__ __forceinline__ u32x4 load_stream(const uint8_t *p, bool nt)
+// tiled rows (4- and 8-bit): a wave instruction reads one whole KiB that is used once per sweep -- stream it past
+// the caches.  The hint is a template argument, not a run-time flag: `if (nt) nontemporal_load(p) else load(p)` is
+// folded by the optimiser into ONE plain load before inlining (the two arms read the same address and the merged
+// instruction keeps only the metadata both carry), which is how the int8 sweeps came to run without the hint.
+template <bool NT>
+__device__ __forceinline__ u32x4 load_stream(const uint8_t *p)
 {
-    if (nt) return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-    return *reinterpret_cast<const u32x4 *>(p);
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    else return *reinterpret_cast<const u32x4 *>(p);
 }
 
 // Stage n16 16-byte words of a query image into LDS.  Written as load-all / store-all groups of six: with the plain
@@ -600,8 +603,8 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
 #define MQS_ISSUE(u)                                                                     \
     {                                                                                    \
         const int adj_ = (odd && is == SS - 1) ? back : 0;                               \
-        ring_a[u] = load_stream(iptr_a + adj_, true); /* whole 128-byte lines, used once: non-temporal */ \
-        ring_b[u] = load_stream(iptr_b + adj_, true);                                    \
+        ring_a[u] = load_stream<true>(iptr_a + adj_); /* whole 128-byte lines, used once: non-temporal */ \
+        ring_b[u] = load_stream<true>(iptr_b + adj_);                                    \
         if (++is == SS) {                                                                \
             is = 0;                                                                      \
             itile += tile_stride;                                                        \
@@ -850,7 +853,7 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
 
 #define MQ8F_ISSUE(u)                                                                    \
     {                                                                                    \
-        ring[u] = load_stream(iptr, a.tiled != 0);                                       \
+        ring[u] = load_stream<true>(iptr); /* FAST: tiled */                                      \
         if (++is == steps) {                                                             \
             is = 0;                                                                      \
             itile += tile_stride;                                                        \
@@ -1037,6 +1040,200 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
 #undef MQ8_CONSUME
 }
 
+
+
+// ---- the same sweep with the row shape fixed at compile time ----------------------------------------------------
+//
+// STEPS = 64-byte steps per row (12 for 768 8-bit dims, 6 for 768 4-bit or 384 8-bit, 3 for 384 4-bit).  Round 3's
+// experiments (profiles/r03_i8_sweep_experiments.txt) showed mq_score_i8_kernel 25 % below a bare probe that does
+// the same loads, LDS operand reads, MFMAs and dot products (scripts/readbw: 6.9 TB/s), and indifferent to every
+// tunable.  What the probe has and that kernel lacks is a loop whose shape the compiler knows: here the loop walks
+// one TILE per iteration, its STEPS steps unrolled with slot = step % D (D divides STEPS), so every load address
+// is `tile pointer + constant`, every A operand an LDS read at a constant offset, the ring wait a fixed vmcnt(D-1),
+// and there is ONE copy of the tile finish (the rotating-slot loop above carries four, each with the inlined hit
+// path: 13 000 lines of ISA).  Whole 64-byte steps, fused selection only; other shapes keep mq_score_i8_kernel.
+#ifndef SZG_SABL
+#define SZG_SABL 0
+#endif
+// Waves per CU and ring depth (16-byte loads per lane in flight; divides STEPS) of the shape kernels.  768-byte rows
+// (12 steps): 8 waves with 6 KiB each in flight -- 0.122 ms per 1M-row pass against 0.134 with 12 x 4, fewer waves
+// queueing behind one another's tile finish.  Shorter rows have a finish per fewer bytes and want the 12 waves
+// (384 bytes: 0.069 against 0.075; 192: 0.046 against 0.052), and so do 4-bit rows with twice the arithmetic per byte.
+#ifndef SZG_S12_WAVES
+#define SZG_S12_WAVES 8
+#endif
+#ifndef SZG_S12_RING
+#define SZG_S12_RING 6
+#endif
+#ifndef SZG_S6_RING
+#define SZG_S6_RING 3
+#endif
+template <int RB, int STEPS>
+constexpr int i8s_waves() { return RB == 8 && STEPS == 12 ? SZG_S12_WAVES : SZG_MQ8_WAVES; }
+template <int RB, int STEPS>
+constexpr int i8s_ring()
+{
+    if (RB == 8 && STEPS == 12) return SZG_S12_RING;
+    if (RB == 8 && STEPS == 6) return SZG_S6_RING;
+    return STEPS % 4 == 0 ? 4 : (STEPS % 3 == 0 ? 3 : (STEPS % 2 == 0 ? 2 : 1));
+}
+template <int NB, int METRIC, int RB, int STEPS>
+__global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_kernel(const MqArgs a)
+{
+    constexpr int T = RB == 4 ? 2 : 1;
+    constexpr int NPL = kMqPlanes;
+    constexpr int D = i8s_ring<RB, STEPS>();
+    constexpr int QSTEP = NPL * T * NB * 64;  // 16-byte words of the image per 64-byte step
+    constexpr int N16 = STEPS * QSTEP;
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const RowLayout mlay{a.pitch, a.tiled, a.steps};
+    const uint32_t istep = a.tiled ? 1024u : 64u;
+    const int n_groups = a.n_groups > 0 ? a.n_groups : 1;
+    constexpr size_t grp_lds = (size_t)N16 * 16 + 4 * 48 * sizeof(float);  // image | qscale, qconst, qnorm2 | thresholds
+    for (int g = 0; g < n_groups; g++) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.queries) +
+                                                           (size_t)g * a.group_stride);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem + (size_t)g * grp_lds);
+        constexpr int n = N16 + (3 * 48 * 4) / 16;  // + constants table
+        stage_image(dst, src, n, tid, blockDim.x);
+        if (tid < 48)
+            reinterpret_cast<float *>(smem + (size_t)g * grp_lds + (size_t)n * 16)[tid] =
+                g * 48 + tid < a.n_queries ? a.thr[g * 48 + tid] : -3.0e38f;
+    }
+    const int trow = lane & 15;
+    const int c = lane >> 4;
+    const uint64_t n_tiles = ((uint64_t)a.n_rows + 15) / 16;
+    const uint64_t tile_stride = (uint64_t)gridDim.x * nwaves;
+    const uint64_t tile_first = (uint64_t)blockIdx.x * nwaves + wave;
+    const uint64_t n_it = tile_first < n_tiles ? (n_tiles - tile_first + tile_stride - 1) / tile_stride : 0;
+    auto row_ptr = [&](uint64_t tile) -> const uint8_t * {
+        if (SZG_SABL & 16) return a.rows + tile * (uint64_t)(STEPS * 1024) + (uint64_t)lane * 16;  // (experiment: the probe's addressing)
+        const uint64_t r = min(tile * 16 + trow, (uint64_t)a.n_rows - 1);  // past the end: a valid row, discarded
+        return a.rows + piece_offset(mlay, r, (uint32_t)c);
+    };
+    HitBuf hb;
+    {
+        uint8_t *base = smem + (size_t)n_groups * grp_lds;
+        hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
+        hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
+        hb.n = 0;
+    }
+
+    for (int grp = 0; grp < n_groups; grp++) {
+        const int qoff = grp * 48;
+        const uint8_t *gbase = smem + (size_t)grp * grp_lds;
+        const v4i32 *qimg = reinterpret_cast<const v4i32 *>(gbase) + lane;
+        const float *qtab = reinterpret_cast<const float *>(gbase + (size_t)N16 * 16);
+        const float *thr_lds = qtab + 3 * 48;
+        u32x4 ring[D];
+        v4i32 acc[NPL][NB];
+#pragma unroll
+        for (int p = 0; p < NPL; p++)
+#pragma unroll
+            for (int b = 0; b < NB; b++) acc[p][b] = v4i32{0, 0, 0, 0};
+        int SQ = 0, SV = 0;
+        uint64_t tile = tile_first;
+        const uint8_t *cur = row_ptr(tile);
+        // the ring's first D steps (D <= STEPS: all inside the first tile)
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            ring[u] = load_stream<true>(cur + (size_t)u * istep);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (grp == 0) __syncthreads();  // the query images are complete (the rows do not depend on them)
+        for (uint64_t it = 0; it < n_it; it++, tile += tile_stride) {
+            // (past the wave's last tile: its own tile again -- D loads nobody consumes)
+            const uint8_t *nxt = it + 1 < n_it ? row_ptr(tile + tile_stride) : cur;
+#pragma unroll
+            for (int st = 0; st < STEPS; st++) {
+                constexpr int kDummy = 0;
+                (void)kDummy;
+                const u32x4 v_ = ring[st % D];
+                // this slot's next load: the step D ahead, in this tile or the next
+                ring[st % D] = st + D < STEPS ? load_stream<true>(cur + (size_t)(st + D) * istep)
+                                              : load_stream<true>(nxt + (size_t)(st + D - STEPS) * istep);
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t raw_[4] = {v_.x, v_.y, v_.z, v_.w};
+                if (SZG_SABL & 8) { asm volatile("" :: "v"(v_)); continue; }
+                v4i32 bop_[T];
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    if (RB == 8) {
+                        const int wn_ = (int)(raw_[d] ^ 0x80808080u);
+                        bop_[0][d] = wn_;
+                        SQ = __builtin_amdgcn_sdot4(wn_, wn_, SQ, false);
+                        SV = __builtin_amdgcn_sdot4(wn_, 0x01010101, SV, false);
+                    } else {
+                        const int wn_ = (int)(raw_[d] ^ 0x88888888u);
+                        bop_[0][d] = (int)((raw_[d] >> 4) & 0x0F0F0F0Fu);
+                        bop_[T - 1][d] = (int)(raw_[d] & 0x0F0F0F0Fu);
+                        SQ = __builtin_amdgcn_sdot8(wn_, wn_, SQ, false);
+                        SV = __builtin_amdgcn_sdot8(wn_, 0x11111111, SV, false);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < T; t++)
+#pragma unroll
+                    for (int p = 0; p < NPL; p++)
+#pragma unroll
+                        for (int b = 0; b < NB; b++) {
+                            if (SZG_SABL & 4) { asm volatile("" :: "v"(bop_[t])); continue; }
+                            const v4i32 qc_ = qimg[st * QSTEP + ((p * T + t) * NB + b) * 64];
+                            acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qc_, bop_[t], acc[p][b], 0, 0, 0);
+                        }
+            }
+            // ---- the tile is done: row norms across the 4 chunk lanes, keys, hit test
+            if (SZG_SABL & 1) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(SQ), "v"(SV)); cur = nxt; continue; }
+            int nrm = 4 * (SQ + SV);
+            nrm += __shfl_xor(nrm, 16);
+            nrm += __shfl_xor(nrm, 32);
+            const float norm = (float)nrm + a.norm_bias;
+            const float inv = __frsqrt_rn(norm);
+            const uint64_t row = tile * 16 + trow;
+            float keys[NB][4];
+            uint32_t hm = 0;
+            const bool row_ok = row < a.n_rows;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const int q0 = b * 16 + c * 4;
+                const float4 qs4 = *reinterpret_cast<const float4 *>(qtab + q0);
+                const float4 qc4 = *reinterpret_cast<const float4 *>(qtab + 48 + q0);
+                const float4 qn4 = METRIC == kCosine ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                                     : *reinterpret_cast<const float4 *>(qtab + 96 + q0);
+                const float4 th4 = *reinterpret_cast<const float4 *>(thr_lds + q0);
+                const float qsv[4] = {qs4.x, qs4.y, qs4.z, qs4.w}, qcv[4] = {qc4.x, qc4.y, qc4.z, qc4.w};
+                const float qnv[4] = {qn4.x, qn4.y, qn4.z, qn4.w}, thv[4] = {th4.x, th4.y, th4.z, th4.w};
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float dot = (float)acc[0][b][r];  // plane 0 = the top digit
+#pragma unroll
+                    for (int p = 1; p < NPL; p++) dot = fmaf(128.0f, dot, (float)acc[p][b][r]);
+                    const float d2 = fmaf(2.0f, dot, qcv[r]);  // sum Q n
+                    float key;
+                    if (METRIC == kCosine)
+                        key = -(d2 * qsv[r]) * inv;
+                    else
+                        key = fmaf(-2.0f * qsv[r], d2, qnv[r] + norm);
+                    keys[b][r] = key;
+                    hm |= (row_ok && key <= thv[r]) ? (1u << (b * 4 + r)) : 0u;  // unused queries: thr = -3e38
+                }
+            }
+            offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row, qoff);
+#pragma unroll
+            for (int p = 0; p < NPL; p++)
+#pragma unroll
+                for (int b = 0; b < NB; b++) acc[p][b] = v4i32{0, 0, 0, 0};
+            SQ = 0;
+            SV = 0;
+            cur = nxt;
+        }
+        hit_flush(a, hb, lane);
+    }
+}
 
 #endif  // SZG_MQ_PART == 1 || 2
 
@@ -1639,11 +1836,38 @@ hipError_t launch_mq_score_i8_t(const MqArgs &a, int grid, size_t lds, hipStream
                        stream, a);
     return hipGetLastError();
 }
+template <int NB, int METRIC, int STEPS>
+hipError_t launch_mq_score_i8s_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mq_score_i8s_kernel<NB, METRIC, kRowBits, STEPS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((mq_score_i8s_kernel<NB, METRIC, kRowBits, STEPS>), dim3(grid), dim3(64 * i8s_waves<kRowBits, STEPS>()), lds, stream, a);
+    return hipGetLastError();
+}
+template <int NB, int METRIC>
+bool launch_mq_score_i8s(const MqArgs &a, int grid, size_t lds, hipStream_t stream, hipError_t *e)
+{
+    switch (a.r16 / 4) {  // the row shapes with a kernel of their own (768 / 384 dims, 8- and 4-bit)
+    case 12: *e = launch_mq_score_i8s_t<NB, METRIC, 12>(a, grid, lds, stream); return true;
+    case 6: *e = launch_mq_score_i8s_t<NB, METRIC, 6>(a, grid, lds, stream); return true;
+    case 3: *e = launch_mq_score_i8s_t<NB, METRIC, 3>(a, grid, lds, stream); return true;
+    default: return false;
+    }
+}
 template <int NB>
 hipError_t launch_mq_score_i8_m(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
     if (a.collect) {
-        if (a.r16 % 4 == 0 && a.n_rows > 0) {  // whole 64-byte steps: the predicate-free kernel
+        if constexpr (NB == 3) {  // full query groups: the row shapes with a kernel of their own
+            if (a.shape_kernels && a.tiled && a.r16 % 4 == 0 && a.n_rows > 0) {
+                hipError_t e = hipSuccess;
+                if (a.metric == kCosine ? launch_mq_score_i8s<NB, kCosine>(a, grid, lds, stream, &e)
+                                        : launch_mq_score_i8s<NB, kEuclidean>(a, grid, lds, stream, &e))
+                    return e;
+            }
+        }
+        if (a.tiled && a.r16 % 4 == 0 && a.n_rows > 0) {  // whole 64-byte steps: the predicate-free kernel
             if (a.metric == kCosine) return launch_mq_score_i8_t<NB, kCosine, true, true>(a, grid, lds, stream);
             return launch_mq_score_i8_t<NB, kEuclidean, true, true>(a, grid, lds, stream);
         }

@@ -224,6 +224,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
     a.queries = c->d_mq;
     a.n_queries = nq;
     a.n_groups = p.groups;
+    a.shape_kernels = ix->shape_kernels;
     a.group_stride = (uint32_t)p.group_stride;
     a.metric = ix->metric;
     for (int q = 0; q < nq && q < szg::kMqMaxQueries; q++) a.qnorm2[q] = (float)c->meta[q].qnorm2;
