@@ -804,6 +804,13 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
             reinterpret_cast<float *>(smem + (size_t)g * grp_lds + (size_t)n * 16)[tid] =
                 g * 48 + tid < a.n_queries ? a.thr[g * 48 + tid] : -3.0e38f;
     }
+    HitBuf hb;
+    {
+        uint8_t *base = smem + (size_t)n_groups * grp_lds;
+        hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
+        hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
+        hb.n = 0;
+    }
     for (int grp = 0; grp < n_groups; grp++) {
     const int qoff = grp * 48;  // first query of the group
     const uint8_t *gbase = smem + (size_t)grp * grp_lds;
@@ -812,13 +819,6 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
     const v4i32 *qimg = reinterpret_cast<const v4i32 *>(gbase);
     const float *qtab = reinterpret_cast<const float *>(gbase + (size_t)n16 * 16);
     const float *thr_lds = qtab + 3 * 48;
-    HitBuf hb;
-    {
-        uint8_t *base = smem + (size_t)n_groups * grp_lds;
-        hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
-        hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
-        hb.n = 0;
-    }
 
     const int trow = lane & 15;
     const int c = lane >> 4;
@@ -1030,8 +1030,8 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
         MQ8_RUN_RING(MQ8F_ISSUE, MQ8F_CONSUME)
     else
         MQ8_RUN_RING(MQ8_ISSUE, MQ8_CONSUME)
-    if (COLLECT) hit_flush(a, hb, lane);
     }  // groups
+    if (COLLECT) hit_flush(a, hb, lane);  // once for both groups (see mq_score_i8s_kernel)
 #undef MQ8F_ISSUE
 #undef MQ8F_CONSUME
 #undef MQ8_CONSUME_X
@@ -1044,17 +1044,14 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
 
 // ---- the same sweep with the row shape fixed at compile time ----------------------------------------------------
 //
-// STEPS = 64-byte steps per row (12 for 768 8-bit dims, 6 for 768 4-bit or 384 8-bit, 3 for 384 4-bit).  Round 3's
-// experiments (profiles/r03_i8_sweep_experiments.txt) showed mq_score_i8_kernel 25 % below a bare probe that does
-// the same loads, LDS operand reads, MFMAs and dot products (scripts/readbw: 6.9 TB/s), and indifferent to every
-// tunable.  What the probe has and that kernel lacks is a loop whose shape the compiler knows: here the loop walks
-// one TILE per iteration, its STEPS steps unrolled with slot = step % D (D divides STEPS), so every load address
-// is `tile pointer + constant`, every A operand an LDS read at a constant offset, the ring wait a fixed vmcnt(D-1),
-// and there is ONE copy of the tile finish (the rotating-slot loop above carries four, each with the inlined hit
-// path: 13 000 lines of ISA).  Whole 64-byte steps, fused selection only; other shapes keep mq_score_i8_kernel.
-#ifndef SZG_SABL
-#define SZG_SABL 0
-#endif
+// STEPS = 64-byte steps per row (12 for 768 8-bit dims, 6 for 768 4-bit or 384 8-bit, 3 for 384 4-bit).  The loop
+// walks one TILE per iteration, its STEPS steps unrolled with slot = step % D (D divides STEPS), so every load
+// address is `tile pointer + constant`, every A operand an LDS read at a constant offset, the ring wait a fixed
+// vmcnt(D-1), and there is ONE copy of the tile finish (the rotating-slot loop above carries four, each with the
+// inlined hit path: 13 000 lines of ISA).  Whole 64-byte steps of tiled rows, fused selection only; other shapes
+// keep mq_score_i8_kernel.  Measured against it (1M rows, ms per 48-query pass): 768 dims 8-bit 0.122 / 0.134,
+// 768 dims 4-bit 0.088 / 0.092, 384 dims 4-bit 0.053 / 0.062 (profiles/r03_i8_sweep_experiments.txt, which also
+// has the probe -- scripts/readbw -- that found the int8 sweeps running without their non-temporal hint).
 // Waves per CU and ring depth (16-byte loads per lane in flight; divides STEPS) of the shape kernels.  768-byte rows
 // (12 steps): 8 waves with 6 KiB each in flight -- 0.122 ms per 1M-row pass against 0.134 with 12 x 4, fewer waves
 // queueing behind one another's tile finish.  Shorter rows have a finish per fewer bytes and want the 12 waves
@@ -1111,7 +1108,6 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
     const uint64_t tile_first = (uint64_t)blockIdx.x * nwaves + wave;
     const uint64_t n_it = tile_first < n_tiles ? (n_tiles - tile_first + tile_stride - 1) / tile_stride : 0;
     auto row_ptr = [&](uint64_t tile) -> const uint8_t * {
-        if (SZG_SABL & 16) return a.rows + tile * (uint64_t)(STEPS * 1024) + (uint64_t)lane * 16;  // (experiment: the probe's addressing)
         const uint64_t r = min(tile * 16 + trow, (uint64_t)a.n_rows - 1);  // past the end: a valid row, discarded
         return a.rows + piece_offset(mlay, r, (uint32_t)c);
     };
@@ -1150,15 +1146,12 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
             const uint8_t *nxt = it + 1 < n_it ? row_ptr(tile + tile_stride) : cur;
 #pragma unroll
             for (int st = 0; st < STEPS; st++) {
-                constexpr int kDummy = 0;
-                (void)kDummy;
                 const u32x4 v_ = ring[st % D];
                 // this slot's next load: the step D ahead, in this tile or the next
                 ring[st % D] = st + D < STEPS ? load_stream<true>(cur + (size_t)(st + D) * istep)
                                               : load_stream<true>(nxt + (size_t)(st + D - STEPS) * istep);
                 __builtin_amdgcn_sched_barrier(0);
                 const uint32_t raw_[4] = {v_.x, v_.y, v_.z, v_.w};
-                if (SZG_SABL & 8) { asm volatile("" :: "v"(v_)); continue; }
                 v4i32 bop_[T];
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
@@ -1181,13 +1174,11 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
                     for (int p = 0; p < NPL; p++)
 #pragma unroll
                         for (int b = 0; b < NB; b++) {
-                            if (SZG_SABL & 4) { asm volatile("" :: "v"(bop_[t])); continue; }
                             const v4i32 qc_ = qimg[st * QSTEP + ((p * T + t) * NB + b) * 64];
                             acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qc_, bop_[t], acc[p][b], 0, 0, 0);
                         }
             }
             // ---- the tile is done: row norms across the 4 chunk lanes, keys, hit test
-            if (SZG_SABL & 1) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(SQ), "v"(SV)); cur = nxt; continue; }
             int nrm = 4 * (SQ + SV);
             nrm += __shfl_xor(nrm, 16);
             nrm += __shfl_xor(nrm, 32);
@@ -1231,8 +1222,10 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
             SV = 0;
             cur = nxt;
         }
-        hit_flush(a, hb, lane);
     }
+    // one flush for both groups (the buffered query index carries the group): a flush is a returning atomic per hit
+    // and a drained load queue -- a memory round trip with nothing in flight, which at the end of every pass cost 3 %
+    hit_flush(a, hb, lane);
 }
 
 #endif  // SZG_MQ_PART == 1 || 2
