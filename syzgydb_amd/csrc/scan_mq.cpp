@@ -10,15 +10,19 @@ namespace szgi {
 void build_image_bf16(const szg_index *ix, Ctx *c, int nq, int nb)
 {
     uint16_t *im = reinterpret_cast<uint16_t *>(c->h_mq);
+    const int dim = ix->dim;
     for (int q = 0; q < nq; q++) {
-        const double *src = c->h_q64 + (size_t)q * ix->dim;
+        const double *src = c->h_q64 + (size_t)q * dim;
         const double m1 = c->meta[q].m1;
         double scale = m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0;
         if (ix->metric != SZG_COSINE) scale = 1.0;
         const int b = q / 16, qi = q % 16;
-        for (int e = 0; e < ix->dim; e++) {
-            const int S = e >> 5, w = e & 31;
-            im[((((size_t)S * nb + b) * 64) + (w >> 3) * 16 + qi) * 8 + (w & 7)] = bf16_rne((float)(src[e] * scale));
+        // runs of 8 consecutive elements are contiguous in the image (one lane's 16 bytes)
+        for (int e0 = 0; e0 < dim; e0 += 8) {
+            const int S = e0 >> 5, kg = (e0 & 31) >> 3;
+            uint16_t *dst = im + ((((size_t)S * nb + b) * 64) + kg * 16 + qi) * 8;
+            const int cnt = std::min(8, dim - e0);
+            for (int i = 0; i < cnt; i++) dst[i] = bf16_rne((float)(src[e0 + i] * scale));
         }
     }
 }
@@ -30,27 +34,45 @@ void build_image_bf16(const szg_index *ix, Ctx *c, int nq, int nb)
 // 32*piece + 2*bi (+1 for the odd half); the operand is the nibble x and n = 2x - 15.
 void build_image_i8(const szg_index *ix, Ctx *c, int nq, int nb, size_t group_stride)
 {
-    const int r16 = ix->map.r16;
-    const int NP = szg::kMqPlanes, T = ix->bits == 4 ? 2 : 1;
+    const int r16 = ix->map.r16, dim = ix->dim;
+    constexpr int NP = szg::kMqPlanes;
+    const int T = ix->bits == 4 ? 2 : 1;
     const int epp = ix->bits == 4 ? 32 : 16;  // elements per 16-byte piece
     const size_t plane = (size_t)T * nb * 64 * 16;  // bytes between digit planes of a step
+    const size_t half = (size_t)nb * 64 * 16;       // 4-bit rows: bytes from the even elements' operand to the odd elements'
     for (int q = 0; q < nq; q++) {
-        const int32_t *Qv = c->h_mqQ + (size_t)q * ix->dim;
+        const int32_t *Qv = c->h_mqQ + (size_t)q * dim;
         const int ql = q % (16 * nb);  // position inside its group
         uint8_t *im8 = c->h_mq + (size_t)(q / (16 * nb)) * group_stride;
         const int b = ql / 16, qi = ql % 16;
-        for (int e = 0; e < ix->dim; e++) {
-            int Q = Qv[e];
-            const int j = e / epp, i = e % epp;
-            const int bi = T == 2 ? i >> 1 : i, half = T == 2 ? i & 1 : 0;
-            const int s = j >> 2, ch = j & 3;
-            uint8_t *dst = im8 + ((((size_t)s * NP * T + half) * nb + b) * 64 + ch * 16 + qi) * 16 + bi;
-            for (int p = NP - 1; p > 0; p--) {   // low digits first, balanced in [-64, 63]
-                const int dig = ((Q + 64) & 127) - 64;
-                Q = (Q - dig) >> 7;
-                dst[(size_t)p * plane] = (uint8_t)(int8_t)dig;
+        // one 16-byte piece of the row = one lane's word per (plane, half): its bytes are contiguous in the image
+        for (int j = 0, e0 = 0; e0 < dim; j++, e0 += epp) {
+            const int cnt = std::min(epp, dim - e0);
+            int8_t dig[NP][32];
+            for (int i = 0; i < cnt; i++) {   // low digits first, balanced in [-64, 63]; plane 0 = the top digit
+                int Q = Qv[e0 + i];
+                for (int p = NP - 1; p > 0; p--) {
+                    const int d = ((Q + 64) & 127) - 64;
+                    Q = (Q - d) >> 7;
+                    dig[p][i] = (int8_t)d;
+                }
+                dig[0][i] = (int8_t)Q;
             }
-            dst[0] = (uint8_t)(int8_t)Q;         // plane 0 = the top digit
+            for (int p = 0; p < NP; p++)
+                for (int i = cnt; i < epp; i++) dig[p][i] = 0;
+            const int st = j >> 2, ch = j & 3;
+            uint8_t *dst = im8 + ((((size_t)st * NP * T) * nb + b) * 64 + ch * 16 + qi) * 16;
+            for (int p = 0; p < NP; p++) {
+                uint8_t *d = dst + (size_t)p * plane;
+                if (T == 1) {
+                    memcpy(d, dig[p], 16);
+                } else {
+                    for (int k = 0; k < 16; k++) {
+                        d[k] = (uint8_t)dig[p][2 * k];
+                        d[half + k] = (uint8_t)dig[p][2 * k + 1];
+                    }
+                }
+            }
         }
         float *tab = reinterpret_cast<float *>(im8 + szg::mq_i8_image_bytes(ix->bits, r16, nb));
         tab[ql] = (float)c->meta[q].mq_qscale;
