@@ -507,8 +507,8 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 //
 // A wave owns a tile of 16 rows and multiplies 32 elements of them per step with one A operand per
 // query block (image [32-element step][query block][lane = k-group*16 + query][8 bf16]).  Row
-// norms (of the float32 values) are VALU side work as in mq_score_kernel.  Whole 64-byte steps
-// only (dim % 16 == 0); other shapes use mq_score_kernel.
+// norms (of the float32 values) are VALU side work as in mq_score_kernel.  Any dimension: rows are walked in
+// 128-byte steps and the chunks of a short last step that lie past the row are read as zeros.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -536,9 +536,9 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int nwaves = blockDim.x >> 6;
-    const int steps = a.r16 / 4;
-    const int SS = (steps + 1) / 2;
-    const bool odd = (steps & 1) != 0;
+    const int SS = (a.r16 + 7) / 8;             // 128-byte (32-element) steps per row, the last one possibly short
+    const int last_valid = a.r16 - 8 * (SS - 1);  // 16-byte chunks of the last step that belong to the row (1..8)
+    const bool partial = last_valid < 8;
     const int n16 = SS * NB * 64;
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
@@ -596,15 +596,17 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
         iptr_b = a.rows + (size_t)min(tile * 16 + 8 + r8, last) * a.pitch + (size_t)ch * 16;
     };
     set_rows(tile_first);
-    // the half step at the end of an odd row: its upper four chunks lie past the row; those lanes read
-    // the lower four again (zeros stand against them in the image) and keep them out of the norm
-    const int back = ch >= 4 ? -64 : 0;
+    // a short step at the end of a row whose pitch is not a multiple of 128 bytes (any dimension that is not a
+    // multiple of 32): the chunks past the row belong to the next row -- those lanes read the shard's zero block
+    // instead (zeros for the products, the norm and the zero-row test alike; the padding inside the row's last
+    // 16-byte piece is stored as zeros)
+    const bool past = ch >= last_valid;
 
 #define MQS_ISSUE(u)                                                                     \
     {                                                                                    \
-        const int adj_ = (odd && is == SS - 1) ? back : 0;                               \
-        ring_a[u] = load_stream<true>(iptr_a + adj_); /* whole 128-byte lines, used once: non-temporal */ \
-        ring_b[u] = load_stream<true>(iptr_b + adj_);                                    \
+        const bool z_ = partial && is == SS - 1 && past;                                 \
+        ring_a[u] = load_stream<true>(z_ ? a.zero16 : iptr_a); /* whole 128-byte lines, used once: non-temporal */ \
+        ring_b[u] = load_stream<true>(z_ ? a.zero16 : iptr_b);                           \
         if (++is == SS) {                                                                \
             is = 0;                                                                      \
             itile += tile_stride;                                                        \
@@ -618,15 +620,12 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
 #define MQS_CONSUME(u)                                                                   \
     {                                                                                    \
         const u32x4 va_ = ring_a[u], vb_ = ring_b[u];                                    \
-        const bool skip_ = odd && cs == SS - 1 && ch >= 4;                               \
         const float xa_[4] = {__uint_as_float(va_.x), __uint_as_float(va_.y), __uint_as_float(va_.z),       \
                               __uint_as_float(va_.w)};                                   \
         const float xb_[4] = {__uint_as_float(vb_.x), __uint_as_float(vb_.y), __uint_as_float(vb_.z),       \
                               __uint_as_float(vb_.w)};                                   \
-        if (!skip_) {                                                                    \
-            _Pragma("unroll") for (int i = 0; i < 4; i++) nrm_a = fmaf(xa_[i], xa_[i], nrm_a); \
-            _Pragma("unroll") for (int i = 0; i < 4; i++) nrm_b = fmaf(xb_[i], xb_[i], nrm_b); \
-        }                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) nrm_a = fmaf(xa_[i], xa_[i], nrm_a);   \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) nrm_b = fmaf(xb_[i], xb_[i], nrm_b);   \
         nz_a |= va_.x | va_.y;                                                           \
         nz_a |= va_.z | va_.w;                                                           \
         nz_b |= vb_.x | vb_.y;                                                           \
@@ -1328,7 +1327,7 @@ __global__ __launch_bounds__(256) void cand_select_kernel(const uint64_t *cand_b
 // Second stage of the bfloat16 sweep: the (few thousand) candidates it collected are scored again in
 // float32 -- one wave per (query, candidate), the query as float32 in LDS -- and the key inside the
 // candidate word is replaced, so that the selection and the certification that follow work with
-// float32 keys (bound: key_eps, mq branch).  grid (blocks, queries); 32-bit rows, dim % 4 == 0.
+// float32 keys (bound: key_eps, mq branch).  grid (blocks, queries); 32-bit rows, any dim.
 template <int METRIC>
 __global__ __launch_bounds__(256) void cand_rescore_kernel(const uint8_t *rows, uint32_t pitch, int dim,
                                                            const double *q64, const double *qscale,
@@ -1341,10 +1340,10 @@ __global__ __launch_bounds__(256) void cand_rescore_kernel(const uint8_t *rows, 
     const int q = blockIdx.y;
     const uint32_t n = min(cand_count[q * kCandCountStride], cand_cap);
     const double sc = qscale[q];
-    for (int i = tid; i < dim; i += blockDim.x) qf[i] = (float)(q64[(size_t)q * dim + i] * sc);
+    const int d4 = (dim + 3) >> 2;  // whole 16-byte pieces: the row's padding is stored as zeros, the query's staged as zeros
+    for (int i = tid; i < 4 * d4; i += blockDim.x) qf[i] = i < dim ? (float)(q64[(size_t)q * dim + i] * sc) : 0.0f;
     __syncthreads();
     const float4 *qf4 = reinterpret_cast<const float4 *>(qf);
-    const int d4 = dim >> 2;
     uint64_t *cb = cand_buf + (size_t)q * cand_cap;
     for (uint32_t ci = blockIdx.x * 4 + wave; ci < n; ci += gridDim.x * 4) {
         const uint32_t row = (uint32_t)cb[ci];
@@ -1515,7 +1514,8 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
     for (uint32_t i = tid; i < n; i += kRefineThreads) cand[i] = src[i];
     if (MODE > 0) {
         const double sc = qscale[q];
-        for (int i = tid; i < dim; i += kRefineThreads) qf[i] = (float)(q64[(size_t)q * dim + i] * sc);
+        for (int i = tid; i < 4 * ((dim + 3) >> 2); i += kRefineThreads)
+            qf[i] = i < dim ? (float)(q64[(size_t)q * dim + i] * sc) : 0.0f;  // (padding: zeros, as in the rows)
     }
     if (tid == 0) n_band = 0;
     WaveList wl;
@@ -1565,7 +1565,7 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
     }
     // float32 keys for the band: one wave per candidate
     const float4 *qf4 = reinterpret_cast<const float4 *>(qf);
-    const int d4 = dim >> 2;
+    const int d4 = (dim + 3) >> 2;
     for (uint32_t ci = wave; ci < nb; ci += NW) {
         const uint32_t row = (uint32_t)band[ci];
         const float4 *rp = reinterpret_cast<const float4 *>(rows + (size_t)row * pitch);
@@ -1639,9 +1639,8 @@ hipError_t launch_cand_rescore(int metric, const uint8_t *rows, uint32_t pitch, 
                                const double *qscale, uint64_t *cand_buf, const uint32_t *cand_count,
                                uint32_t cand_cap, int n_queries, hipStream_t stream)
 {
-    if (dim % 4 != 0) return hipErrorInvalidValue;
     const dim3 grid(SZG_RESCORE_BLOCKS, n_queries);  // x 4 waves: one candidate per wave and trip
-    const size_t lds = (size_t)dim * sizeof(float);
+    const size_t lds = (size_t)((dim + 3) & ~3) * sizeof(float);
     if (metric == kCosine)
         hipLaunchKernelGGL(cand_rescore_kernel<kCosine>, grid, dim3(256), lds, stream, rows, pitch, dim, q64, qscale,
                            cand_buf, cand_count, cand_cap);
@@ -1653,7 +1652,7 @@ hipError_t launch_cand_rescore(int metric, const uint8_t *rows, uint32_t pitch, 
 
 bool cand_refine_applies(int kp, uint32_t cand_cap, int dim, bool rescore)
 {
-    return kp <= kRefineMaxKp && cand_cap <= (uint32_t)kRefineMaxCands && (!rescore || (dim % 4 == 0 && dim <= 4096));
+    return kp <= kRefineMaxKp && cand_cap <= (uint32_t)kRefineMaxCands && (!rescore || dim <= 4096);
 }
 
 hipError_t launch_cand_refine(int mode, const uint8_t *rows, uint32_t pitch, int dim, const double *q64,
@@ -1663,7 +1662,7 @@ hipError_t launch_cand_refine(int mode, const uint8_t *rows, uint32_t pitch, int
 {
     if (!cand_refine_applies(kp, cand_cap, dim, mode > 0)) return hipErrorInvalidValue;
     const size_t lds = ((size_t)kRefineMaxCands + (size_t)(kRefineThreads / 64) * kp + kp + kRefineMaxBand) * sizeof(uint64_t) +
-                       (mode > 0 ? (size_t)dim * sizeof(float) : 0);
+                       (mode > 0 ? (size_t)((dim + 3) & ~3) * sizeof(float) : 0);
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1754,7 +1753,7 @@ size_t mq_i8_lds_bytes(int row_bits, int r16, int nb, int groups)
 {   // per group: image + constants + thresholds; + the 12 waves' hit buffers
     return (size_t)groups * (mq_i8_image_bytes(row_bits, r16, nb) + 4 * 48 * sizeof(float)) + (size_t)SZG_MQ8_WAVES * 64 * 9;
 }
-size_t mq_bf16_image_bytes(int r16, int nb) { return (size_t)((r16 / 4 + 1) / 2) * nb * 1024; }
+size_t mq_bf16_image_bytes(int r16, int nb) { return (size_t)((r16 + 7) / 8) * nb * 1024; }
 size_t mq_bf16_lds_bytes(int r16, int nb)
 {   // + thresholds, |q|^2 table and the waves' hit buffers
     return mq_bf16_image_bytes(r16, nb) + 2 * kMqMaxQueries * sizeof(float) + (size_t)SZG_MQB_WAVES * kHitCap * 9 +
@@ -1802,7 +1801,7 @@ hipError_t launch_mq_score_bf16_m(const MqArgs &a, int grid, size_t lds, hipStre
 
 hipError_t launch_mq_score_bf16_rows32(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
 {
-    if (a.r16 % 4 != 0 || a.dim != a.r16 * 4 || a.tiled || a.n_rows == 0) return hipErrorInvalidValue;
+    if (a.tiled || a.n_rows == 0 || !a.zero16) return hipErrorInvalidValue;
     switch (nb) {
     case 1: return launch_mq_score_bf16_m<1>(a, grid, lds, stream);
     case 2: return launch_mq_score_bf16_m<2>(a, grid, lds, stream);

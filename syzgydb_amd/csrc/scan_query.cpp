@@ -219,10 +219,10 @@ double key_eps(const szg_index *ix, double key, const QMeta &m)
 // ---- multi-query sweep (32-bit rows, cosine): B queries share one pass ------------
 
 bool mq_uses_i8(const szg_index *ix) { return (ix->bits == 8 || ix->bits == 4) && ix->mq_i8; }
-// 32-bit rows of whole 64-byte steps: the bfloat16 sweep
+// 32-bit rows (any dimension; not the experimental tiled layout): the bfloat16 sweep
 bool mq_uses_bf16(const szg_index *ix)
 {
-    return ix->bits == 32 && ix->mq_bf16 && ix->map.r16 % 4 == 0 && ix->dim == ix->map.r16 * 4 && !ix->layout.tiled;
+    return ix->bits == 32 && ix->mq_bf16 && !ix->layout.tiled;
 }
 
 // round to nearest even, as v_cvt_pk_bf16_f32 does (NaN stays NaN)

@@ -40,7 +40,7 @@ def test_shared_sweep_matches_oracle(dim, n, nq):
         check(ix, rows, dim, Q, 10)
         st = ix.stats()
         if DEFAULT_TUNABLES:
-            cap = 96 if dim % 16 == 0 else 48   # bfloat16 sweep (whole 64-byte steps): 6 query blocks, else 3
+            cap = 96   # bfloat16 sweep (32-bit rows of any dimension): 6 query blocks
             shared = nq - (nq % cap if nq % cap < 2 else 0)   # a tail below mq_min (2) gets its own sweep
             assert st["mq_queries"] == shared and st["mq_launches"] == (shared + cap - 1) // cap
         ix.set_option("multi_query", 0)
@@ -207,13 +207,15 @@ def test_fused_selection_overflow_falls_back(bits):
                 assert ((got == want) | (np.isnan(got) & np.isnan(want))).all(), qi
 
 
-# ---- bfloat16 shared sweep (32-bit rows of whole 64-byte steps) ------------------------------------
+# ---- bfloat16 shared sweep (32-bit rows, any dimension) --------------------------------------------
 
 @pytest.mark.parametrize("metric", [SZG_COSINE, SZG_EUCLIDEAN])
-@pytest.mark.parametrize("dim,n", [(768, 3000), (48, 6000), (16, 9000), (80, 4000), (1040, 2500), (1536, 2000)])
+@pytest.mark.parametrize("dim,n", [(768, 3000), (48, 6000), (16, 9000), (80, 4000), (1040, 2500), (1536, 2000),
+                                   (100, 4000), (37, 3000), (3, 2500), (33, 5000), (770, 2500), (8, 6000), (63, 3000),
+                                   (1001, 2000)])
 def test_bf16_sweep_matches_oracle(metric, dim, n):
-    """Even and odd numbers of 64-byte steps per row (the last 32-element step half empty), two-stage
-    selection; answers identical to the reference loop's."""
+    """Any dimension: whole 128-byte steps, a last step of 1..7 16-byte pieces (read past the row as zeros), a last
+    piece with padding; two-stage selection; answers identical to the reference loop's."""
     rows = orc.synth_rows(900 + dim, 0, n, dim, 32)
     Q = orc.synth_vectors(901 + dim, 0, 50, dim)
     with ScanIndex(dim, 32, metric) as ix:
