@@ -18,7 +18,7 @@ rng = np.random.default_rng(seed)
 OPTS = [("queries_per_launch", [1, 3, 16]), ("multi_query", [0, 1]), ("mq_fused", [0, 1]), ("mq_i8", [0, 1]),
         ("serialize_scans", [0, 1]), ("shape_kernels", [0, 1]), ("blocks_per_cu", [0, 1, 3]),
         ("mq_min", [2, 8]), ("mq_blocks", [1, 2, 3]), ("slack", [0, 16, 40]), ("mq_bf16", [0, 1, 1]),
-        ("mq_overlap", [0, 1]), ("mq_bf16_slack", [0, 118]), ("mq_hits", [64, 1024]), ("sketch", [0, 1, 1]),
+        ("mq_overlap", [0, 1]), ("mq_bf16_slack", [0, 118, 246]), ("mq_hits", [64, 1024]), ("sketch", [0, 1, 1]),
         ("sketch_extra", [0, 30]), ("sketch_min_rows", [1, 1, 4096]), ("mq_i8_groups", [1, 2]),
         ("mq_refine", [0, 1, 1]), ("first_batch", [0, 1, 4]), ("mask_dense", [0, 1]), ("coalesce", [0, 1])]
 

@@ -201,12 +201,13 @@ bool cand_refine_applies(int kp, uint32_t cand_cap, int dim, bool rescore);
 hipError_t launch_cand_refine(int mode, const uint8_t *rows, uint32_t pitch, int dim, const double *q64,
                               const double *qscale, const double *qnorm2, const uint64_t *cand_buf, uint32_t *cand_count,
                               uint32_t cand_cap, int kp, int n_queries, const uint64_t *sent, int n_sent,
-                              uint64_t *lists, float *band_edge, hipStream_t stream);
-// float32 re-score of the collected candidates of a bfloat16 sweep (32-bit rows): replaces the key in every
-// candidate word; qscale[q] = 1/|q| (cosine) or 1 (euclid), the float32 query is (float)(q64 * qscale)
+                              uint64_t *lists, float *band_edge, int row_bits, hipStream_t stream);
+// float32 re-score of the collected candidates of a bfloat16 sweep (32-bit rows, or 16-bit rows of whole 16-byte
+// pieces, decoded to n = 2v - 65535): replaces the key in every candidate word; qscale[q] = 1/|q| (cosine) or the
+// prepared query's scale (euclid: 1, or 65535 for 16-bit rows), the float32 query is (float)(q64 * qscale)
 hipError_t launch_cand_rescore(int metric, const uint8_t *rows, uint32_t pitch, int dim, const double *q64,
                                const double *qscale, uint64_t *cand_buf, const uint32_t *cand_count,
-                               uint32_t cand_cap, int n_queries, hipStream_t stream);
+                               uint32_t cand_cap, int n_queries, int row_bits, hipStream_t stream);
 
 // Exact integer shared sweep for 8-bit rows (v_mfma_i32_16x16x64_i8).  MqArgs.queries is
 // the image [64-byte step][digit plane h,m,l][query block][lane = chunk*16 + query][16 bytes]
@@ -221,9 +222,9 @@ hipError_t launch_mq_score_i8(int row_bits, const MqArgs &a, int nb, int grid, h
 // bfloat16 shared sweep for 32-bit rows of whole 64-byte steps (v_mfma_f32_16x16x32_bf16): MqArgs.queries is the
 // image [32-element step][query block][lane = k-group*16 + query][8 bf16 = elements 8*k-group + 0..7 of the step]
 // (zeros where the row has ended).
-size_t mq_bf16_image_bytes(int r16, int nb);
-size_t mq_bf16_lds_bytes(int r16, int nb);
-hipError_t launch_mq_score_bf16(const MqArgs &a, int nb, int grid, hipStream_t stream);
+size_t mq_bf16_image_bytes(int row_bits, int r16, int nb);
+size_t mq_bf16_lds_bytes(int row_bits, int r16, int nb);
+hipError_t launch_mq_score_bf16(int row_bits, const MqArgs &a, int nb, int grid, hipStream_t stream);  // 32- or 16-bit rows
 hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStream_t stream);  // a.metric picks the key
 hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_rows,
                             const uint64_t *live_bits, const uint64_t *allow_bits,

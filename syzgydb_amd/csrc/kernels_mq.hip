@@ -203,7 +203,7 @@ __device__ __forceinline__ void offer_tile_hits(const MqArgs &a, HitBuf &hb, int
                 hit_offer(a, hb, lane, (hm >> (b * 4 + r)) & 1u, qoff + b * 16 + c * 4 + r, row, keys[b][r]);
 }
 
-#if SZG_MQ_PART >= 4
+#if SZG_MQ_PART >= 4 && SZG_MQ_PART < 100
 // LDS image of the batch: [piece j][query block][group of 4 elements][query 16][4 floats]
 // FAST: rows are whole 64-byte steps of real elements (r16 % 4 == 0, dim a multiple of the
 // elements per piece) -- no per-piece range predicates, the row and LDS addresses advance
@@ -491,19 +491,19 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
     if (COLLECT) hit_flush(a, hb, lane);
 }
 
-#endif  // SZG_MQ_PART >= 4
+#endif  // SZG_MQ_PART >= 4 (float32 sweeps)
 
-#if SZG_MQ_PART == 3
+#if SZG_MQ_PART == 3 || SZG_MQ_PART == 116
 // ---- bfloat16 shared sweep, 32-bit rows ---------------------------------------------------------------------------
 //
 // The sweep only has to RANK: what it keeps is re-scored in float64 and certified against the
 // bound of its own arithmetic (key_eps, bf16 branch), so its products need not carry 24 bits.
 // Rows and queries are rounded to bfloat16 on the fly (v_cvt_pk_bf16_f32, round to nearest
-// even: relative error <= 2^-9 each, same exponent range as float32) and multiplied by
+// even: 7 fraction bits, relative error <= 2^-8 each, same exponent range as float32) and multiplied by
 // v_mfma_f32_16x16x32_bf16 -- 16 x the rate of the float32 MFMA, which turns the 48-query
 // sweep from matrix-bound (0.64 ms at 1M x 768) into a plain stream of the rows.  By
-// Cauchy-Schwarz the dot product moves by at most (2^-8 + 2^-18) |x| |q|, i.e. 0.0039 in -cos:
-// a band that holds a few dozen rows of a million, all of which the float64 re-rank sees.
+// Cauchy-Schwarz the dot product moves by at most (2^-7 + 2^-16) |x| |q|, i.e. 0.0078 in -cos:
+// a band that holds on the order of a hundred rows of a million, all of which the float32 re-score sees.
 //
 // A wave owns a tile of 16 rows and multiplies 32 elements of them per step with one A operand per
 // query block (image [32-element step][query block][lane = k-group*16 + query][8 bf16]).  Row
@@ -528,18 +528,26 @@ constexpr int kRingBPrefix = SZG_MQB_RING_PREFIX;
 // the MFMA operand layout through its own KiB of LDS: convert, ds_write_b64 in row-major order,
 // ds_read_b128 as lane (row, k-group).  The image is in natural order: lane (query, k-group g)
 // holds elements 8g..8g+7 of the step.
-template <int NB, int METRIC, bool COLLECT>
+//
+// QBITS = 16: the rows are 16-bit codes v, decoded on the fly to n = 2v - 65535 (exact in float32) and rounded to
+// bfloat16 like float rows.  A 128-byte step then holds 64 elements = two MFMA K-steps: the wave stages and
+// multiplies the lower and the upper four chunks one after the other through the same KiB.  A chunk read from the
+// zero block (past a short last step) decodes to -65535 per element: zeros stand against it in the image, and
+// those lanes stay out of the norm.  Whole 16-byte pieces only (dim % 8 == 0: padding codes would decode to
+// -65535 inside the norm).
+template <int NB, int METRIC, bool COLLECT, int QBITS>
 __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArgs a)
 {
+    constexpr int KS = QBITS == 16 ? 2 : 1;  // 32-element MFMA K-steps per 128-byte step of a row
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int nwaves = blockDim.x >> 6;
-    const int SS = (a.r16 + 7) / 8;             // 128-byte (32-element) steps per row, the last one possibly short
+    const int SS = (a.r16 + 7) / 8;             // 128-byte steps per row, the last one possibly short
     const int last_valid = a.r16 - 8 * (SS - 1);  // 16-byte chunks of the last step that belong to the row (1..8)
     const bool partial = last_valid < 8;
-    const int n16 = SS * NB * 64;
+    const int n16 = SS * KS * NB * 64;
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -566,6 +574,8 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
     const int r8 = lane >> 3, ch = lane & 7;    // load role: rows r8 and 8 + r8, 16-byte chunk of the 128-byte step
     uint2 *w_a = reinterpret_cast<uint2 *>(stage + r8 * 64 + ch * 8);
     uint2 *w_b = reinterpret_cast<uint2 *>(stage + 512 + r8 * 64 + ch * 8);
+    uint4 *w16_a = reinterpret_cast<uint4 *>(stage + r8 * 64 + (ch & 3) * 16);  // QBITS = 16: 8 bf16 per chunk, half a step at a time
+    uint4 *w16_b = reinterpret_cast<uint4 *>(stage + 512 + r8 * 64 + (ch & 3) * 16);
     const v4i32b *r_op = reinterpret_cast<const v4i32b *>(stage + trow * 64 + c * 16);
 
     const uint64_t n_tiles = ((uint64_t)a.n_rows + 15) / 16;
@@ -620,32 +630,74 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
 #define MQS_CONSUME(u)                                                                   \
     {                                                                                    \
         const u32x4 va_ = ring_a[u], vb_ = ring_b[u];                                    \
-        const float xa_[4] = {__uint_as_float(va_.x), __uint_as_float(va_.y), __uint_as_float(va_.z),       \
-                              __uint_as_float(va_.w)};                                   \
-        const float xb_[4] = {__uint_as_float(vb_.x), __uint_as_float(vb_.y), __uint_as_float(vb_.z),       \
-                              __uint_as_float(vb_.w)};                                   \
-        _Pragma("unroll") for (int i = 0; i < 4; i++) nrm_a = fmaf(xa_[i], xa_[i], nrm_a);   \
-        _Pragma("unroll") for (int i = 0; i < 4; i++) nrm_b = fmaf(xb_[i], xb_[i], nrm_b);   \
-        nz_a |= va_.x | va_.y;                                                           \
-        nz_a |= va_.z | va_.w;                                                           \
-        nz_b |= vb_.x | vb_.y;                                                           \
-        nz_b |= vb_.z | vb_.w;                                                           \
-        const bf16x2 t0_ = __builtin_convertvector(f32x2{xa_[0], xa_[1]}, bf16x2);       \
-        const bf16x2 t1_ = __builtin_convertvector(f32x2{xa_[2], xa_[3]}, bf16x2);       \
-        const bf16x2 t2_ = __builtin_convertvector(f32x2{xb_[0], xb_[1]}, bf16x2);       \
-        const bf16x2 t3_ = __builtin_convertvector(f32x2{xb_[2], xb_[3]}, bf16x2);       \
-        *w_a = make_uint2(__builtin_bit_cast(uint32_t, t0_), __builtin_bit_cast(uint32_t, t1_)); \
-        *w_b = make_uint2(__builtin_bit_cast(uint32_t, t2_), __builtin_bit_cast(uint32_t, t3_)); \
-        __builtin_amdgcn_wave_barrier();                                                 \
-        const v4i32b bop_ = *r_op;                                                       \
-        __builtin_amdgcn_wave_barrier();                                                 \
-        const int qnext_ = lane + (cs + 1 == SS ? 0 : cs + 1) * (NB * 64);               \
-        _Pragma("unroll") for (int b = 0; b < NB; b++)                                   \
-        {                                                                                \
-            const v4i32b qc_ = qn[b];                                                    \
-            qn[b] = qimg[qnext_ + b * 64];                                               \
-            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qc_),              \
-                                                             __builtin_bit_cast(bf16x8, bop_), acc[b], 0, 0, 0); \
+        if constexpr (QBITS == 32) {                                                     \
+            const float xa_[4] = {__uint_as_float(va_.x), __uint_as_float(va_.y), __uint_as_float(va_.z),   \
+                                  __uint_as_float(va_.w)};                               \
+            const float xb_[4] = {__uint_as_float(vb_.x), __uint_as_float(vb_.y), __uint_as_float(vb_.z),   \
+                                  __uint_as_float(vb_.w)};                               \
+            _Pragma("unroll") for (int i = 0; i < 4; i++) nrm_a = fmaf(xa_[i], xa_[i], nrm_a);   \
+            _Pragma("unroll") for (int i = 0; i < 4; i++) nrm_b = fmaf(xb_[i], xb_[i], nrm_b);   \
+            nz_a |= va_.x | va_.y;                                                       \
+            nz_a |= va_.z | va_.w;                                                       \
+            nz_b |= vb_.x | vb_.y;                                                       \
+            nz_b |= vb_.z | vb_.w;                                                       \
+            const bf16x2 t0_ = __builtin_convertvector(f32x2{xa_[0], xa_[1]}, bf16x2);   \
+            const bf16x2 t1_ = __builtin_convertvector(f32x2{xa_[2], xa_[3]}, bf16x2);   \
+            const bf16x2 t2_ = __builtin_convertvector(f32x2{xb_[0], xb_[1]}, bf16x2);   \
+            const bf16x2 t3_ = __builtin_convertvector(f32x2{xb_[2], xb_[3]}, bf16x2);   \
+            *w_a = make_uint2(__builtin_bit_cast(uint32_t, t0_), __builtin_bit_cast(uint32_t, t1_)); \
+            *w_b = make_uint2(__builtin_bit_cast(uint32_t, t2_), __builtin_bit_cast(uint32_t, t3_)); \
+            __builtin_amdgcn_wave_barrier();                                             \
+            const v4i32b bop_ = *r_op;                                                   \
+            __builtin_amdgcn_wave_barrier();                                             \
+            const int qnext_ = lane + (cs + 1 == SS ? 0 : cs + 1) * (NB * 64);           \
+            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
+            {                                                                            \
+                const v4i32b qc_ = qn[b];                                                \
+                qn[b] = qimg[qnext_ + b * 64];                                           \
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qc_),          \
+                                                                 __builtin_bit_cast(bf16x8, bop_), acc[b], 0, 0, 0); \
+            }                                                                            \
+        } else {                                                                         \
+            const uint32_t wa_[4] = {va_.x, va_.y, va_.z, va_.w}, wb_[4] = {vb_.x, vb_.y, vb_.z, vb_.w};    \
+            const bool out_ = partial && cs == SS - 1 && past; /* read from the zero block: not part of the row */ \
+            uint32_t pa_[4], pb_[4];                                                     \
+            float sa_ = 0.f, sb_ = 0.f;                                                  \
+            _Pragma("unroll") for (int i = 0; i < 4; i++)                                \
+            {                                                                            \
+                const float a0_ = fmaf((float)(wa_[i] & 0xFFFFu), 2.0f, -65535.0f);      \
+                const float a1_ = fmaf((float)(wa_[i] >> 16), 2.0f, -65535.0f);          \
+                const float b0_ = fmaf((float)(wb_[i] & 0xFFFFu), 2.0f, -65535.0f);      \
+                const float b1_ = fmaf((float)(wb_[i] >> 16), 2.0f, -65535.0f);          \
+                sa_ = fmaf(a0_, a0_, sa_);                                               \
+                sa_ = fmaf(a1_, a1_, sa_);                                               \
+                sb_ = fmaf(b0_, b0_, sb_);                                               \
+                sb_ = fmaf(b1_, b1_, sb_);                                               \
+                pa_[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a0_, a1_}, bf16x2)); \
+                pb_[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{b0_, b1_}, bf16x2)); \
+            }                                                                            \
+            nrm_a += out_ ? 0.f : sa_;                                                   \
+            nrm_b += out_ ? 0.f : sb_;                                                   \
+            nz_a = nz_b = 1u; /* a decoded code is odd: never a zero row */              \
+            _Pragma("unroll") for (int h = 0; h < 2; h++)                                \
+            {                                                                            \
+                if ((ch >> 2) == h) {                                                    \
+                    *w16_a = make_uint4(pa_[0], pa_[1], pa_[2], pa_[3]);                 \
+                    *w16_b = make_uint4(pb_[0], pb_[1], pb_[2], pb_[3]);                 \
+                }                                                                        \
+                __builtin_amdgcn_wave_barrier();                                         \
+                const v4i32b bop_ = *r_op;                                               \
+                __builtin_amdgcn_wave_barrier();                                         \
+                const int kn_ = cs * 2 + h + 1;                                          \
+                const int qnext_ = lane + (kn_ == SS * 2 ? 0 : kn_) * (NB * 64);         \
+                _Pragma("unroll") for (int b = 0; b < NB; b++)                           \
+                {                                                                        \
+                    const v4i32b qc_ = qn[b];                                            \
+                    qn[b] = qimg[qnext_ + b * 64];                                       \
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qc_),      \
+                                                                     __builtin_bit_cast(bf16x8, bop_), acc[b], 0, 0, 0); \
+                }                                                                        \
+            }                                                                            \
         }                                                                                \
         if (++cs == SS) {                                                                \
             finish_tile(ctile);                                                          \
@@ -750,7 +802,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
     if (COLLECT) hit_flush(a, hb, lane);
 }
 
-#endif  // SZG_MQ_PART == 3
+#endif  // SZG_MQ_PART == 3 || 116
 
 #if SZG_MQ_PART == 1 || SZG_MQ_PART == 2
 // ---- exact integer shared sweep, 8-bit rows (part 1) and 4-bit rows (part 2) ---------------------------------------
@@ -1328,11 +1380,50 @@ __global__ __launch_bounds__(256) void cand_select_kernel(const uint64_t *cand_b
 // float32 -- one wave per (query, candidate), the query as float32 in LDS -- and the key inside the
 // candidate word is replaced, so that the selection and the certification that follow work with
 // float32 keys (bound: key_eps, mq branch).  grid (blocks, queries); 32-bit rows, any dim.
+// One 16-byte piece of a 32- or 16-bit row against the float32 query staged in LDS: 4 floats, or 8 codes decoded to
+// n = 2v - 65535.  COS: dot, norm and the zero-row bits; else the squared difference (into dot).
+template <bool COS>
+__device__ __forceinline__ void rescore_piece(const uint8_t *row, const float *qf, int piece, int row_bits, float &dot,
+                                              float &nrm, uint32_t &nz)
+{
+    const uint4 w = reinterpret_cast<const uint4 *>(row)[piece];
+    float x[8];
+    int n;
+    if (row_bits == 16) {
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            x[2 * i] = fmaf((float)(ww[i] & 0xFFFFu), 2.0f, -65535.0f);
+            x[2 * i + 1] = fmaf((float)(ww[i] >> 16), 2.0f, -65535.0f);
+        }
+        n = 8;
+        nz |= 1u;
+    } else {
+        x[0] = __uint_as_float(w.x); x[1] = __uint_as_float(w.y); x[2] = __uint_as_float(w.z); x[3] = __uint_as_float(w.w);
+        x[4] = x[5] = x[6] = x[7] = 0.f;
+        n = 4;
+        nz |= (w.x | w.y | w.z | w.w) & 0x7FFFFFFFu;
+    }
+    const float *y = qf + (size_t)piece * n;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i < n) {
+            if (COS) {
+                dot = fmaf(x[i], y[i], dot);
+                nrm = fmaf(x[i], x[i], nrm);
+            } else {
+                const float d = x[i] - y[i];
+                dot = fmaf(d, d, dot);
+            }
+        }
+    }
+}
+
 template <int METRIC>
 __global__ __launch_bounds__(256) void cand_rescore_kernel(const uint8_t *rows, uint32_t pitch, int dim,
                                                            const double *q64, const double *qscale,
                                                            uint64_t *cand_buf, const uint32_t *cand_count,
-                                                           uint32_t cand_cap)
+                                                           uint32_t cand_cap, int row_bits)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     float *qf = reinterpret_cast<float *>(smem);
@@ -1340,27 +1431,18 @@ __global__ __launch_bounds__(256) void cand_rescore_kernel(const uint8_t *rows, 
     const int q = blockIdx.y;
     const uint32_t n = min(cand_count[q * kCandCountStride], cand_cap);
     const double sc = qscale[q];
-    const int d4 = (dim + 3) >> 2;  // whole 16-byte pieces: the row's padding is stored as zeros, the query's staged as zeros
-    for (int i = tid; i < 4 * d4; i += blockDim.x) qf[i] = i < dim ? (float)(q64[(size_t)q * dim + i] * sc) : 0.0f;
+    // whole 16-byte pieces: a 32-bit row's padding is stored as zeros, the query's staged as zeros (16-bit rows come
+    // here with whole pieces only)
+    const int epp = row_bits == 16 ? 8 : 4, pieces = (dim + epp - 1) / epp;
+    for (int i = tid; i < epp * pieces; i += blockDim.x) qf[i] = i < dim ? (float)(q64[(size_t)q * dim + i] * sc) : 0.0f;
     __syncthreads();
-    const float4 *qf4 = reinterpret_cast<const float4 *>(qf);
     uint64_t *cb = cand_buf + (size_t)q * cand_cap;
     for (uint32_t ci = blockIdx.x * 4 + wave; ci < n; ci += gridDim.x * 4) {
         const uint32_t row = (uint32_t)cb[ci];
-        const float4 *rp = reinterpret_cast<const float4 *>(rows + (size_t)row * pitch);
+        const uint8_t *rp = rows + (size_t)row * pitch;
         float dot = 0.f, nrm = 0.f;
         uint32_t nz = 0;
-        for (int i = lane; i < d4; i += 64) {
-            const float4 x = rp[i], y = qf4[i];
-            if (METRIC == kCosine) {
-                dot = fmaf(x.x, y.x, dot); dot = fmaf(x.y, y.y, dot); dot = fmaf(x.z, y.z, dot); dot = fmaf(x.w, y.w, dot);
-                nrm = fmaf(x.x, x.x, nrm); nrm = fmaf(x.y, x.y, nrm); nrm = fmaf(x.z, x.z, nrm); nrm = fmaf(x.w, x.w, nrm);
-                nz |= (__float_as_uint(x.x) | __float_as_uint(x.y) | __float_as_uint(x.z) | __float_as_uint(x.w)) & 0x7FFFFFFFu;
-            } else {
-                const float a0 = x.x - y.x, a1 = x.y - y.y, a2 = x.z - y.z, a3 = x.w - y.w;
-                dot = fmaf(a0, a0, dot); dot = fmaf(a1, a1, dot); dot = fmaf(a2, a2, dot); dot = fmaf(a3, a3, dot);
-            }
-        }
+        for (int i = lane; i < pieces; i += 64) rescore_piece<METRIC == kCosine>(rp, qf, i, row_bits, dot, nrm, nz);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             dot += __shfl_xor(dot, o);
@@ -1495,7 +1577,7 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
                                                                      const double *qnorm2, const uint64_t *cand_buf,
                                                                      uint32_t *cand_count, uint32_t cand_cap, int kp,
                                                                      const uint64_t *sent, int n_sent, uint64_t *lists,
-                                                                     float *band_edge)
+                                                                     float *band_edge, int row_bits)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1514,7 +1596,8 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
     for (uint32_t i = tid; i < n; i += kRefineThreads) cand[i] = src[i];
     if (MODE > 0) {
         const double sc = qscale[q];
-        for (int i = tid; i < 4 * ((dim + 3) >> 2); i += kRefineThreads)
+        const int epp0 = row_bits == 16 ? 8 : 4;
+        for (int i = tid; i < epp0 * ((dim + epp0 - 1) / epp0); i += kRefineThreads)
             qf[i] = i < dim ? (float)(q64[(size_t)q * dim + i] * sc) : 0.0f;  // (padding: zeros, as in the rows)
     }
     if (tid == 0) n_band = 0;
@@ -1537,7 +1620,7 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
     float edge = 3.0e38f;  // fewer than kp candidates: everything collected is in the band
     if (kth != kInvalidCand) {
         const float t = key_from_ordered((uint32_t)(kth >> 32));
-        const float c = 1.01f * 0x1p-8f, nu = ((float)dim + 16.0f) * 0x1p-24f;
+        const float c = 1.01f * 0x1p-7f, nu = ((float)dim + 16.0f) * 0x1p-24f;  // key_eps (scan_query.cpp), bfloat16 branch
         float eps;
         if (MODE == 1) {
             eps = c + 4.0f * nu + 1e-6f;
@@ -1564,24 +1647,13 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
         return;
     }
     // float32 keys for the band: one wave per candidate
-    const float4 *qf4 = reinterpret_cast<const float4 *>(qf);
-    const int d4 = (dim + 3) >> 2;
+    const int epp = row_bits == 16 ? 8 : 4, pieces = (dim + epp - 1) / epp;
     for (uint32_t ci = wave; ci < nb; ci += NW) {
         const uint32_t row = (uint32_t)band[ci];
-        const float4 *rp = reinterpret_cast<const float4 *>(rows + (size_t)row * pitch);
+        const uint8_t *rp = rows + (size_t)row * pitch;
         float dot = 0.f, nrm = 0.f;
         uint32_t nz = 0;
-        for (int i = lane; i < d4; i += 64) {
-            const float4 x = rp[i], y = qf4[i];
-            if (MODE == 1) {
-                dot = fmaf(x.x, y.x, dot); dot = fmaf(x.y, y.y, dot); dot = fmaf(x.z, y.z, dot); dot = fmaf(x.w, y.w, dot);
-                nrm = fmaf(x.x, x.x, nrm); nrm = fmaf(x.y, x.y, nrm); nrm = fmaf(x.z, x.z, nrm); nrm = fmaf(x.w, x.w, nrm);
-                nz |= (__float_as_uint(x.x) | __float_as_uint(x.y) | __float_as_uint(x.z) | __float_as_uint(x.w)) & 0x7FFFFFFFu;
-            } else {
-                const float a0 = x.x - y.x, a1 = x.y - y.y, a2 = x.z - y.z, a3 = x.w - y.w;
-                dot = fmaf(a0, a0, dot); dot = fmaf(a1, a1, dot); dot = fmaf(a2, a2, dot); dot = fmaf(a3, a3, dot);
-            }
-        }
+        for (int i = lane; i < pieces; i += 64) rescore_piece<MODE == 1>(rp, qf, i, row_bits, dot, nrm, nz);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             dot += __shfl_xor(dot, o);
@@ -1637,16 +1709,17 @@ hipError_t launch_cand_select(const uint64_t *cand_buf, const uint32_t *cand_cou
 
 hipError_t launch_cand_rescore(int metric, const uint8_t *rows, uint32_t pitch, int dim, const double *q64,
                                const double *qscale, uint64_t *cand_buf, const uint32_t *cand_count,
-                               uint32_t cand_cap, int n_queries, hipStream_t stream)
+                               uint32_t cand_cap, int n_queries, int row_bits, hipStream_t stream)
 {
+    if (row_bits != 32 && !(row_bits == 16 && dim % 8 == 0)) return hipErrorInvalidValue;
     const dim3 grid(SZG_RESCORE_BLOCKS, n_queries);  // x 4 waves: one candidate per wave and trip
-    const size_t lds = (size_t)((dim + 3) & ~3) * sizeof(float);
+    const size_t lds = (size_t)((dim + 7) & ~7) * sizeof(float);
     if (metric == kCosine)
         hipLaunchKernelGGL(cand_rescore_kernel<kCosine>, grid, dim3(256), lds, stream, rows, pitch, dim, q64, qscale,
-                           cand_buf, cand_count, cand_cap);
+                           cand_buf, cand_count, cand_cap, row_bits);
     else
         hipLaunchKernelGGL(cand_rescore_kernel<kEuclidean>, grid, dim3(256), lds, stream, rows, pitch, dim, q64,
-                           qscale, cand_buf, cand_count, cand_cap);
+                           qscale, cand_buf, cand_count, cand_cap, row_bits);
     return hipGetLastError();
 }
 
@@ -1658,16 +1731,17 @@ bool cand_refine_applies(int kp, uint32_t cand_cap, int dim, bool rescore)
 hipError_t launch_cand_refine(int mode, const uint8_t *rows, uint32_t pitch, int dim, const double *q64,
                               const double *qscale, const double *qnorm2, const uint64_t *cand_buf, uint32_t *cand_count,
                               uint32_t cand_cap, int kp, int n_queries, const uint64_t *sent, int n_sent,
-                              uint64_t *lists, float *band_edge, hipStream_t stream)
+                              uint64_t *lists, float *band_edge, int row_bits, hipStream_t stream)
 {
     if (!cand_refine_applies(kp, cand_cap, dim, mode > 0)) return hipErrorInvalidValue;
+    if (mode > 0 && row_bits != 32 && !(row_bits == 16 && dim % 8 == 0)) return hipErrorInvalidValue;
     const size_t lds = ((size_t)kRefineMaxCands + (size_t)(kRefineThreads / 64) * kp + kp + kRefineMaxBand) * sizeof(uint64_t) +
-                       (mode > 0 ? (size_t)((dim + 3) & ~3) * sizeof(float) : 0);
+                       (mode > 0 ? (size_t)((dim + 7) & ~7) * sizeof(float) : 0);
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(n_queries), dim3(kRefineThreads), lds, stream, rows, pitch, dim, q64, qscale, qnorm2,
-                           cand_buf, cand_count, cand_cap, kp, sent, n_sent, lists, band_edge);
+                           cand_buf, cand_count, cand_cap, kp, sent, n_sent, lists, band_edge, row_bits);
         return hipGetLastError();
     };
     if (mode == 0) return go(&cand_refine_kernel<0>);
@@ -1679,7 +1753,7 @@ size_t mq_lds_bytes(int qbits, int r16, int nb) { return (size_t)r16 * nb * (128
 
 #endif
 
-#if SZG_MQ_PART >= 4
+#if SZG_MQ_PART >= 4 && SZG_MQ_PART < 100
 namespace {
 template <int NB, int QBITS, int METRIC, bool COLLECT, bool FAST>
 hipError_t launch_mq_score_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
@@ -1724,7 +1798,7 @@ hipError_t SZG_CAT(launch_mq_score_q, SZG_MQ_PART)(const MqArgs &a, int nb, int 
 {
     return launch_mq_score_q<SZG_MQ_PART>(a, nb, grid, lds, stream);
 }
-#endif  // SZG_MQ_PART >= 4
+#endif  // SZG_MQ_PART >= 4 (float32 sweeps)
 
 #if SZG_MQ_PART == 0
 hipError_t launch_mq_score_q4(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
@@ -1753,16 +1827,23 @@ size_t mq_i8_lds_bytes(int row_bits, int r16, int nb, int groups)
 {   // per group: image + constants + thresholds; + the 12 waves' hit buffers
     return (size_t)groups * (mq_i8_image_bytes(row_bits, r16, nb) + 4 * 48 * sizeof(float)) + (size_t)SZG_MQ8_WAVES * 64 * 9;
 }
-size_t mq_bf16_image_bytes(int r16, int nb) { return (size_t)((r16 + 7) / 8) * nb * 1024; }
-size_t mq_bf16_lds_bytes(int r16, int nb)
+size_t mq_bf16_image_bytes(int row_bits, int r16, int nb)
+{   // a KiB per 32-element K-step and query block; a 128-byte step of a row holds one (32-bit rows) or two (16-bit)
+    return (size_t)((r16 + 7) / 8) * (row_bits == 16 ? 2 : 1) * nb * 1024;
+}
+size_t mq_bf16_lds_bytes(int row_bits, int r16, int nb)
 {   // + thresholds, |q|^2 table and the waves' hit buffers
-    return mq_bf16_image_bytes(r16, nb) + 2 * kMqMaxQueries * sizeof(float) + (size_t)SZG_MQB_WAVES * kHitCap * 9 +
+    return mq_bf16_image_bytes(row_bits, r16, nb) + 2 * kMqMaxQueries * sizeof(float) + (size_t)SZG_MQB_WAVES * kHitCap * 9 +
            (size_t)SZG_MQB_WAVES * 1024;  // + a KiB of operand staging per wave
 }
 hipError_t launch_mq_score_bf16_rows32(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
-hipError_t launch_mq_score_bf16(const MqArgs &a, int nb, int grid, hipStream_t stream)
+hipError_t launch_mq_score_bf16_rows16(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
+hipError_t launch_mq_score_bf16(int row_bits, const MqArgs &a, int nb, int grid, hipStream_t stream)
 {
-    return launch_mq_score_bf16_rows32(a, nb, grid, mq_bf16_lds_bytes(a.r16, nb), stream);
+    const size_t lds = mq_bf16_lds_bytes(row_bits, a.r16, nb);
+    if (row_bits == 32) return launch_mq_score_bf16_rows32(a, nb, grid, lds, stream);
+    if (row_bits == 16) return launch_mq_score_bf16_rows16(a, nb, grid, lds, stream);
+    return hipErrorInvalidValue;
 }
 hipError_t launch_mq_score_i8_rows8(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
 hipError_t launch_mq_score_i8_rows4(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
@@ -1775,12 +1856,13 @@ hipError_t launch_mq_score_i8(int row_bits, const MqArgs &a, int nb, int grid, h
 }
 #endif  // SZG_MQ_PART == 0
 
-#if SZG_MQ_PART == 3
+#if SZG_MQ_PART == 3 || SZG_MQ_PART == 116
 namespace {
+constexpr int kBfRowBits = SZG_MQ_PART == 3 ? 32 : 16;
 template <int NB, int METRIC, bool COLLECT>
 hipError_t launch_mq_score_bf16_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
-    auto *kern = &mq_score_bf16s_kernel<NB, METRIC, COLLECT>;
+    auto *kern = &mq_score_bf16s_kernel<NB, METRIC, COLLECT, kBfRowBits>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -1799,9 +1881,14 @@ hipError_t launch_mq_score_bf16_m(const MqArgs &a, int grid, size_t lds, hipStre
 }
 }  // namespace
 
+#if SZG_MQ_PART == 3
 hipError_t launch_mq_score_bf16_rows32(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
+#else
+hipError_t launch_mq_score_bf16_rows16(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
+#endif
 {
     if (a.tiled || a.n_rows == 0 || !a.zero16) return hipErrorInvalidValue;
+    if (kBfRowBits == 16 && a.dim % 8 != 0) return hipErrorInvalidValue;
     switch (nb) {
     case 1: return launch_mq_score_bf16_m<1>(a, grid, lds, stream);
     case 2: return launch_mq_score_bf16_m<2>(a, grid, lds, stream);
@@ -1812,7 +1899,7 @@ hipError_t launch_mq_score_bf16_rows32(const MqArgs &a, int nb, int grid, size_t
     default: return hipErrorInvalidValue;
     }
 }
-#endif  // SZG_MQ_PART == 3
+#endif  // SZG_MQ_PART == 3 || 116
 
 #if SZG_MQ_PART == 1 || SZG_MQ_PART == 2
 namespace {

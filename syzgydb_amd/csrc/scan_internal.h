@@ -333,7 +333,7 @@ struct szg_index {
                               // against its own bound and re-ranked in float64 like every other path
     int mq_overlap = 1;       // bfloat16 sweeps: a batch's threshold pass and its post-processing run on the context's
                               // stream beside the neighbouring batches' sweeps (the sweep is a bare stream of the rows)
-    int mq_bf16_slack = 118;  // candidates kept beyond k by a bfloat16 sweep (its band holds more rows)
+    int mq_bf16_slack = 246;  // candidates kept beyond k by a bfloat16 sweep in the score-matrix form (its band holds more rows)
     int mq_tail_overlap = 0;  // shared sweep: post-processing of a batch beside the next batch's sweep
     int mq_min = 2;           // smallest batch worth a shared sweep (measured: 2 queries already break even)
     int mq_blocks_max = 6;    // query blocks of 16 per shared sweep (LDS image permitting; 3 at most for the

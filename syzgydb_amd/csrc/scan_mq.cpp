@@ -15,7 +15,7 @@ void build_image_bf16(const szg_index *ix, Ctx *c, int nq, int nb)
         const double *src = c->h_q64 + (size_t)q * dim;
         const double m1 = c->meta[q].m1;
         double scale = m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0;
-        if (ix->metric != SZG_COSINE) scale = 1.0;
+        if (ix->metric != SZG_COSINE) scale = ix->bits == 16 ? 65535.0 : 1.0;  // maxInt * q against rows decoded to n
         const int b = q / 16, qi = q % 16;
         // runs of 8 consecutive elements are contiguous in the image (one lane's 16 bytes)
         for (int e0 = 0; e0 < dim; e0 += 8) {
@@ -131,7 +131,7 @@ MqPlan mq_plan(const szg_index *ix, const Shard *sh, int kp, int kp_wide, int nq
     p.bf16 = mq_uses_bf16(ix);
     p.groups = p.i8 ? (nq + 16 * nb - 1) / (16 * nb) : 1;
     p.group_stride = p.i8 ? ((szg::mq_i8_image_bytes(ix->bits, r16, nb) + 3 * 48 * sizeof(float) + 255) & ~(size_t)255) : 0;
-    p.img = p.bf16 ? szg::mq_bf16_image_bytes(r16, nb) : p.i8 ? p.group_stride * p.groups : szg::mq_lds_bytes(ix->bits, r16, nb);
+    p.img = p.bf16 ? szg::mq_bf16_image_bytes(ix->bits, r16, nb) : p.i8 ? p.group_stride * p.groups : szg::mq_lds_bytes(ix->bits, r16, nb);
     const uint64_t hits = std::max<uint64_t>((uint64_t)ix->mq_hits, 16ull * kp);
     p.prefix = ((sh->n_rows * (uint64_t)kp + hits - 1) / hits + 15) & ~15ull;
     p.prefix = std::max<uint64_t>(p.prefix, 16ull * kp);
@@ -177,7 +177,8 @@ int mq_buffers(szg_index *ix, Ctx *c, const MqPlan &p, int nq, int n_out)
         if (!c->d_qscale) HIPCHK(hipMalloc((void **)&c->d_qscale, 256 * sizeof(double)));
         for (int q = 0; q < nq; q++) {
             const double m1 = c->meta[q].m1;
-            c->h_qscale[q] = ix->metric == SZG_COSINE ? (m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0) : 1.0;
+            c->h_qscale[q] = ix->metric == SZG_COSINE ? (m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0)
+                                                      : (ix->bits == 16 ? 65535.0 : 1.0);  // euclid: the prepared query, maxInt * q
             c->h_qscale[128 + q] = c->meta[q].qnorm2;
         }
         HIPCHK(hipMemcpyAsync(c->d_qscale, c->h_qscale, sizeof(double) * 256, hipMemcpyHostToDevice, c->stream));
@@ -258,7 +259,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
     const uint64_t *allow = has_allow ? c->d_allow : nullptr;
     const uint32_t words = (uint32_t)shard_words(sh);
     auto launch_score = [&](const szg::MqArgs &x, hipStream_t s2) -> hipError_t {
-        if (p.bf16) return szg::launch_mq_score_bf16(x, nb, sh->cu_count, s2);
+        if (p.bf16) return szg::launch_mq_score_bf16(ix->bits, x, nb, sh->cu_count, s2);
         return p.i8 ? szg::launch_mq_score_i8(ix->bits, x, nb, sh->cu_count, s2)
                     : szg::launch_mq_score(ix->bits, x, nb, sh->cu_count, s2);
     };
@@ -314,11 +315,11 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
             HIPCHK(szg::launch_cand_refine(mode, sh->rows, ix->pitch, ix->dim, c->d_q64, c->d_qscale,
                                            c->d_qscale ? c->d_qscale + 128 : nullptr, c->d_cand, c->d_cand_count,
                                            p.cand_cap, kp, nq, merge_sent ? c->d_sent : nullptr, merge_sent ? n_sent : 0,
-                                           c->d_lists_a, c->d_thr + 128, tail));
+                                           c->d_lists_a, c->d_thr + 128, ix->bits, tail));
         } else if (p.fused) {
             if (p.stage2)
                 HIPCHK(szg::launch_cand_rescore(ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64, c->d_qscale, c->d_cand,
-                                                c->d_cand_count, p.cand_cap, nq, tail));
+                                                c->d_cand_count, p.cand_cap, nq, ix->bits, tail));
             HIPCHK(szg::launch_cand_select(c->d_cand, c->d_cand_count, p.cand_cap, kp, nq, c->d_lists_a, tail));
         } else {
             // score matrix of every row -> per-query sorted lists of kp -> merged

@@ -165,12 +165,16 @@ double key_eps(const szg_index *ix, double key, const QMeta &m)
         // escalates more often.
         const double u = 0x1p-24, n = (double)ix->dim + 16.0;
         if (m.mq_bf16) {
-            // bfloat16 sweep: each operand is rounded to 8 significant bits (relative error <= 2^-9,
-            // the query once more from float32), the products are exact in float32 and summed by the
-            // matrix core in float32.  |sum bf(x_i) bf(g_i) - sum x_i g_i| <= c |x| |g| (Cauchy-Schwarz)
-            // with c = (1 + 2^-9)^2 (1 + 2^-24) - 1 < 1.01 * 2^-8; the float32 part of the bound is
-            // doubled (the accumulation order and rounding of the matrix core are its own).
-            const double c = 1.01 * 0x1p-8;
+            // bfloat16 sweep: each operand is rounded to 8 significant bits -- a bfloat16 keeps 7 fraction bits, so the
+            // spacing at 1 is 2^-7 and round-to-nearest moves a value by at most 2^-8 of itself (the query once more
+            // from float32) -- the products are exact in float32 and summed by the matrix core in float32.
+            // |sum bf(x_i) bf(g_i) - sum x_i g_i| <= c |x| |g| (Cauchy-Schwarz) with
+            // c = (1 + 2^-8)^2 (1 + 2^-24) - 1 < 1.01 * 2^-7; the float32 part of the bound is doubled (the
+            // accumulation order and rounding of the matrix core are its own).  (Rounds 2-3 had 2^-9 per operand
+            // here, i.e. half this band: a 2-dimensional corpus far from the origin, where both elements can round
+            // the same way, showed a key 0.0044 off -- scripts/fuzz_gpu.py seed 311.  At >= 16 dimensions the
+            // errors never lined up, which is why nothing had caught it.)
+            const double c = 1.01 * 0x1p-7;
             if (ix->metric == SZG_COSINE) return c + 4.0 * n * u + 1e-6;
             // euclid: the key moves by 2 c |x| |g|, and |x| <= |g| + d with d^2 <= key + 2 c |x| |g|
             // gives |x| <= 1.1 |g| + sqrt(key) for this c; the last term keeps key - eps(key) monotone
@@ -219,10 +223,12 @@ double key_eps(const szg_index *ix, double key, const QMeta &m)
 // ---- multi-query sweep (32-bit rows, cosine): B queries share one pass ------------
 
 bool mq_uses_i8(const szg_index *ix) { return (ix->bits == 8 || ix->bits == 4) && ix->mq_i8; }
-// 32-bit rows (any dimension; not the experimental tiled layout): the bfloat16 sweep
+// the bfloat16 sweep: 32-bit rows of any dimension, 16-bit rows of whole 16-byte pieces (a padding code would decode
+// to -65535 inside the row norm); not the experimental tiled layout
 bool mq_uses_bf16(const szg_index *ix)
 {
-    return ix->bits == 32 && ix->mq_bf16 && !ix->layout.tiled;
+    if (!ix->mq_bf16 || ix->layout.tiled) return false;
+    return ix->bits == 32 || (ix->bits == 16 && ix->dim % 8 == 0);
 }
 
 // round to nearest even, as v_cvt_pk_bf16_f32 does (NaN stays NaN)
@@ -268,7 +274,7 @@ int mq_blocks(const szg_index *ix, int nq)
     const bool bf16 = mq_uses_bf16(ix);
     int nb = std::min((nq + 15) / 16, std::min(ix->mq_blocks_max, bf16 ? 6 : 3));
     auto fits = [&](int n) {  // the image (+ tables, hit buffers, staging) must fit LDS
-        if (bf16) return szg::mq_bf16_lds_bytes(ix->map.r16, n) <= 160u * 1024u;
+        if (bf16) return szg::mq_bf16_lds_bytes(ix->bits, ix->map.r16, n) <= 160u * 1024u;
         return (mq_uses_i8(ix) ? szg::mq_i8_lds_bytes(ix->bits, ix->map.r16, n)
                                : szg::mq_lds_bytes(ix->bits, ix->map.r16, n)) <= 150u * 1024u;
     };

@@ -238,6 +238,58 @@ def test_bf16_sweep_matches_oracle(metric, dim, n):
         assert ix.stats()["mq_bf16_sweeps"] == 0
 
 
+@pytest.mark.parametrize("metric", [SZG_COSINE, SZG_EUCLIDEAN])
+@pytest.mark.parametrize("dim,n", [(768, 3000), (384, 4000), (64, 6000), (8, 5000), (40, 4000), (72, 3000), (1000, 2500),
+                                   (1536, 2000)])
+def test_bf16_sweep_16bit_rows(metric, dim, n):
+    """16-bit rows of whole 16-byte pieces go through the bfloat16 sweep too (codes decoded to n = 2v - 65535 on the
+    fly, two K-steps per 128-byte step, short last steps): answers identical to the reference loop's, with and
+    without a filter; other dimensions keep the float32 sweep."""
+    rows = orc.synth_rows(1900 + dim, 0, n, dim, 16)
+    Q = orc.synth_vectors(1901 + dim, 0, 50, dim)
+    allow = np.arange(n) % 5 != 1
+    with ScanIndex(dim, 16, metric) as ix:
+        ix.load(rows)
+        check(ix, rows, dim, Q, 10, bits=16, metric=metric)
+        st = ix.stats()
+        if DEFAULT_TUNABLES:
+            assert st["mq_bf16_sweeps"] == st["mq_launches"] >= 1 and st["mq_queries"] == 50
+            assert st["mq_fallbacks"] == 0
+        check(ix, rows, dim, Q[:20], 7, allow=allow, bits=16, metric=metric)
+        ix.set_option("mq_bf16", 0)
+        ix.reset_stats()
+        check(ix, rows, dim, Q[:20], 10, bits=16, metric=metric)
+        assert ix.stats()["mq_bf16_sweeps"] == 0
+    if dim == 40:  # 36 dims: 4.5 pieces -- the float32 sweep
+        rows = orc.synth_rows(1950, 0, n, 36, 16)
+        with ScanIndex(36, 16, metric) as ix:
+            ix.load(rows)
+            check(ix, rows, 36, orc.synth_vectors(1951, 0, 40, 36), 10, bits=16, metric=metric)
+            assert ix.stats()["mq_bf16_sweeps"] == 0 and ix.stats()["mq_queries"] == 40
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("dim", [1, 2, 3, 5, 16])
+def test_bf16_sweep_few_dims_far_from_origin(dim, fused):
+    """Every row and query within a few degrees of one direction, 1..16 dimensions: with so few elements their
+    bfloat16 roundings can all point the same way, and the sweep's key is off by up to 2^-7 (two operands at 2^-8
+    each) -- the certification band must be that wide (scripts/fuzz_gpu.py seed 311 found it at half)."""
+    n = 5000
+    for seed in range(6):
+        rng = np.random.default_rng(7000 + 10 * dim + seed)
+        vec = rng.uniform(-1, 1, (n, dim)) * 1e3 + 5e3
+        Q = rng.uniform(-1, 1, (8, dim)) * 1e3 + 5e3
+        rows = orc.encode_rows(vec, 32)
+        with ScanIndex(dim, 32, SZG_COSINE) as ix:
+            ix.load(rows)
+            ix.set_option("mq_fused", fused)
+            ix.set_option("mq_min", 8)
+            check(ix, rows, dim, Q, 1)
+            check(ix, rows, dim, Q, 10, allow=rng.random(n) < 0.5)
+            if DEFAULT_TUNABLES:
+                assert ix.stats()["mq_bf16_sweeps"] >= 2
+
+
 def test_bf16_sweep_near_duplicates_and_scales():
     """Rows that bfloat16 cannot tell apart (relative differences of 1e-4 .. 1e-7, far below 2^-8), rows
     scaled by 1e+-18 (the same direction: equal cosine keys, the norms near the float32 range ends) and
