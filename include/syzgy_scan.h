@@ -276,7 +276,7 @@ typedef struct szg_stats {
     double host_enqueue_us;
     uint64_t sketch_queries;   /* top-k queries answered through the 8-bit sketch pre-pass ("sketch" option) */
     uint64_t sketch_fallbacks; /* ... that it could not settle and handed to the full-precision path */
-    uint64_t mq_bf16_sweeps;   /* shared sweeps that ran on the bfloat16 matrix cores (32-bit rows; their candidates
+    uint64_t mq_bf16_sweeps;   /* shared sweeps that ran on the bfloat16 matrix cores (32- / 16-bit rows; their candidates
                                   are re-scored in float32 and re-ranked in float64 like every other path's) */
 } szg_stats;
 
@@ -327,15 +327,16 @@ int szg_reset_stats(szg_index *ix);
  *                             the image does not fit LDS); 0 = one sweep per query
  *     mq_i8               1   8- and 4-bit rows: exact integer sweep on the int8 matrix cores
  *                             (v_mfma_i32_16x16x64_i8); 0 = the float32 MFMA sweep
- *     mq_bf16             1   32-bit rows of whole 64-byte steps (dim % 16 == 0): the sweep multiplies
- *                             bfloat16 roundings of rows and queries (v_mfma_f32_16x16x32_bf16, 16 x the
- *                             float32 matrix rate: the sweep becomes a plain stream of the rows), its
+ *     mq_bf16             1   32-bit rows (any dimension) and 16-bit rows of whole 16-byte pieces
+ *                             (dim % 8 == 0; decoded on the fly): the sweep multiplies bfloat16
+ *                             roundings of rows and queries (v_mfma_f32_16x16x32_bf16, 16 x the float32
+ *                             matrix rate: the sweep becomes a plain stream of the rows), its
  *                             candidates are scored again in float32 before the selection, and the
- *                             certification uses the bfloat16 bound (2^-8 |x||q|) for the rows it left
- *                             out; 0 = the float32 MFMA sweep
+ *                             certification uses the bfloat16 bound (2^-7 |x||q|: 2^-8 per operand)
+ *                             for the rows it left out; 0 = the float32 MFMA sweep
  *     mq_overlap          1   bfloat16 sweeps: a batch's threshold pass and post-processing run on the
  *                             context's stream beside the neighbouring batches' sweeps (+13 % queries/s)
- *     mq_bf16_slack       118 candidates kept beyond k where the lists hold bfloat16 keys themselves
+ *     mq_bf16_slack       246 candidates kept beyond k where the lists hold bfloat16 keys themselves
  *                             (score-matrix form: small shards, overflow reruns)
  *     mq_i8_groups        2   int8 sweeps: one launch walks the passes of up to two groups of 48 queries
  *                             (both LDS images staged up front); 1 = one group per launch
