@@ -349,6 +349,9 @@ int szg_reset_stats(szg_index *ix);
  *                             per shared sweep, by whichever caller finds no batch in flight;
  *                             concurrent szg_search_radius callers likewise share query-major
  *                             collect launches (16 sweeps per launch, each with its own radius)
+ *     finish_thread       1   a call of three or more shared-sweep batches assembles its finished
+ *                             batches (waits, certification, output) on a second host thread while
+ *                             the caller's prepares and enqueues the next ones; 0 = one thread
  *   tests / tuning hooks: force_escalate, lanes_per_row
  */
 int szg_set_option(szg_index *ix, const char *name, int64_t value);

@@ -45,7 +45,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 done
 
 echo "[mq] shared sweeps: kernel stats + counters" | tee -a $out/progress.log
-for b in 32 8 4; do
+for b in 32 16 8 4; do
   rm -rf /tmp/prof_mq$b
   SZG_BITS=$b rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mq$b -- python3 $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /tmp/mq.log 2>&1
   one /tmp/prof_mq$b "*kernel_stats.csv" $out/${tag}_mq_${b}bit_kernel_stats.csv
@@ -54,9 +54,10 @@ done
 rm -rf /tmp/prof_mqf
 SZG_BITS=32 SZG_OPTS=mq_bf16=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mqf -- python3 $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /tmp/mq.log 2>&1
 one /tmp/prof_mqf "*kernel_stats.csv" $out/${tag}_mq_32bit_f32mfma_kernel_stats.csv
-SZG_BITS=8 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_i8_kernel<3, 1, true" $out/${tag}_pmc_mq_i8_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
-SZG_BITS=4 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_i8_kernel<3, 1, true" $out/${tag}_pmc_mq_i8_4bit_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
+SZG_BITS=8 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_i8s_kernel<3, 1" $out/${tag}_pmc_mq_i8_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
+SZG_BITS=4 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_i8s_kernel<3, 1" $out/${tag}_pmc_mq_i8_4bit_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
 SZG_BITS=32 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_bf16s_kernel<6, 1, true" $out/${tag}_pmc_mq_bf16_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
+SZG_BITS=16 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_bf16s_kernel<6, 1, true" $out/${tag}_pmc_mq_bf16_16bit_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
 SZG_BITS=32 SZG_OPTS=mq_bf16=0 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_kernel<3, 32, 1, true" $out/${tag}_pmc_mq_f32_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
 python3 $GRAFT_REPO_ROOT/scripts/make_traffic.py $out $tag > $out/traffic.json || true
 echo done | tee -a $out/progress.log

@@ -20,7 +20,8 @@ OPTS = [("queries_per_launch", [1, 3, 16]), ("multi_query", [0, 1]), ("mq_fused"
         ("mq_min", [2, 8]), ("mq_blocks", [1, 2, 3]), ("slack", [0, 16, 40]), ("mq_bf16", [0, 1, 1]),
         ("mq_overlap", [0, 1]), ("mq_bf16_slack", [0, 118, 246]), ("mq_hits", [64, 1024]), ("sketch", [0, 1, 1]),
         ("sketch_extra", [0, 30]), ("sketch_min_rows", [1, 1, 4096]), ("mq_i8_groups", [1, 2]),
-        ("mq_refine", [0, 1, 1]), ("first_batch", [0, 1, 4]), ("mask_dense", [0, 1]), ("coalesce", [0, 1])]
+        ("mq_refine", [0, 1, 1]), ("first_batch", [0, 1, 4]), ("mask_dense", [0, 1]), ("coalesce", [0, 1]),
+        ("finish_thread", [0, 1, 1])]
 
 
 def same(got_r, got_d, want_r, want_d):
@@ -43,6 +44,8 @@ while time.time() < t_end:
     if dim * n > 4_000_000:
         n = max(1, 4_000_000 // dim)
     nq = int(rng.choice([1, 2, 7, 8, 9, 16, 17, 33, 50]))
+    if rng.random() < 0.04 and dim * n <= 400_000:   # a long call: 3+ shared-sweep batches (the finisher thread)
+        nq = int(rng.choice([200, 330]))
     k = int(rng.choice([1, 2, 10, 11, 50, 100, 300, 5000]))
     kind = int(rng.integers(0, 8))
     vec = rng.uniform(-1, 1, (n, dim))

@@ -15,6 +15,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -26,6 +27,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace szgi {
@@ -316,6 +318,8 @@ struct szg_index {
     int query_batch = 16;     // queries per scan launch
     int first_batch = 4;      // ... of a call's first launch (0 = query_batch): the card starts sooner
     int short_call = 32;      // calls of up to this many one-sweep queries are ONE batch on the scan stream (0 = off)
+    int finish_thread = 1;    // shared-sweep calls of 3+ batches: a second host thread assembles the finished batches
+                              // while the caller's prepares and enqueues the next ones (0 = one thread does both)
     int shape_kernels = 1;    // use the row-shape-specialised scan kernels where they exist
     int ring = 0;             // tuning hook: 8 = always the deep piece ring
     int queries_per_launch = 16;  // sweeps one scan launch walks back to back (query-major)

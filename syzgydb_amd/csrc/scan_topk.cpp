@@ -859,7 +859,74 @@ int TopkCall::run()
     std::deque<Ticket> inflight;
     int rc = SZG_OK;
     const int B1 = std::max(1, std::min(ix->query_batch, kMaxBatch));
-    for (int q0 = 0; q0 < n_queries && rc == SZG_OK;) {
+
+    // A call of several shared-sweep batches is bound by its host work (3-4 us per query against 2.7-3.7 us of GPU
+    // time for the int8 and 16-bit sweeps): a second thread takes the finished batches -- waits, candidate
+    // assembly, certification, output -- while this one prepares and enqueues.  The hand-over is the ticket queue;
+    // contexts are the flow control (acquire blocks until the finisher has released one).
+    struct Finisher {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<Ticket> q;
+        bool done = false;
+        int rc = SZG_OK;
+        std::string err;
+        std::atomic<bool> failed{false};
+        std::thread th;
+        void stop()
+        {
+            if (!th.joinable()) return;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                done = true;
+            }
+            cv.notify_one();
+            th.join();
+        }
+        ~Finisher() { stop(); }  // (an exception unwinding the call: the queued tickets are still finished first)
+    } fin;
+    bool threaded = false;
+    {
+        const int nb0 = replay_all ? 0 : mq_blocks(ix, n_queries);
+        threaded = ix->finish_thread && nb0 > 0 && n_queries > 2 * 16 * nb0 * (mq_uses_i8(ix) ? 2 : 1);
+    }
+    if (threaded) {
+        try {
+            fin.th = std::thread([this, &fin] {
+                for (;;) {
+                    std::unique_lock<std::mutex> lk(fin.mu);
+                    fin.cv.wait(lk, [&] { return !fin.q.empty() || fin.done; });
+                    if (fin.q.empty()) return;
+                    Ticket t(std::move(fin.q.front()));
+                    fin.q.pop_front();
+                    lk.unlock();
+                    int r;
+                    try {
+                        r = finish(t);
+                    } catch (const std::bad_alloc &) {
+                        r = fail(SZG_E_NOMEM, "out of host memory");
+                    } catch (...) {
+                        r = fail(SZG_E_DEVICE, "unexpected exception");
+                    }
+                    if (r != SZG_OK && !fin.failed.load()) {  // (every ticket is still finished: its contexts go back)
+                        fin.rc = r;
+                        fin.err = szg_last_error();
+                        fin.failed.store(true);
+                    }
+                }
+            });
+        } catch (...) {
+            threaded = false;  // no thread to be had: this one does both
+        }
+    }
+    auto hand_over = [&](Ticket &&t) {
+        {
+            std::lock_guard<std::mutex> lk(fin.mu);
+            fin.q.push_back(std::move(t));
+        }
+        fin.cv.notify_one();
+    };
+    for (int q0 = 0; q0 < n_queries && rc == SZG_OK && !fin.failed.load();) {
         Ticket t;
         t.owner = ix;
         t.first = q0;
@@ -888,6 +955,14 @@ int TopkCall::run()
         t.kp_wide = bf16_sweep ? std::min(4096, std::max(kp, k + std::max(ix->mq_bf16_slack, k / 2))) : kp;
         t.ctx.assign(n_sh, nullptr);
         t.meta.assign(t.nq, QMeta{});
+        if (threaded) {
+            (void)acquire(t, true);  // blocks until the finisher (or another caller) gives a context back
+            rc = stage(t, nb, bf16_sweep);
+            t.failed = rc != SZG_OK;
+            q0 += t.nq;
+            hand_over(std::move(t));
+            continue;
+        }
         if (!acquire(t, inflight.empty())) {  // no free context: finish the oldest batch first
             rc = finish(inflight.front());
             inflight.pop_front();
@@ -897,6 +972,11 @@ int TopkCall::run()
         t.failed = rc != SZG_OK;  // nothing to gather: finish() only drains and releases
         inflight.push_back(std::move(t));
         q0 += inflight.back().nq;
+    }
+    if (threaded) {
+        fin.stop();
+        if (rc == SZG_OK && fin.failed.load()) rc = fail(fin.rc, fin.err.c_str());  // (this thread's last-error slot)
+        return rc;
     }
     while (!inflight.empty()) {
         const int r2 = finish(inflight.front());

@@ -356,3 +356,39 @@ def test_int8_sweep_two_query_groups_per_launch(bits, metric):
         ix.set_option("mq_i8_groups", 1)
         ix.set_option("mq_fused", 1)
         check(ix, rows, dim, Q[:60], 10, bits=bits, metric=metric)
+
+
+# ---- long calls: the finished batches are assembled on a second host thread ----------------------------------------
+
+@pytest.mark.parametrize("bits,dim", [(8, 64), (4, 128), (16, 64), (32, 48), (32, 20)])
+@pytest.mark.parametrize("metric", [SZG_COSINE, SZG_EUCLIDEAN])
+def test_long_calls_with_and_without_the_finisher_thread(bits, dim, metric):
+    """Calls of 3+ shared-sweep batches (here 330 and 530 queries) hand their finished batches to a second host
+    thread; the answers are the oracle's, with a filter, with forced escalations, and equal to the one-thread form's."""
+    n = 2500
+    rows = orc.synth_rows(4100 + bits + dim, 0, n, dim, bits)
+    Q = orc.synth_vectors(4101 + bits + dim, 0, 530, dim)
+    rng = np.random.default_rng(bits * 1000 + dim)
+    allow = rng.random((530, n)) < 0.6
+    with ScanIndex(dim, bits, metric) as ix:
+        ix.load(rows)
+        r1, d1, c1 = ix.search_topk(Q, 10)
+        r1m, d1m, c1m = ix.search_topk(Q[:330], 7, allow=allow[:330])
+        ix.set_option("force_escalate", 1)
+        r1e, d1e, c1e = ix.search_topk(Q[:330], 3)
+        ix.set_option("force_escalate", 0)
+        ix.set_option("finish_thread", 0)
+        r0, d0, c0 = ix.search_topk(Q, 10)
+        r0m, d0m, c0m = ix.search_topk(Q[:330], 7, allow=allow[:330])
+        assert (r1 == r0).all() and (c1 == c0).all() and ((d1 == d0) | (np.isnan(d1) & np.isnan(d0))).all()
+        assert (r1m == r0m).all() and (c1m == c0m).all() and ((d1m == d0m) | (np.isnan(d1m) & np.isnan(d0m))).all()
+    for qi in list(range(0, 530, 37)) + [329, 529]:
+        o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, Q[qi], k=10)
+        assert [int(x) for x in r1[qi, : c1[qi]]] == [int(x) for x in o_rows], qi
+        assert (d1[qi, : c1[qi]] == np.asarray(o_dist)).all(), qi
+        if qi < 330:
+            o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, Q[qi], k=7, allow=allow[qi].astype(np.uint8))
+            assert [int(x) for x in r1m[qi, : c1m[qi]]] == [int(x) for x in o_rows], qi
+            o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, Q[qi], k=3)
+            assert [int(x) for x in r1e[qi, : c1e[qi]]] == [int(x) for x in o_rows], qi
+            assert (d1e[qi, : c1e[qi]] == np.asarray(o_dist)).all(), qi
