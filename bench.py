@@ -25,6 +25,7 @@ Rank 0 prints ONE JSON line: metric/value/unit/..., plus
                   toolchain in this image) on this box's host cores, bounded sample (N=1);
   "batched":      the shared multi-query sweep on the matrix cores (its own fixed query set);
   "sketch_prepass": the optional 8-bit sketch pre-pass on the headline workload (same answers);
+  "batched_quantized": the shared sweep on 16- / 8- / 4-bit copies of the headline shape (960 queries per call);
   "host_us_per_query", "ranks", "rccl_ranks", "other_workloads" (cfg2/cfg3/cfg4/cfg5 per-GPU
                   shards: queries/s and one short roofline object each, peak 8000 GB/s).
 The printed line is the compact form; the full objects (kernels, launch times, PMC traffic, host time
@@ -97,6 +98,12 @@ def compact(obj):
                    {"value": w["value"], "roofline": _rf(w["roofline"]),
                     "identical_to_oracle": "%d/%d" % (w["parity"]["identical_to_oracle"], w["parity"]["queries_checked"])})
             for name, w in o["other_workloads"].items()}
+    if "batched_quantized" in o:
+        o["batched_quantized"] = {
+            name: ({"error": w["error"]} if "error" in w else
+                   {"value": w["value"], "avg_pass_ms": w["avg_pass_ms"], "roofline": _rf(w["roofline"]),
+                    "identical_to_single_query_path": w["ids_and_distances_identical_to_single_query_path"]})
+            for name, w in o["batched_quantized"].items()}
     if "host_us_breakdown" in o:
         del o["host_us_breakdown"]
     return o
@@ -290,6 +297,41 @@ def side_workload(name, n_queries, devices):
             out["parity"] = {"rows": nchk, "queries_checked": 2, "identical_to_oracle": same}
     log("side workload %s: %.1f s, %.0f GB/s" % (name, time.time() - t0, rf["achieved"]))
     return out
+
+
+def batched_leg(bits, n_rows, dim, metric, k, devices, seed):
+    """The shared sweep on a quantized copy of the headline shape: 960 queries in one call (the int8 sweeps for 8- and
+    4-bit rows, the bfloat16 sweep for 16-bit rows)."""
+    from syzgydb_amd import ScanIndex
+    from syzgydb_amd.synth import synth_vectors
+    with ScanIndex(dim, bits, metric, devices=devices) as ix:
+        ix.synth(n_rows, seed)
+        qb = synth_vectors(seed + 2, 0, 960, dim)
+        ix.search_topk(qb, k)
+        ix.search_topk(qb, k)
+        t0 = time.perf_counter()
+        b_rows, b_dist, _ = ix.search_topk(qb, k)
+        elapsed = time.perf_counter() - t0
+        ix.set_timing(True)
+        ix.reset_stats()
+        ix.search_topk(qb, k)
+        st = ix.stats()
+        ix.set_timing(False)
+        ix.set_option("multi_query", 0)
+        s_rows, s_dist, _ = ix.search_topk(qb[:32], k)
+        pass_ms = st["scan_ms"] / max(st["timed_launches"], 1)
+        gbps = n_rows * ix.row_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms else 0.0
+        kern = ("szg::mq_score_bf16s_kernel (v_mfma_f32_16x16x32_bf16, 16-bit codes decoded on the fly)" if bits == 16
+                else "szg::mq_score_i8s_kernel (v_mfma_i32_16x16x64_i8, exact integer)")
+        return {"workload": "%d x %d, %d-bit, cosine, k=%d, 960 queries in one call" % (n_rows, dim, bits, k),
+                "value": round(960 / elapsed, 1), "unit": "queries/s",
+                "queries_per_pass": round(st["mq_queries"] / max(st["mq_launches"], 1), 2),
+                "avg_pass_ms": round(pass_ms, 5), "kernel": kern,
+                "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(gbps / HBM_PEAK_GBS, 4), "traffic": None},
+                "escalations": int(st["escalations"]),
+                "ids_and_distances_identical_to_single_query_path":
+                    bool((b_rows[:32] == s_rows).all() and (b_dist[:32] == s_dist).all())}
 
 
 def main():
@@ -629,7 +671,7 @@ def main():
             # rows and queries rounded to bfloat16 on the fly, v_mfma_f32_16x16x32_bf16: the sweep is a
             # stream of the rows (HBM-bound); candidates re-scored in float32, re-ranked in float64
             out["batched"].update({
-                "kernel": "szg::mq_score_bf16s_kernel<3,cosine,collect> (v_mfma_f32_16x16x32_bf16)",
+                "kernel": "szg::mq_score_bf16s_kernel<6,cosine,collect,32> (v_mfma_f32_16x16x32_bf16)",
                 "f32_equivalent_TFLOPs": round(tf, 2),
                 "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(gbps / HBM_PEAK_GBS, 4), "traffic": None},
@@ -760,6 +802,14 @@ def main():
             except Exception as e:  # a side leg never takes the headline line down with it
                 extras[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["other_workloads"] = extras
+        if args.workload == "headline":
+            bq = {}
+            for b in (16, 8, 4):
+                try:
+                    bq["%dbit" % b] = batched_leg(b, n_rows, dim, metric, k, devices, SEED + 40 + b)
+                except Exception as e:
+                    bq["%dbit" % b] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["batched_quantized"] = bq
 
     if rank == 0:
         emit(out)
