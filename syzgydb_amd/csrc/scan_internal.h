@@ -318,6 +318,7 @@ struct szg_index {
     int query_batch = 16;     // queries per scan launch
     int first_batch = 4;      // ... of a call's first launch (0 = query_batch): the card starts sooner
     int short_call = 32;      // calls of up to this many one-sweep queries are ONE batch on the scan stream (0 = off)
+    int radius_mq = 1;        // radius batches of 2+ queries share one sweep of the corpus (the shared sweeps' collect form)
     int finish_thread = 1;    // shared-sweep calls of 3+ batches: a second host thread assembles the finished batches
                               // while the caller's prepares and enqueues the next ones (0 = one thread does both)
     int shape_kernels = 1;    // use the row-shape-specialised scan kernels where they exist
@@ -428,6 +429,9 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
 
 // the batch's tail will compute the sentinel rows' distances itself (stage them, do not launch their own rerank)
 bool mq_tail_takes_sentinels(const szg_index *ix, const Shard *sh, int kp, int kp_wide, int nq, int nb);
+// radius batches: ONE shared sweep collects every (query, row) pair at or below the query's key threshold
+// (thr[q], host) into c->d_collect (cap entries per query, counts in c->d_count)
+int enqueue_collect_mq(szg_index *ix, Shard *sh, Ctx *c, int nq, int nb, bool has_allow, const float *thr, size_t cap);
 
 // ---- scan_sketch.cpp
 int search_topk_any(szg_index *ix, const double *queries, int n_queries, int k, const uint64_t *allow_bits,

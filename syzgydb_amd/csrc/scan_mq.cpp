@@ -363,4 +363,90 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
     return SZG_OK;
 }
 
+// ---- a radius batch through ONE shared sweep ----------------------------------------------------------------------
+//
+// A radius search needs no threshold pass: the radius IS the threshold (radius_key_threshold, with the sweep's own
+// error bound).  The collect form of the shared sweeps appends every (query, row) pair at or below its query's key
+// threshold to the query's buffer; the caller re-ranks all of them in float64 and applies the reference's predicate.
+// One pass of the corpus then serves up to 96 queries instead of one.
+int enqueue_collect_mq(szg_index *ix, Shard *sh, Ctx *c, int nq, int nb, bool has_allow, const float *thr, size_t cap)
+{
+    HIPCHK(hipSetDevice(sh->device));
+    const int r16 = ix->map.r16;
+    const bool i8 = mq_uses_i8(ix), bf16 = mq_uses_bf16(ix);
+    const int groups = i8 ? (nq + 16 * nb - 1) / (16 * nb) : 1;
+    if (nq > szg::kMqMaxQueries || groups > 2 || (groups == 2 && nb != 3))
+        return fail(SZG_E_INVALID, "shared radius sweep: batch too large for the image");
+    const size_t group_stride = i8 ? ((szg::mq_i8_image_bytes(ix->bits, r16, nb) + 3 * 48 * sizeof(float) + 255) & ~(size_t)255) : 0;
+    const size_t img = bf16 ? szg::mq_bf16_image_bytes(ix->bits, r16, nb) : i8 ? group_stride * groups : szg::mq_lds_bytes(ix->bits, r16, nb);
+    int rc = ensure_host(&c->h_mq, &c->h_mq_cap, img);
+    if (rc) return rc;
+    rc = ensure_dev(&c->d_mq, &c->d_mq_cap, img);
+    if (rc) return rc;
+    memset(c->h_mq, 0, img);
+    if (bf16) build_image_bf16(ix, c, nq, nb);
+    else if (i8) build_image_i8(ix, c, nq, nb, group_stride);
+    else build_image_f32(ix, c, nq, nb);
+    HIPCHK(hipMemcpyAsync(c->d_mq, c->h_mq, img, hipMemcpyHostToDevice, c->work));
+    if (!c->d_thr) HIPCHK(hipMalloc((void **)&c->d_thr, 256 * sizeof(float)));
+    if (!c->h_thr) HIPCHK(hipHostMalloc((void **)&c->h_thr, 256 * sizeof(float), hipHostMallocDefault));
+    for (int q = 0; q < nq; q++) c->h_thr[q] = thr[q];
+    HIPCHK(hipMemcpyAsync(c->d_thr, c->h_thr, sizeof(float) * nq, hipMemcpyHostToDevice, c->work));
+
+    szg::MqArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows = sh->rows;
+    a.n_rows = (uint32_t)sh->n_rows;
+    a.pitch = ix->pitch;
+    a.tiled = ix->layout.tiled;
+    a.steps = ix->layout.steps;
+    a.r16 = r16;
+    a.dim = ix->dim;
+    a.queries = c->d_mq;
+    a.n_queries = nq;
+    a.n_groups = groups;
+    a.shape_kernels = ix->shape_kernels;
+    a.group_stride = (uint32_t)group_stride;
+    a.metric = ix->metric;
+    for (int q = 0; q < nq; q++) a.qnorm2[q] = (float)c->meta[q].qnorm2;
+    a.zero16 = sh->zero16;
+    a.norm_bias = (float)ix->norm_bias;
+    a.collect = 1;
+    a.thr = c->d_thr;
+    a.cand_buf = c->d_collect;
+    a.cand_count = c->d_count;
+    a.cand_cap = (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu);
+    a.live_bits = sh->has_dead ? sh->live_bits : nullptr;
+    a.allow_bits = has_allow ? c->d_allow : nullptr;
+    a.allow_stride = (uint32_t)shard_words(sh);
+    {
+        std::lock_guard<std::mutex> lk(sh->chain_mu);
+        hipStream_t st = ix->serialize_scans ? sh->scan_stream : c->work;
+        if (st != c->work) {  // the sweep must see the image, the thresholds, the masks and the zeroed counters
+            HIPCHK(hipEventRecord(c->ev_up, c->work));
+            HIPCHK(hipStreamWaitEvent(st, c->ev_up, 0));
+        }
+        if (ix->timing) HIPCHK(hipEventRecord(c->ev_scan0, st));
+        if (bf16) HIPCHK(szg::launch_mq_score_bf16(ix->bits, a, nb, sh->cu_count, st));
+        else if (i8) HIPCHK(szg::launch_mq_score_i8(ix->bits, a, nb, sh->cu_count, st));
+        else HIPCHK(szg::launch_mq_score(ix->bits, a, nb, sh->cu_count, st));
+        if (ix->timing) {
+            HIPCHK(hipEventRecord(c->ev_scan1, st));
+            c->timed_scan = true;
+            c->timed_n = groups;
+        }
+        if (st != c->work) {
+            HIPCHK(hipEventRecord(c->ev_scan_done, st));
+            HIPCHK(hipStreamWaitEvent(c->work, c->ev_scan_done, 0));
+        }
+    }
+    std::lock_guard<std::mutex> lk(ix->stats_mu);
+    ix->stats.scan_launches += (uint64_t)groups;
+    ix->stats.scan_bytes += (uint64_t)groups * sh->n_rows * (uint64_t)ix->row_bytes;
+    ix->stats.mq_launches += (uint64_t)groups;
+    ix->stats.mq_queries += (uint64_t)nq;
+    ix->stats.mq_bf16_sweeps += bf16 ? 1 : 0;
+    return SZG_OK;
+}
+
 }  // namespace szgi

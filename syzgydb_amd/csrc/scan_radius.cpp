@@ -36,24 +36,20 @@ constexpr size_t kRadiusBlockCopyBytes = 2u << 20;  // a batch's re-ranked hits 
 // distinct priorities yields them in descending order whatever the push order was, so the result is simply the hits
 // sorted by distance; only when two hits share a distance (or one is NaN, which `<=` never admits anyway) does the
 // order inside the tie depend on the heap's history, and only then is the heap replayed (three times the work).
-void radius_assemble(std::vector<Cand> &cs, double radius, std::vector<HeapItem> *out)
-{
-    size_t n = 0;
-    for (size_t i = 0; i < cs.size(); i++)
-        if (cs[i].dist <= radius) cs[n++] = cs[i];
-    cs.resize(n);
-    std::sort(cs.begin(), cs.end(), [](const Cand &x, const Cand &y) { return x.dist < y.dist; });
+void radius_assemble(std::vector<HeapItem> &cs, std::vector<HeapItem> *out)
+{   // cs: the hits (distance <= radius already applied), any order
+    const size_t n = cs.size();
+    std::sort(cs.begin(), cs.end(), [](const HeapItem &x, const HeapItem &y) { return x.priority < y.priority; });
     bool tie = false;
-    for (size_t i = 1; i < n && !tie; i++) tie = cs[i].dist == cs[i - 1].dist;
+    for (size_t i = 1; i < n && !tie; i++) tie = cs[i].priority == cs[i - 1].priority;
     if (!tie) {
-        out->resize(n);
-        for (size_t i = 0; i < n; i++) (*out)[i] = HeapItem{cs[i].row, cs[i].dist};
+        out->swap(cs);
         return;
     }
-    std::sort(cs.begin(), cs.end(), [](const Cand &x, const Cand &y) { return x.row < y.row; });
+    std::sort(cs.begin(), cs.end(), [](const HeapItem &x, const HeapItem &y) { return x.row < y.row; });
     GoHeap h;
     h.a.reserve(n);
-    for (const Cand &c : cs) h.push(HeapItem{c.row, c.dist});
+    for (const HeapItem &c : cs) h.push(c);
     h.drain(out);
 }
 
@@ -61,7 +57,9 @@ struct RadiusCall;
 struct RadiusTicket {
     int first = 0, nq = 0;
     std::vector<Ctx *> ctx;       // one per shard
-    std::vector<float> thr;       // key threshold per query
+    std::vector<float> thr;       // key threshold per query (of the sweep that runs: shared or one per query)
+    std::vector<float> thr_single; // ... of the single-query collect sweep (a query that overflows is swept again on its own)
+    int nb = 0;                   // > 0: the batch shares ONE sweep (query blocks of 16)
     std::vector<size_t> cap;      // per shard: entries per sweep of this batch's buffers
     std::vector<uint8_t> copied;  // per shard: the block of re-ranked hits was copied back at enqueue time
     bool any_mask = false;
@@ -134,6 +132,9 @@ int RadiusCall::enqueue_shard(RadiusTicket &t, size_t s)
     HIPCHK(hipSetDevice(sh->device));
     // buffers: t.nq sweeps x cap entries; cap follows the largest hit count this context has seen
     size_t cap = std::max(kRadiusCapMin, c->radius_cap);
+    // (a shared sweep's batch is up to 96 queries: keep its buffers within 8M entries; a query with more hits than
+    // its share is swept again on its own)
+    if (t.nb > 0) cap = std::min(cap, std::max(kRadiusCapMin, ((size_t)8 << 20) / (size_t)t.nq));
     t.cap[s] = cap;
     int rc = ensure_dev(&c->d_collect, &c->collect_cap, cap * (size_t)t.nq);
     if (rc) return rc;
@@ -141,9 +142,13 @@ int RadiusCall::enqueue_shard(RadiusTicket &t, size_t s)
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(uint32_t) * (size_t)t.nq * szg::kCandCountStride, c->work));
     HIPCHK(hipEventRecord(c->ev_up, c->work));  // the sweeps must see the queries, the masks and the zeroed counters
+    if (t.nb > 0) {  // one shared sweep for the whole batch
+        rc = enqueue_collect_mq(ix, sh, c, t.nq, t.nb, t.any_mask, t.thr.data(), cap);
+        if (rc) return rc;
+    }
     const int qpl = std::max(1, std::min(ix->queries_per_launch, szg::kMaxSweepsPerLaunch));
-    std::vector<szg::ScanArgs> a((t.nq + qpl - 1) / qpl);
-    for (int j0 = 0; j0 < t.nq; j0 += qpl) {  // launches of <= 16 sweeps, back to back
+    std::vector<szg::ScanArgs> a(t.nb > 0 ? 0 : (t.nq + qpl - 1) / qpl);
+    for (int j0 = 0; j0 < t.nq && t.nb == 0; j0 += qpl) {  // launches of <= 16 sweeps, back to back
         szg::ScanArgs &x = a[j0 / qpl];
         const int m = std::min(qpl, t.nq - j0);
         fill_scan_args(ix, sh, c, t.any_mask, j0, m, &x);
@@ -158,8 +163,10 @@ int RadiusCall::enqueue_shard(RadiusTicket &t, size_t s)
             x.mask_dense = lowest >= 0.5 ? 1 : 0;
         }
     }
-    rc = launch_scans_chained(ix, sh, c, a, scan_geometry(ix, sh, 0));
-    if (rc) return rc;
+    if (t.nb == 0) {
+        rc = launch_scans_chained(ix, sh, c, a, scan_geometry(ix, sh, 0));
+        if (rc) return rc;
+    }
     // float64 distances of the hits: the counts stay on the device
     HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, c->d_collect, c->d_count,
                               (uint32_t)cap, t.nq, c->d_out, c->work, szg::kCandCountStride));
@@ -189,17 +196,32 @@ int RadiusCall::stage(RadiusTicket &t)
     }
     const double t0 = now_us();
     Ctx *c0 = nullptr;
+    const bool int_planes = t.nb > 0 && mq_uses_i8(ix);
     for (size_t s = 0; s < n_sh; s++) {
         Ctx *c = t.ctx[s];
         if (!c) continue;
+        if (int_planes && !c->h_mqQ) {
+            c->h_mqQ = (int32_t *)malloc(sizeof(int32_t) * (size_t)kMaxBatch * ix->dim);
+            if (!c->h_mqQ) return fail(SZG_E_NOMEM, "host scratch");
+        }
         if (!c0) {
             c0 = c;
             for (int j = 0; j < t.nq; j++) {
+                // (the single-query form is built too: a query whose hits overflow the batch's buffers is swept again
+                // on its own)
                 prep_query(ix, q + (size_t)j * ix->dim, c->h_qsw + (size_t)j * ix->qsw_bytes, &c->meta[j]);
-                t.thr[j] = radius_key_threshold(ix, radii[t.first + j], c->meta[j]);
+                t.thr_single[j] = t.thr[j] = radius_key_threshold(ix, radii[t.first + j], c->meta[j]);
+                if (t.nb > 0) {  // the shared sweep's arithmetic has its own error bound
+                    if (int_planes) prep_mq_int(ix, q + (size_t)j * ix->dim, &c->meta[j], c->h_mqQ + (size_t)j * ix->dim);
+                    QMeta m2 = c->meta[j];
+                    m2.mq = !int_planes;
+                    m2.mq_bf16 = mq_uses_bf16(ix);
+                    t.thr[j] = radius_key_threshold(ix, radii[t.first + j], m2);
+                }
             }
         } else {
             memcpy(c->h_qsw, c0->h_qsw, ix->qsw_bytes * (size_t)t.nq);
+            if (int_planes) memcpy(c->h_mqQ, c0->h_mqQ, sizeof(int32_t) * (size_t)t.nq * ix->dim);
             for (int j = 0; j < t.nq; j++) c->meta[j] = c0->meta[j];
         }
     }
@@ -222,7 +244,7 @@ int RadiusCall::finish(RadiusTicket &t)
         return SZG_OK;
     }
     int rc = SZG_OK;
-    std::vector<std::vector<Cand>> cands(t.nq);
+    std::vector<std::vector<HeapItem>> cands(t.nq);  // the hits proper: `distance <= Radius` (collection.go:598) applied here
     std::vector<uint8_t> redo(t.nq, 0);  // more hits than the batch's buffers hold: the query is swept again on its own
     double t_wait = 0;
     const double t0 = now_us();
@@ -269,22 +291,27 @@ int RadiusCall::finish(RadiusTicket &t)
         for (int j = 0; j < t.nq; j++) {
             if (redo[j]) continue;
             cands[j].reserve(cands[j].size() + cnt[j]);
+            const double rad = radii[t.first + j];
             for (size_t i = off[j]; i < off[j] + cnt[j]; i++) {
                 const szg::RerankOut &r = c->h_out[i];
-                cands[j].push_back(Cand{sh->first + r.row, r.dist, szg::key_from_ordered(r.ukey), 0.0});
+                if (r.dist <= rad) cands[j].push_back(HeapItem{sh->first + r.row, r.dist});
             }
         }
     }
     for (int j = 0; j < t.nq && rc == SZG_OK; j++) {
         if (redo[j]) {
             cands[j].clear();
+            std::vector<Cand> all;
             const double tw = now_us();
             for (size_t s = 0; s < n_sh && rc == SZG_OK; s++)
-                if (t.ctx[s]) rc = run_collect(ix, ix->shards[s], t.ctx[s], j, t.thr[j], t.any_mask, &cands[j]);
+                if (t.ctx[s]) rc = run_collect(ix, ix->shards[s], t.ctx[s], j, t.thr_single[j], t.any_mask, &all);
             t_wait += now_us() - tw;
             if (rc) break;
+            const double rad = radii[t.first + j];
+            for (const Cand &c : all)
+                if (c.dist <= rad) cands[j].push_back(HeapItem{c.row, c.dist});
         }
-        radius_assemble(cands[j], radii[t.first + j], &(*results)[t.first + j]);
+        radius_assemble(cands[j], &(*results)[t.first + j]);
     }
     {
         std::lock_guard<std::mutex> lk(ix->stats_mu);
@@ -311,16 +338,26 @@ int RadiusCall::run()
         const int left = n_queries - q0;
         const int edge = std::max(1, std::min(qpl, ix->first_batch > 0 ? ix->first_batch : qpl));
         t.nq = std::min(qpl, left);
+        // two or more queries left: they share one sweep of the corpus (up to 96 per pass), as top-k batches do
+        t.nb = ix->radius_mq && left >= 2 ? mq_blocks(ix, left) : 0;
+        if (t.nb > 0) {
+            const int groups = t.nb == 3 && mq_uses_i8(ix) && ix->mq_i8_groups > 1 && left > 48 &&
+                                       szg::mq_i8_lds_bytes(ix->bits, ix->map.r16, 3, 2) <= 160u * 1024u
+                                   ? 2 : 1;
+            t.nq = std::min(left, 16 * t.nb * groups);
+        }
         // (only the smallest calls are ONE batch here: a radius query's result assembly -- hundreds of hits to sort --
         // takes the host ~15 us, which a longer call hides behind the next batch's sweeps)
-        single_batch = q0 == 0 && ix->short_call > 0 && n_queries <= std::min(edge, ix->short_call);
+        single_batch = t.nb == 0 && q0 == 0 && ix->short_call > 0 && n_queries <= std::min(edge, ix->short_call);
         if (single_batch) t.nq = n_queries;
+        else if (t.nb > 0) ;  // (a shared sweep takes what fits its image)
         else if (q0 == 0 && left > edge) t.nq = edge;
         else if (left > edge && left <= qpl + edge) t.nq = left - edge;
         t.ctx.assign(n_sh, nullptr);
         t.cap.assign(n_sh, 0);
         t.copied.assign(n_sh, 0);
         t.thr.assign(t.nq, 0.0f);
+        t.thr_single.assign(t.nq, 0.0f);
         if (!acquire(t, inflight.empty())) {
             rc = finish(inflight.front());
             inflight.pop_front();

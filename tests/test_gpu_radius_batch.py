@@ -164,3 +164,44 @@ def test_empty_collection_and_empty_batch():
         assert len(hits) == 3 and all(len(r) == 0 and len(d) == 0 for r, d in hits)
         ix.load(orc.synth_rows(SEED, 0, 10, 8, 32))
         assert ix.search_radius_batch(np.zeros((0, 8)), 0.4) == []
+
+
+@pytest.mark.parametrize("bits,metric,dim,n", [(4, SZG_COSINE, 384, 6000), (8, SZG_COSINE, 768, 2500), (8, SZG_EUCLIDEAN, 100, 5000),
+                                               (16, SZG_COSINE, 64, 4000), (16, SZG_EUCLIDEAN, 36, 3000),
+                                               (32, SZG_COSINE, 96, 7000), (32, SZG_EUCLIDEAN, 33, 4000),
+                                               (32, SZG_COSINE, 2, 5000)])
+def test_radius_batches_share_one_sweep(bits, metric, dim, n):
+    """A radius batch of 2+ queries takes ONE shared sweep (the radius is the collect threshold, widened by the
+    sweep's own error bound); answers identical to the oracle's and to the one-sweep-per-query form's -- with
+    filters, radii that admit nothing, everything, or more hits than the batch's buffers hold."""
+    rows = orc.synth_rows(SEED + 300 + bits + dim, 0, n, dim, bits)
+    Q = orc.synth_vectors(SEED + 301 + dim, 0, 110, dim)   # 110: a full batch of 96 and a ragged one
+    if dim == 2:  # rows and queries within a few degrees of one direction (the bfloat16 band's worst case)
+        rng0 = np.random.default_rng(9)
+        rows = orc.encode_rows(rng0.uniform(-1, 1, (n, dim)) * 1e3 + 5e3, bits)
+        Q = rng0.uniform(-1, 1, (110, dim)) * 1e3 + 5e3
+    rng = np.random.default_rng(bits + dim)
+    masks = rng.random((len(Q), n)) < 0.7
+    with ScanIndex(dim, bits, metric) as ix:
+        ix.load(rows)
+        _, dd, _ = ix.search_topk(Q, 150)
+        radii = np.array([dd[i, [4, 30, 149, 0][i % 4]] for i in range(len(Q))])
+        radii = np.maximum(radii, 1e-12)
+        radii[7] *= 0.25                                       # (usually) nothing
+        radii[11] = 1.0 if metric == SZG_COSINE else 1e30      # everything: overflows the batch's buffers
+        radii[12] = float(dd[12, -1]) * 1.5                    # many
+        ix.reset_stats()
+        hits = ix.search_radius_batch(Q, radii)
+        st = ix.stats()
+        check(hits, rows, dim, bits, metric, Q, radii)
+        assert len(hits[11][0]) == n
+        if not __import__("os").environ.get("SZG_OPTIONS"):
+            assert st["mq_queries"] == 110 and st["mq_launches"] >= 2
+        hm = ix.search_radius_batch(Q[:40], radii[:40], allow=masks[:40])
+        check(hm, rows, dim, bits, metric, Q[:40], radii[:40], masks=masks[:40])
+        ix.set_option("radius_mq", 0)
+        ix.reset_stats()
+        h0 = ix.search_radius_batch(Q, radii)
+        assert ix.stats()["mq_queries"] == 0
+        for a, b in zip(hits, h0):
+            assert (a[0] == b[0]).all() and (np.asarray(a[1]) == np.asarray(b[1])).all()
