@@ -349,6 +349,12 @@ int szg_reset_stats(szg_index *ix);
  *                             per shared sweep, by whichever caller finds no batch in flight;
  *                             concurrent szg_search_radius callers likewise share query-major
  *                             collect launches (16 sweeps per launch, each with its own radius)
+ *     radius_mq           1   radius batches (szg_search_radius_batch, coalesced szg_search_radius
+ *                             callers) of two or more queries share ONE sweep of the corpus per up to 96
+ *                             queries -- the shared sweeps' collect form with the radius as threshold;
+ *                             0 = one collect sweep per query
+ *     radius_sort         1   a radius batch's re-ranked hits are sorted by distance on the device
+ *                             (lists of up to 2 048 hits); 0 = the host sorts
  *     finish_thread       1   a call of three or more shared-sweep batches assembles its finished
  *                             batches (waits, certification, output) on a second host thread while
  *                             the caller's prepares and enqueues the next ones; 0 = one thread

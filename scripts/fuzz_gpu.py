@@ -21,7 +21,7 @@ OPTS = [("queries_per_launch", [1, 3, 16]), ("multi_query", [0, 1]), ("mq_fused"
         ("mq_overlap", [0, 1]), ("mq_bf16_slack", [0, 118, 246]), ("mq_hits", [64, 1024]), ("sketch", [0, 1, 1]),
         ("sketch_extra", [0, 30]), ("sketch_min_rows", [1, 1, 4096]), ("mq_i8_groups", [1, 2]),
         ("mq_refine", [0, 1, 1]), ("first_batch", [0, 1, 4]), ("mask_dense", [0, 1]), ("coalesce", [0, 1]),
-        ("finish_thread", [0, 1, 1])]
+        ("finish_thread", [0, 1, 1]), ("radius_mq", [0, 1, 1]), ("radius_sort", [0, 1, 1])]
 
 
 def same(got_r, got_d, want_r, want_d):

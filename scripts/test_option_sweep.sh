@@ -19,7 +19,7 @@ run() {  # $1 = label, rest = pytest arguments
 # SWEEP_SKIP_MAIN=1 skips this loop (a box allows 20 minutes per call: the two loops can go in two calls)
 [ -n "$SWEEP_SKIP_MAIN" ] || for opts in ${SWEEP_SETS:-serialize_scans=0 queries_per_launch=1 queries_per_launch=3,blocks_per_cu=1 shape_kernels=0,block_threads=128 \
             mq_fused=0,mq_i8=0 mq_tail_overlap=1,mq_blocks=2 multi_query=0,query_batch=5 contexts=1,blocks_per_cu=6 mask_dense=0,coalesce=0 \
-            mq_min=8,tie_mode=0 ring=8,mq_hits=256 mq_bf16=0 mq_overlap=0,mq_bf16_slack=0 sketch=1,sketch_min_rows=1 sketch=1,multi_query=0,sketch_extra=0,sketch_min_rows=1 mq_refine=0 first_batch=0,queries_per_launch=5 first_batch=1 finish_thread=0,mq_hits=256}; do
+            mq_min=8,tie_mode=0 ring=8,mq_hits=256 mq_bf16=0 mq_overlap=0,mq_bf16_slack=0 sketch=1,sketch_min_rows=1 sketch=1,multi_query=0,sketch_extra=0,sketch_min_rows=1 mq_refine=0 first_batch=0,queries_per_launch=5 first_batch=1 finish_thread=0,mq_hits=256 radius_mq=0,radius_sort=0}; do
   run "$opts" tests -m gpu -q -x --ignore=tests/test_gpu_fullsize.py --ignore=tests/test_gpu_bench_launch.py \
       --deselect tests/test_gpu_multiquery.py::test_shared_sweep_matches_oracle \
       --deselect tests/test_gpu_multiquery.py::test_shared_sweep_quantized_rows \

@@ -247,6 +247,11 @@ struct RerankOut {
 // n_queries queries: query_f64 [n_queries][dim], cands/out [n_queries][n_cands_max].
 // n_cands_dev (nullable): the candidate count of query q is min(n_cands_dev[q * n_dev_stride], n_cands_max), read on
 // the device (collect sweeps: the hit counters, no host round trip between the sweep and its re-rank).
+// sorts each query's re-ranked hits out[q * cap .. + min(count[q * count_stride], cap)) by distance, ascending, when the
+// list has 2 .. kSortHitsMax entries (longer lists are left as they are)
+constexpr int kSortHitsMax = 2048;
+hipError_t launch_sort_hits(RerankOut *out, const uint32_t *count, uint32_t count_stride, uint32_t cap, int n_queries,
+                            hipStream_t stream);
 hipError_t launch_rerank(int qbits, int metric, const uint8_t *rows, RowLayout layout, int dim,
                          const double *query_f64, const uint64_t *cands, const uint32_t *n_cands_dev,
                          uint32_t n_cands_max, int n_queries, RerankOut *out, hipStream_t stream,

@@ -635,4 +635,69 @@ hipError_t launch_f64_probe(int op, const double *a, const double *b, double *ou
     return hipGetLastError();
 }
 
+
+// ---- a radius batch's hits, sorted on the device ------------------------------------------------------------------
+// The host assembles a radius result as the hits sorted by distance (scan_radius.cpp: radius_assemble); sorting
+// ~500 doubles costs it ~13 us per query, which is what a shared-sweep radius batch is bound by.  One block per
+// query sorts the query's re-ranked hits by distance in LDS (bitonic over (ordered distance, index) pairs, the
+// entries themselves staged beside them) -- lists of 2 .. kSortHitsMax entries; longer ones are left to the host.
+// Not stable: equal distances are the host's business anyway (it replays the reference's heap for them).
+namespace {
+__device__ __forceinline__ uint64_t ordered_f64(double d)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__global__ __launch_bounds__(256) void sort_hits_kernel(RerankOut *out, const uint32_t *count, uint32_t count_stride,
+                                                        uint32_t cap)
+{
+    __shared__ RerankOut ent[kSortHitsMax];
+    __shared__ uint64_t key[kSortHitsMax];
+    __shared__ uint16_t idx[kSortHitsMax];
+    const uint32_t n = min(count[(size_t)blockIdx.x * count_stride], cap);
+    if (n < 2 || n > (uint32_t)kSortHitsMax) return;
+    uint32_t P = 2;
+    while (P < n) P <<= 1;
+    RerankOut *o = out + (size_t)blockIdx.x * cap;
+    for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) {
+        if (i < n) {
+            ent[i] = o[i];
+            key[i] = ordered_f64(ent[i].dist);
+        } else {
+            key[i] = ~0ull;
+        }
+        idx[i] = (uint16_t)i;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const uint64_t a = key[i], b = key[l];
+                    if ((a > b) == up) {
+                        key[i] = b;
+                        key[l] = a;
+                        const uint16_t t = idx[i];
+                        idx[i] = idx[l];
+                        idx[l] = t;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) o[i] = ent[idx[i]];
+}
+}  // namespace
+
+hipError_t launch_sort_hits(RerankOut *out, const uint32_t *count, uint32_t count_stride, uint32_t cap, int n_queries,
+                            hipStream_t stream)
+{
+    if (n_queries <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sort_hits_kernel, dim3(n_queries), dim3(256), 0, stream, out, count, count_stride, cap);
+    return hipGetLastError();
+}
+
 }  // namespace szg

@@ -709,6 +709,9 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
     } else if (n == "query_batch") {
         if (value < 1 || value > kMaxBatch) return fail(SZG_E_INVALID, "query_batch out of range");
         ix->query_batch = (int)value;
+    } else if (n == "radius_sort") {
+        if (value < 0 || value > 1) return fail(SZG_E_INVALID, "radius_sort is 0 or 1");
+        ix->radius_sort = (int)value;
     } else if (n == "radius_mq") {
         if (value < 0 || value > 1) return fail(SZG_E_INVALID, "radius_mq is 0 or 1");
         ix->radius_mq = (int)value;

@@ -318,6 +318,7 @@ struct szg_index {
     int query_batch = 16;     // queries per scan launch
     int first_batch = 4;      // ... of a call's first launch (0 = query_batch): the card starts sooner
     int short_call = 32;      // calls of up to this many one-sweep queries are ONE batch on the scan stream (0 = off)
+    int radius_sort = 1;      // a radius batch's re-ranked hits are sorted by distance on the device (lists of up to 2 048)
     int radius_mq = 1;        // radius batches of 2+ queries share one sweep of the corpus (the shared sweeps' collect form)
     int finish_thread = 1;    // shared-sweep calls of 3+ batches: a second host thread assembles the finished batches
                               // while the caller's prepares and enqueues the next ones (0 = one thread does both)

@@ -36,10 +36,11 @@ constexpr size_t kRadiusBlockCopyBytes = 2u << 20;  // a batch's re-ranked hits 
 // distinct priorities yields them in descending order whatever the push order was, so the result is simply the hits
 // sorted by distance; only when two hits share a distance (or one is NaN, which `<=` never admits anyway) does the
 // order inside the tie depend on the heap's history, and only then is the heap replayed (three times the work).
-void radius_assemble(std::vector<HeapItem> &cs, std::vector<HeapItem> *out)
-{   // cs: the hits (distance <= radius already applied), any order
+void radius_assemble(std::vector<HeapItem> &cs, bool presorted, std::vector<HeapItem> *out)
+{   // cs: the hits (distance <= radius already applied); presorted: already ascending by distance (the device's sort)
     const size_t n = cs.size();
-    std::sort(cs.begin(), cs.end(), [](const HeapItem &x, const HeapItem &y) { return x.priority < y.priority; });
+    if (!presorted)
+        std::sort(cs.begin(), cs.end(), [](const HeapItem &x, const HeapItem &y) { return x.priority < y.priority; });
     bool tie = false;
     for (size_t i = 1; i < n && !tie; i++) tie = cs[i].priority == cs[i - 1].priority;
     if (!tie) {
@@ -62,6 +63,7 @@ struct RadiusTicket {
     int nb = 0;                   // > 0: the batch shares ONE sweep (query blocks of 16)
     std::vector<size_t> cap;      // per shard: entries per sweep of this batch's buffers
     std::vector<uint8_t> copied;  // per shard: the block of re-ranked hits was copied back at enqueue time
+    std::vector<uint8_t> sorted;  // per shard: lists of up to kSortHitsMax hits arrive sorted by distance
     bool any_mask = false;
     bool failed = false;
     RadiusCall *owner = nullptr;
@@ -170,6 +172,9 @@ int RadiusCall::enqueue_shard(RadiusTicket &t, size_t s)
     // float64 distances of the hits: the counts stay on the device
     HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, c->d_collect, c->d_count,
                               (uint32_t)cap, t.nq, c->d_out, c->work, szg::kCandCountStride));
+    // ... and each query's hits sorted by distance there too (lists of up to kSortHitsMax: the host only filters)
+    if (ix->radius_sort) HIPCHK(szg::launch_sort_hits(c->d_out, c->d_count, szg::kCandCountStride, (uint32_t)cap, t.nq, c->work));
+    t.sorted[s] = ix->radius_sort != 0;
     HIPCHK(hipMemcpyAsync(c->h_count, c->d_count, sizeof(uint32_t) * (size_t)t.nq * szg::kCandCountStride, hipMemcpyDeviceToHost,
                           c->work));
     // the re-ranked hits: while the batch's buffers are small (the usual hundreds of hits per query) the whole block
@@ -246,6 +251,8 @@ int RadiusCall::finish(RadiusTicket &t)
     int rc = SZG_OK;
     std::vector<std::vector<HeapItem>> cands(t.nq);  // the hits proper: `distance <= Radius` (collection.go:598) applied here
     std::vector<uint8_t> redo(t.nq, 0);  // more hits than the batch's buffers hold: the query is swept again on its own
+    std::vector<uint8_t> presorted(t.nq, 1);  // the query's hits come from ONE shard's device-sorted list
+    std::vector<uint8_t> lists(t.nq, 0);
     double t_wait = 0;
     const double t0 = now_us();
     for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
@@ -291,6 +298,9 @@ int RadiusCall::finish(RadiusTicket &t)
         for (int j = 0; j < t.nq; j++) {
             if (redo[j]) continue;
             cands[j].reserve(cands[j].size() + cnt[j]);
+            if (cnt[j]) {
+                if (!t.sorted[s] || cnt[j] > (size_t)szg::kSortHitsMax || ++lists[j] > 1) presorted[j] = 0;
+            }
             const double rad = radii[t.first + j];
             for (size_t i = off[j]; i < off[j] + cnt[j]; i++) {
                 const szg::RerankOut &r = c->h_out[i];
@@ -310,8 +320,9 @@ int RadiusCall::finish(RadiusTicket &t)
             const double rad = radii[t.first + j];
             for (const Cand &c : all)
                 if (c.dist <= rad) cands[j].push_back(HeapItem{c.row, c.dist});
+            presorted[j] = 0;
         }
-        radius_assemble(cands[j], &(*results)[t.first + j]);
+        radius_assemble(cands[j], presorted[j] != 0, &(*results)[t.first + j]);
     }
     {
         std::lock_guard<std::mutex> lk(ix->stats_mu);
@@ -356,6 +367,7 @@ int RadiusCall::run()
         t.ctx.assign(n_sh, nullptr);
         t.cap.assign(n_sh, 0);
         t.copied.assign(n_sh, 0);
+        t.sorted.assign(n_sh, 0);
         t.thr.assign(t.nq, 0.0f);
         t.thr_single.assign(t.nq, 0.0f);
         if (!acquire(t, inflight.empty())) {
