@@ -54,6 +54,7 @@ namespace {
 [[maybe_unused]] constexpr int kMqbThreads = 64 * SZG_MQB_WAVES;
 typedef int v4i32b __attribute__((ext_vector_type(4)));
 [[maybe_unused]] constexpr int kMq8Threads = 64 * SZG_MQ8_WAVES;
+[[maybe_unused]] constexpr int kMq8TableRows = 6;  // 48-float rows after a group's image: qscale, qconst, qnorm2 | thresholds, pre-test s, w
 
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -1103,6 +1104,37 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
 // keep mq_score_i8_kernel.  Measured against it (1M rows, ms per 48-query pass): 768 dims 8-bit 0.122 / 0.134,
 // 768 dims 4-bit 0.088 / 0.092, 384 dims 4-bit 0.053 / 0.062 (profiles/r03_i8_sweep_experiments.txt, which also
 // has the probe -- scripts/readbw -- that found the int8 sweeps running without their non-temporal hint).
+// Per-query constants of the shape kernels' hit PRE-TEST (see the kernel's tile finish).  With g = sum Q n (a float)
+// the key is  cosine: -fl(fl(g qs) inv)   Euclidean: fl(fma(-2 qs, g, fl(qn + norm))),  and a hit is key <= thr.
+//   cosine:     key <= thr  ==>  g inv >= (-thr - 4e-7 |thr|) / qs =: T             pre-test  fma(g, inv, w) >= 0, w = -T
+//   Euclidean:  key <= thr  ==>  2 qs g - norm (1 - 6e-8) >= qn - thr - 2e-6 (qn + |thr|) =: V
+//                                                          pre-test  fma(g, s, w) >= norm (1 - 2e-6), s = 2 qs, w = -V
+// (two roundings of 2^-24 each in the cosine chain, one plus the rounded qn + norm in the Euclidean one; the margins
+// are several times that, and the float forms of w are nudged two more ulps towards "pass").  A query the algebra
+// does not cover (qs <= 0, a NaN anywhere) gets w = +inf: every tile takes the exact path for it.  An unused query
+// slot (thr = -3e38) gets w = -inf.
+template <int METRIC>
+__device__ __forceinline__ void pretest_consts(float thr, float qs, float qn, float *ps, float *pw)
+{
+    float s = 0.0f, w;
+    if (thr <= -3.0e38f) {
+        w = -__builtin_inff();
+    } else if (METRIC == kCosine) {
+        const double T = (-(double)thr - 4.0e-7 * fabs((double)thr)) / (double)qs;
+        w = (float)(-T);
+        w += fabsf(w) * 2.4e-7f + 1.0e-37f;
+        if (!(qs > 0.0f) || w != w) w = __builtin_inff();
+    } else {
+        const double V = (double)qn - (double)thr - 2.0e-6 * (fabs((double)qn) + fabs((double)thr));
+        s = 2.0f * qs;
+        w = (float)(-V);
+        w += fabsf(w) * 2.4e-7f + 1.0e-37f;
+        if (!(qs > 0.0f) || !(qn >= 0.0f) || w != w) w = __builtin_inff();
+    }
+    *ps = s;
+    *pw = w;
+}
+
 // Waves per CU and ring depth (16-byte loads per lane in flight; divides STEPS) of the shape kernels.  768-byte rows
 // (12 steps): 8 waves with 6 KiB each in flight -- 0.122 ms per 1M-row pass against 0.134 with 12 x 4, fewer waves
 // queueing behind one another's tile finish.  Shorter rows have a finish per fewer bytes and want the 12 waves
@@ -1131,6 +1163,7 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
     constexpr int T = RB == 4 ? 2 : 1;
     constexpr int NPL = kMqPlanes;
     constexpr int D = i8s_ring<RB, STEPS>();
+    static_assert(NPL == 2, "the integer plane combine in the tile finish assumes two digit planes");
     constexpr int QSTEP = NPL * T * NB * 64;  // 16-byte words of the image per 64-byte step
     constexpr int N16 = STEPS * QSTEP;
     extern __shared__ __align__(16) uint8_t smem[];
@@ -1141,16 +1174,23 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
     const RowLayout mlay{a.pitch, a.tiled, a.steps};
     const uint32_t istep = a.tiled ? 1024u : 64u;
     const int n_groups = a.n_groups > 0 ? a.n_groups : 1;
-    constexpr size_t grp_lds = (size_t)N16 * 16 + 4 * 48 * sizeof(float);  // image | qscale, qconst, qnorm2 | thresholds
+    constexpr size_t grp_lds = (size_t)N16 * 16 + kMq8TableRows * 48 * sizeof(float);  // image | qscale, qconst, qnorm2 | thresholds, pre-test s, w
     for (int g = 0; g < n_groups; g++) {
         const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.queries) +
                                                            (size_t)g * a.group_stride);
         uint4 *dst = reinterpret_cast<uint4 *>(smem + (size_t)g * grp_lds);
         constexpr int n = N16 + (3 * 48 * 4) / 16;  // + constants table
         stage_image(dst, src, n, tid, blockDim.x);
-        if (tid < 48)
-            reinterpret_cast<float *>(smem + (size_t)g * grp_lds + (size_t)n * 16)[tid] =
-                g * 48 + tid < a.n_queries ? a.thr[g * 48 + tid] : -3.0e38f;
+        if (tid < 48) {
+            float *tab = reinterpret_cast<float *>(smem + (size_t)g * grp_lds + (size_t)n * 16);
+            const float thr = g * 48 + tid < a.n_queries ? a.thr[g * 48 + tid] : -3.0e38f;
+            const float *qconsts = reinterpret_cast<const float *>(src + N16);  // qscale | qconst | qnorm2
+            float ps, pw;
+            pretest_consts<METRIC>(thr, qconsts[tid], qconsts[96 + tid], &ps, &pw);
+            tab[tid] = thr;
+            tab[48 + tid] = ps;
+            tab[96 + tid] = pw;
+        }
     }
     const int trow = lane & 15;
     const int c = lane >> 4;
@@ -1229,42 +1269,73 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
                             acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qc_, bop_[t], acc[p][b], 0, 0, 0);
                         }
             }
-            // ---- the tile is done: row norms across the 4 chunk lanes, keys, hit test
+            // ---- the tile is done: row norms across the 4 chunk lanes, then the hit test in two stages.  On a large
+            // shard a tile of 16 rows x 48 queries holds a hit a few times in a hundred (a radius batch: far less), so
+            // every tile pays only a PRE-TEST of ~4 VALU instructions per (row, query) -- one integer combine, one
+            // convert, two fmas, a running max -- against per-query constants staged with a safety margin
+            // (pretest_consts), and only a tile in which some lane passes it forms the keys proper and tests them
+            // against the thresholds.  The pre-test passes whenever key <= thr would (the same inequality solved for
+            // the integer dot product, the rounding of the key's float chain covered by the margin), so the hits are
+            // exactly the one-stage test's.  (1M rows with the default 1 024 expected hits per query: more than half
+            // the tiles hold a hit and the two-stage form measures the same as the one-stage form; 12.5M rows: see
+            // profiles/r03_i8_sweep_experiments.txt, section 11.)
             int nrm = 4 * (SQ + SV);
             nrm += __shfl_xor(nrm, 16);
             nrm += __shfl_xor(nrm, 32);
             const float norm = (float)nrm + a.norm_bias;
             const float inv = __frsqrt_rn(norm);
             const uint64_t row = tile * 16 + trow;
-            float keys[NB][4];
-            uint32_t hm = 0;
             const bool row_ok = row < a.n_rows;
+            float g[NB][4];  // d2 = sum Q n of the pair, the float the key is made of
+            float best = -__builtin_inff();
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 const int q0 = b * 16 + c * 4;
-                const float4 qs4 = *reinterpret_cast<const float4 *>(qtab + q0);
                 const float4 qc4 = *reinterpret_cast<const float4 *>(qtab + 48 + q0);
-                const float4 qn4 = METRIC == kCosine ? make_float4(0.f, 0.f, 0.f, 0.f)
-                                                     : *reinterpret_cast<const float4 *>(qtab + 96 + q0);
-                const float4 th4 = *reinterpret_cast<const float4 *>(thr_lds + q0);
-                const float qsv[4] = {qs4.x, qs4.y, qs4.z, qs4.w}, qcv[4] = {qc4.x, qc4.y, qc4.z, qc4.w};
-                const float qnv[4] = {qn4.x, qn4.y, qn4.z, qn4.w}, thv[4] = {th4.x, th4.y, th4.z, th4.w};
+                const float4 ps4 = *reinterpret_cast<const float4 *>(thr_lds + 48 + q0);
+                const float4 pw4 = *reinterpret_cast<const float4 *>(thr_lds + 96 + q0);
+                const float qcv[4] = {qc4.x, qc4.y, qc4.z, qc4.w};
+                const float psv[4] = {ps4.x, ps4.y, ps4.z, ps4.w}, pwv[4] = {pw4.x, pw4.y, pw4.z, pw4.w};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    float dot = (float)acc[0][b][r];  // plane 0 = the top digit
+                    // planes combined as integers: |plane sums| < 2^24 and |dot| < 2^31 for these row shapes, so the
+                    // one conversion rounds exactly as fmaf(128, float(acc0), float(acc1)) does (the generic
+                    // kernel's form, which the prefix pass made the thresholds with)
+                    int di = acc[0][b][r];
 #pragma unroll
-                    for (int p = 1; p < NPL; p++) dot = fmaf(128.0f, dot, (float)acc[p][b][r]);
-                    const float d2 = fmaf(2.0f, dot, qcv[r]);  // sum Q n
-                    float key;
-                    if (METRIC == kCosine)
-                        key = -(d2 * qsv[r]) * inv;
-                    else
-                        key = fmaf(-2.0f * qsv[r], d2, qnv[r] + norm);
-                    keys[b][r] = key;
-                    hm |= (row_ok && key <= thv[r]) ? (1u << (b * 4 + r)) : 0u;  // unused queries: thr = -3e38
+                    for (int p = 1; p < NPL; p++) di = di * 128 + acc[p][b][r];
+                    g[b][r] = fmaf(2.0f, (float)di, qcv[r]);
+                    const float e = METRIC == kCosine ? fmaf(g[b][r], inv, pwv[r]) : fmaf(g[b][r], psv[r], pwv[r]);
+                    best = fmaxf(best, e);
                 }
             }
-            offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row, qoff);
+            const bool pass = row_ok && best >= (METRIC == kCosine ? 0.0f : norm * (1.0f - 2.0e-6f));
+            if (__ballot(pass)) {
+                float keys[NB][4];
+                uint32_t hm = 0;
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    const int q0 = b * 16 + c * 4;
+                    const float4 qs4 = *reinterpret_cast<const float4 *>(qtab + q0);
+                    const float4 qn4 = METRIC == kCosine ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                                         : *reinterpret_cast<const float4 *>(qtab + 96 + q0);
+                    const float4 th4 = *reinterpret_cast<const float4 *>(thr_lds + q0);
+                    const float qsv[4] = {qs4.x, qs4.y, qs4.z, qs4.w};
+                    const float qnv[4] = {qn4.x, qn4.y, qn4.z, qn4.w}, thv[4] = {th4.x, th4.y, th4.z, th4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float d2 = g[b][r];
+                        float key;
+                        if (METRIC == kCosine)
+                            key = -(d2 * qsv[r]) * inv;
+                        else
+                            key = fmaf(-2.0f * qsv[r], d2, qnv[r] + norm);
+                        keys[b][r] = key;
+                        hm |= (row_ok & (key <= thv[r])) ? (1u << (b * 4 + r)) : 0u;  // unused queries: thr = -3e38
+                    }
+                }
+                offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row, qoff);
+            }
 #pragma unroll
             for (int p = 0; p < NPL; p++)
 #pragma unroll
@@ -1825,7 +1896,7 @@ size_t mq_i8_image_bytes(int row_bits, int r16, int nb)
 }
 size_t mq_i8_lds_bytes(int row_bits, int r16, int nb, int groups)
 {   // per group: image + constants + thresholds; + the 12 waves' hit buffers
-    return (size_t)groups * (mq_i8_image_bytes(row_bits, r16, nb) + 4 * 48 * sizeof(float)) + (size_t)SZG_MQ8_WAVES * 64 * 9;
+    return (size_t)groups * (mq_i8_image_bytes(row_bits, r16, nb) + kMq8TableRows * 48 * sizeof(float)) + (size_t)SZG_MQ8_WAVES * 64 * 9;
 }
 size_t mq_bf16_image_bytes(int row_bits, int r16, int nb)
 {   // a KiB per 32-element K-step and query block; a 128-byte step of a row holds one (32-bit rows) or two (16-bit)
