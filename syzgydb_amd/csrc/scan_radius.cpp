@@ -180,7 +180,8 @@ int RadiusCall::enqueue_shard(RadiusTicket &t, size_t s)
     // the re-ranked hits: while the batch's buffers are small (the usual hundreds of hits per query) the whole block
     // follows in ONE copy right here -- finish() then needs a single wait; larger ones are copied hit list by hit
     // list once the counts are known
-    t.copied[s] = cap * (size_t)t.nq * sizeof(szg::RerankOut) <= kRadiusBlockCopyBytes;
+    // (a shared sweep's batch of up to 96 queries: a copy call per hit list costs more than 64 KiB of transfer each)
+    t.copied[s] = cap * (size_t)t.nq * sizeof(szg::RerankOut) <= std::max(kRadiusBlockCopyBytes, (size_t)t.nq * (64u << 10));
     if (t.copied[s]) {
         rc = ensure_host(&c->h_out, &c->h_out_cap, cap * (size_t)t.nq);
         if (rc) return rc;

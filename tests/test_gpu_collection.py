@@ -556,3 +556,41 @@ def test_search_batch_equals_search_by_search():
         mixed = c.SearchBatch([args[0], rargs[0], SearchArgs(Offset=0, Limit=3)])
         assert len(mixed) == 3 and len(mixed[2].Results) == 3
         c.Close()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("bits,devices", [(8, [0]), (32, [0, 0])])
+def test_concurrent_long_calls_with_finisher_threads(bits, devices):
+    """Four threads on one handle, each issuing calls of 200-400 queries (3+ shared-sweep batches: producer + finisher
+    thread per call, all of them competing for the shards' three contexts) mixed with radius batches: no deadlock,
+    every answer the oracle's."""
+    import threading
+    dim, n, metric = 48, 6000, 1
+    rows = orc.synth_rows(71 + bits, 0, n, dim, bits)
+    Q = orc.synth_vectors(72, 0, 400, dim)
+    want = {i: orc.search_exact(rows, dim, bits, metric, Q[i], k=6) for i in range(0, 400, 23)}
+    with ScanIndex(dim, bits, metric, devices=devices) as ix:
+        ix.load(rows)
+        _, dd, _ = ix.search_topk(Q[:40], 30)
+        radii = dd[:, -1].copy()
+        want_r = {i: orc.search_exact(rows, dim, bits, metric, Q[i], radius=float(radii[i])) for i in (0, 17, 39)}
+        errs = []
+
+        def worker(t):
+            try:
+                for it in range(3):
+                    nq = (200, 330, 400)[(t + it) % 3]
+                    r, d, c = ix.search_topk(Q[:nq], 6)
+                    for i in want:
+                        if i < nq:
+                            assert [int(x) for x in r[i, : c[i]]] == [int(x) for x in want[i][0]], (t, it, i)
+                            assert (d[i, : c[i]] == want[i][1]).all()
+                    hits = ix.search_radius_batch(Q[:40], radii)
+                    for i in want_r:
+                        assert [int(x) for x in hits[i][0]] == [int(x) for x in want_r[i][0]], (t, it, i)
+            except Exception as e:  # pragma: no cover
+                errs.append(e)
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs
