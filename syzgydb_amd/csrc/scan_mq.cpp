@@ -193,6 +193,46 @@ bool mq_tail_takes_sentinels(const szg_index *ix, const Shard *sh, int kp, int k
     return mq_plan(ix, sh, kp, kp_wide, nq, nb, false).refine;
 }
 
+// the batch's LDS image: built in the context's pinned buffer, uploaded on `st`
+static int upload_mq_image(szg_index *ix, Ctx *c, int nq, int nb, bool bf16, bool i8, size_t img, size_t group_stride,
+                           hipStream_t st)
+{
+    int rc = ensure_host(&c->h_mq, &c->h_mq_cap, img);
+    if (rc) return rc;
+    rc = ensure_dev(&c->d_mq, &c->d_mq_cap, img);
+    if (rc) return rc;
+    memset(c->h_mq, 0, img);
+    if (bf16) build_image_bf16(ix, c, nq, nb);
+    else if (i8) build_image_i8(ix, c, nq, nb, group_stride);
+    else build_image_f32(ix, c, nq, nb);
+    HIPCHK(hipMemcpyAsync(c->d_mq, c->h_mq, img, hipMemcpyHostToDevice, st));
+    return SZG_OK;
+}
+
+// the arguments every shared sweep of a batch has in common (image in c->d_mq, constants from the staged queries)
+static szg::MqArgs mq_args_base(const szg_index *ix, const Shard *sh, const Ctx *c, int nq, int groups, size_t group_stride)
+{
+    szg::MqArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rows = sh->rows;
+    a.n_rows = (uint32_t)sh->n_rows;
+    a.pitch = ix->pitch;
+    a.tiled = ix->layout.tiled;
+    a.steps = ix->layout.steps;
+    a.r16 = ix->map.r16;
+    a.dim = ix->dim;
+    a.queries = c->d_mq;
+    a.n_queries = nq;
+    a.n_groups = groups;
+    a.shape_kernels = ix->shape_kernels;
+    a.group_stride = (uint32_t)group_stride;
+    a.metric = ix->metric;
+    for (int q = 0; q < nq && q < szg::kMqMaxQueries; q++) a.qnorm2[q] = (float)c->meta[q].qnorm2;
+    a.zero16 = sh->zero16;
+    a.norm_bias = (float)ix->norm_bias;
+    return a;
+}
+
 // top-k pass for the nq staged queries through ONE shared sweep:
 //   threshold pass (prefix) -> full sweep, collecting -> cand_refine (selection, float32 re-score of the bfloat16
 //   band, sentinel rows appended) -> ONE rerank -> D2H          [fused selection, the default]
@@ -207,15 +247,8 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
     // (the kernel indexes thresholds, keys and candidates of group g by 48 g + q: a second group needs full groups)
     if (p.groups > 2 || (p.groups == 2 && nb != 3)) return fail(SZG_E_INVALID, "int8 shared sweep: two groups need 48 queries each");
     kp = p.kp;
-    int rc = ensure_host(&c->h_mq, &c->h_mq_cap, p.img);
+    int rc = upload_mq_image(ix, c, nq, nb, p.bf16, p.i8, p.img, p.group_stride, c->stream);
     if (rc) return rc;
-    rc = ensure_dev(&c->d_mq, &c->d_mq_cap, p.img);
-    if (rc) return rc;
-    memset(c->h_mq, 0, p.img);
-    if (p.bf16) build_image_bf16(ix, c, nq, nb);
-    else if (p.i8) build_image_i8(ix, c, nq, nb, p.group_stride);
-    else build_image_f32(ix, c, nq, nb);
-    HIPCHK(hipMemcpyAsync(c->d_mq, c->h_mq, p.img, hipMemcpyHostToDevice, c->stream));
 
     // sentinel rows staged by the caller ride in the batch's one rerank when the tail is the refine launch;
     // otherwise (score-matrix form, an overflow rerun) they get their own
@@ -235,26 +268,9 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
     c->mq_band_used = p.stage2 && p.refine;
     c->mq_bf16_used = p.bf16 && !p.stage2;
 
-    szg::MqArgs a;
-    memset(&a, 0, sizeof(a));
-    a.rows = sh->rows;
-    a.n_rows = (uint32_t)sh->n_rows;
-    a.pitch = ix->pitch;
-    a.tiled = ix->layout.tiled;
-    a.steps = ix->layout.steps;
-    a.r16 = ix->map.r16;
-    a.dim = ix->dim;
-    a.queries = c->d_mq;
-    a.n_queries = nq;
-    a.n_groups = p.groups;
-    a.shape_kernels = ix->shape_kernels;
-    a.group_stride = (uint32_t)p.group_stride;
-    a.metric = ix->metric;
-    for (int q = 0; q < nq && q < szg::kMqMaxQueries; q++) a.qnorm2[q] = (float)c->meta[q].qnorm2;
+    szg::MqArgs a = mq_args_base(ix, sh, c, nq, p.groups, p.group_stride);
     a.keys = c->d_keys;
     a.key_stride = p.key_stride;
-    a.zero16 = sh->zero16;
-    a.norm_bias = (float)ix->norm_bias;
     const uint64_t *live = sh->has_dead ? sh->live_bits : nullptr;
     const uint64_t *allow = has_allow ? c->d_allow : nullptr;
     const uint32_t words = (uint32_t)shard_words(sh);
@@ -379,38 +395,14 @@ int enqueue_collect_mq(szg_index *ix, Shard *sh, Ctx *c, int nq, int nb, bool ha
         return fail(SZG_E_INVALID, "shared radius sweep: batch too large for the image");
     const size_t group_stride = i8 ? ((szg::mq_i8_image_bytes(ix->bits, r16, nb) + 3 * 48 * sizeof(float) + 255) & ~(size_t)255) : 0;
     const size_t img = bf16 ? szg::mq_bf16_image_bytes(ix->bits, r16, nb) : i8 ? group_stride * groups : szg::mq_lds_bytes(ix->bits, r16, nb);
-    int rc = ensure_host(&c->h_mq, &c->h_mq_cap, img);
+    int rc = upload_mq_image(ix, c, nq, nb, bf16, i8, img, group_stride, c->work);
     if (rc) return rc;
-    rc = ensure_dev(&c->d_mq, &c->d_mq_cap, img);
-    if (rc) return rc;
-    memset(c->h_mq, 0, img);
-    if (bf16) build_image_bf16(ix, c, nq, nb);
-    else if (i8) build_image_i8(ix, c, nq, nb, group_stride);
-    else build_image_f32(ix, c, nq, nb);
-    HIPCHK(hipMemcpyAsync(c->d_mq, c->h_mq, img, hipMemcpyHostToDevice, c->work));
     if (!c->d_thr) HIPCHK(hipMalloc((void **)&c->d_thr, 256 * sizeof(float)));
     if (!c->h_thr) HIPCHK(hipHostMalloc((void **)&c->h_thr, 256 * sizeof(float), hipHostMallocDefault));
     for (int q = 0; q < nq; q++) c->h_thr[q] = thr[q];
     HIPCHK(hipMemcpyAsync(c->d_thr, c->h_thr, sizeof(float) * nq, hipMemcpyHostToDevice, c->work));
 
-    szg::MqArgs a;
-    memset(&a, 0, sizeof(a));
-    a.rows = sh->rows;
-    a.n_rows = (uint32_t)sh->n_rows;
-    a.pitch = ix->pitch;
-    a.tiled = ix->layout.tiled;
-    a.steps = ix->layout.steps;
-    a.r16 = r16;
-    a.dim = ix->dim;
-    a.queries = c->d_mq;
-    a.n_queries = nq;
-    a.n_groups = groups;
-    a.shape_kernels = ix->shape_kernels;
-    a.group_stride = (uint32_t)group_stride;
-    a.metric = ix->metric;
-    for (int q = 0; q < nq; q++) a.qnorm2[q] = (float)c->meta[q].qnorm2;
-    a.zero16 = sh->zero16;
-    a.norm_bias = (float)ix->norm_bias;
+    szg::MqArgs a = mq_args_base(ix, sh, c, nq, groups, group_stride);
     a.collect = 1;
     a.thr = c->d_thr;
     a.cand_buf = c->d_collect;
