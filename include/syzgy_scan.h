@@ -327,8 +327,8 @@ int szg_reset_stats(szg_index *ix);
  *                             the image does not fit LDS); 0 = one sweep per query
  *     mq_i8               1   8- and 4-bit rows: exact integer sweep on the int8 matrix cores
  *                             (v_mfma_i32_16x16x64_i8); 0 = the float32 MFMA sweep
- *     mq_bf16             1   32-bit rows (any dimension) and 16-bit rows of whole 16-byte pieces
- *                             (dim % 8 == 0; decoded on the fly): the sweep multiplies bfloat16
+ *     mq_bf16             1   32- and 16-bit rows of any dimension
+ *                             (decoded on the fly): the sweep multiplies bfloat16
  *                             roundings of rows and queries (v_mfma_f32_16x16x32_bf16, 16 x the float32
  *                             matrix rate: the sweep becomes a plain stream of the rows), its
  *                             candidates are scored again in float32 before the selection, and the

@@ -534,8 +534,8 @@ constexpr int kRingBPrefix = SZG_MQB_RING_PREFIX;
 // bfloat16 like float rows.  A 128-byte step then holds 64 elements = two MFMA K-steps: the wave stages and
 // multiplies the lower and the upper four chunks one after the other through the same KiB.  A chunk read from the
 // zero block (past a short last step) decodes to -65535 per element: zeros stand against it in the image, and
-// those lanes stay out of the norm.  Whole 16-byte pieces only (dim % 8 == 0: padding codes would decode to
-// -65535 inside the norm).
+// those lanes stay out of the norm; the padding codes inside the row's last piece (dim % 8 != 0) are taken off
+// the norm at the tile finish.
 template <int NB, int METRIC, bool COLLECT, int QBITS>
 __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArgs a)
 {
@@ -549,6 +549,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
     const int last_valid = a.r16 - 8 * (SS - 1);  // 16-byte chunks of the last step that belong to the row (1..8)
     const bool partial = last_valid < 8;
     const int n16 = SS * KS * NB * 64;
+    const float pad_norm = QBITS == 16 ? (float)(a.r16 * 8 - a.dim) * 4294836225.0f : 0.0f;
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -719,7 +720,9 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
         const int src = (trow & 7) * 8;
         const float na = __shfl(nrm_a, src), nb2 = __shfl(nrm_b, src);
         const uint32_t za = __shfl(nz_a, src), zb = __shfl(nz_b, src);
-        const float nrm = trow < 8 ? na : nb2;
+        // (16-bit rows: the padding codes of the row's last 16-byte piece decode to -65535 each -- zeros stand against
+        // them in the image, and their squares come off the norm here)
+        const float nrm = (trow < 8 ? na : nb2) - pad_norm;
         const uint32_t nz = (trow < 8 ? za : zb) & 0x7FFFFFFFu;
         const uint64_t row = tile * 16 + trow;
         const float inv = __frsqrt_rn(nrm);
@@ -1454,8 +1457,8 @@ __global__ __launch_bounds__(256) void cand_select_kernel(const uint64_t *cand_b
 // One 16-byte piece of a 32- or 16-bit row against the float32 query staged in LDS: 4 floats, or 8 codes decoded to
 // n = 2v - 65535.  COS: dot, norm and the zero-row bits; else the squared difference (into dot).
 template <bool COS>
-__device__ __forceinline__ void rescore_piece(const uint8_t *row, const float *qf, int piece, int row_bits, float &dot,
-                                              float &nrm, uint32_t &nz)
+__device__ __forceinline__ void rescore_piece(const uint8_t *row, const float *qf, int piece, int row_bits, int dim,
+                                              float &dot, float &nrm, uint32_t &nz)
 {
     const uint4 w = reinterpret_cast<const uint4 *>(row)[piece];
     float x[8];
@@ -1467,7 +1470,7 @@ __device__ __forceinline__ void rescore_piece(const uint8_t *row, const float *q
             x[2 * i] = fmaf((float)(ww[i] & 0xFFFFu), 2.0f, -65535.0f);
             x[2 * i + 1] = fmaf((float)(ww[i] >> 16), 2.0f, -65535.0f);
         }
-        n = 8;
+        n = min(8, dim - piece * 8);  // (the last piece's padding codes decode to -65535: not part of the row)
         nz |= 1u;
     } else {
         x[0] = __uint_as_float(w.x); x[1] = __uint_as_float(w.y); x[2] = __uint_as_float(w.z); x[3] = __uint_as_float(w.w);
@@ -1475,7 +1478,7 @@ __device__ __forceinline__ void rescore_piece(const uint8_t *row, const float *q
         n = 4;
         nz |= (w.x | w.y | w.z | w.w) & 0x7FFFFFFFu;
     }
-    const float *y = qf + (size_t)piece * n;
+    const float *y = qf + (size_t)piece * (row_bits == 16 ? 8 : 4);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         if (i < n) {
@@ -1513,7 +1516,7 @@ __global__ __launch_bounds__(256) void cand_rescore_kernel(const uint8_t *rows, 
         const uint8_t *rp = rows + (size_t)row * pitch;
         float dot = 0.f, nrm = 0.f;
         uint32_t nz = 0;
-        for (int i = lane; i < pieces; i += 64) rescore_piece<METRIC == kCosine>(rp, qf, i, row_bits, dot, nrm, nz);
+        for (int i = lane; i < pieces; i += 64) rescore_piece<METRIC == kCosine>(rp, qf, i, row_bits, dim, dot, nrm, nz);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             dot += __shfl_xor(dot, o);
@@ -1724,7 +1727,7 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
         const uint8_t *rp = rows + (size_t)row * pitch;
         float dot = 0.f, nrm = 0.f;
         uint32_t nz = 0;
-        for (int i = lane; i < pieces; i += 64) rescore_piece<MODE == 1>(rp, qf, i, row_bits, dot, nrm, nz);
+        for (int i = lane; i < pieces; i += 64) rescore_piece<MODE == 1>(rp, qf, i, row_bits, dim, dot, nrm, nz);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             dot += __shfl_xor(dot, o);
@@ -1782,7 +1785,7 @@ hipError_t launch_cand_rescore(int metric, const uint8_t *rows, uint32_t pitch, 
                                const double *qscale, uint64_t *cand_buf, const uint32_t *cand_count,
                                uint32_t cand_cap, int n_queries, int row_bits, hipStream_t stream)
 {
-    if (row_bits != 32 && !(row_bits == 16 && dim % 8 == 0)) return hipErrorInvalidValue;
+    if (row_bits != 32 && row_bits != 16) return hipErrorInvalidValue;
     const dim3 grid(SZG_RESCORE_BLOCKS, n_queries);  // x 4 waves: one candidate per wave and trip
     const size_t lds = (size_t)((dim + 7) & ~7) * sizeof(float);
     if (metric == kCosine)
@@ -1805,7 +1808,7 @@ hipError_t launch_cand_refine(int mode, const uint8_t *rows, uint32_t pitch, int
                               uint64_t *lists, float *band_edge, int row_bits, hipStream_t stream)
 {
     if (!cand_refine_applies(kp, cand_cap, dim, mode > 0)) return hipErrorInvalidValue;
-    if (mode > 0 && row_bits != 32 && !(row_bits == 16 && dim % 8 == 0)) return hipErrorInvalidValue;
+    if (mode > 0 && row_bits != 32 && row_bits != 16) return hipErrorInvalidValue;
     const size_t lds = ((size_t)kRefineMaxCands + (size_t)(kRefineThreads / 64) * kp + kp + kRefineMaxBand) * sizeof(uint64_t) +
                        (mode > 0 ? (size_t)((dim + 7) & ~7) * sizeof(float) : 0);
     auto go = [&](auto kern) -> hipError_t {
@@ -1959,7 +1962,6 @@ hipError_t launch_mq_score_bf16_rows16(const MqArgs &a, int nb, int grid, size_t
 #endif
 {
     if (a.tiled || a.n_rows == 0 || !a.zero16) return hipErrorInvalidValue;
-    if (kBfRowBits == 16 && a.dim % 8 != 0) return hipErrorInvalidValue;
     switch (nb) {
     case 1: return launch_mq_score_bf16_m<1>(a, grid, lds, stream);
     case 2: return launch_mq_score_bf16_m<2>(a, grid, lds, stream);

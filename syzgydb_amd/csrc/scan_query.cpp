@@ -223,12 +223,11 @@ double key_eps(const szg_index *ix, double key, const QMeta &m)
 // ---- multi-query sweep (32-bit rows, cosine): B queries share one pass ------------
 
 bool mq_uses_i8(const szg_index *ix) { return (ix->bits == 8 || ix->bits == 4) && ix->mq_i8; }
-// the bfloat16 sweep: 32-bit rows of any dimension, 16-bit rows of whole 16-byte pieces (a padding code would decode
-// to -65535 inside the row norm); not the experimental tiled layout
+// the bfloat16 sweep: 32- and 16-bit rows of any dimension; not the experimental tiled layout
 bool mq_uses_bf16(const szg_index *ix)
 {
     if (!ix->mq_bf16 || ix->layout.tiled) return false;
-    return ix->bits == 32 || (ix->bits == 16 && ix->dim % 8 == 0);
+    return ix->bits == 32 || ix->bits == 16;
 }
 
 // round to nearest even, as v_cvt_pk_bf16_f32 does (NaN stays NaN)
