@@ -534,8 +534,7 @@ constexpr int kRingBPrefix = SZG_MQB_RING_PREFIX;
 // bfloat16 like float rows.  A 128-byte step then holds 64 elements = two MFMA K-steps: the wave stages and
 // multiplies the lower and the upper four chunks one after the other through the same KiB.  A chunk read from the
 // zero block (past a short last step) decodes to -65535 per element: zeros stand against it in the image, and
-// those lanes stay out of the norm; the padding codes inside the row's last piece (dim % 8 != 0) are taken off
-// the norm at the tile finish.
+// those lanes stay out of the norm, and so do the padding codes inside the row's last piece (dim % 8 != 0).
 template <int NB, int METRIC, bool COLLECT, int QBITS>
 __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArgs a)
 {
@@ -549,7 +548,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
     const int last_valid = a.r16 - 8 * (SS - 1);  // 16-byte chunks of the last step that belong to the row (1..8)
     const bool partial = last_valid < 8;
     const int n16 = SS * KS * NB * 64;
-    const float pad_norm = QBITS == 16 ? (float)(a.r16 * 8 - a.dim) * 4294836225.0f : 0.0f;
+    const int pad16 = QBITS == 16 ? a.r16 * 8 - a.dim : 0;  // 16-bit rows: padding codes in the row's last 16-byte piece
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -664,22 +663,36 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
             const uint32_t wa_[4] = {va_.x, va_.y, va_.z, va_.w}, wb_[4] = {vb_.x, vb_.y, vb_.z, vb_.w};    \
             const bool out_ = partial && cs == SS - 1 && past; /* read from the zero block: not part of the row */ \
             uint32_t pa_[4], pb_[4];                                                     \
-            float sa_ = 0.f, sb_ = 0.f;                                                  \
+            float xa_[8], xb_[8];                                                        \
             _Pragma("unroll") for (int i = 0; i < 4; i++)                                \
             {                                                                            \
-                const float a0_ = fmaf((float)(wa_[i] & 0xFFFFu), 2.0f, -65535.0f);      \
-                const float a1_ = fmaf((float)(wa_[i] >> 16), 2.0f, -65535.0f);          \
-                const float b0_ = fmaf((float)(wb_[i] & 0xFFFFu), 2.0f, -65535.0f);      \
-                const float b1_ = fmaf((float)(wb_[i] >> 16), 2.0f, -65535.0f);          \
-                sa_ = fmaf(a0_, a0_, sa_);                                               \
-                sa_ = fmaf(a1_, a1_, sa_);                                               \
-                sb_ = fmaf(b0_, b0_, sb_);                                               \
-                sb_ = fmaf(b1_, b1_, sb_);                                               \
-                pa_[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a0_, a1_}, bf16x2)); \
-                pb_[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{b0_, b1_}, bf16x2)); \
+                xa_[2 * i] = fmaf((float)(wa_[i] & 0xFFFFu), 2.0f, -65535.0f);           \
+                xa_[2 * i + 1] = fmaf((float)(wa_[i] >> 16), 2.0f, -65535.0f);           \
+                xb_[2 * i] = fmaf((float)(wb_[i] & 0xFFFFu), 2.0f, -65535.0f);           \
+                xb_[2 * i + 1] = fmaf((float)(wb_[i] >> 16), 2.0f, -65535.0f);           \
+                pa_[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{xa_[2 * i], xa_[2 * i + 1]}, bf16x2)); \
+                pb_[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{xb_[2 * i], xb_[2 * i + 1]}, bf16x2)); \
             }                                                                            \
-            nrm_a += out_ ? 0.f : sa_;                                                   \
-            nrm_b += out_ ? 0.f : sb_;                                                   \
+            float sa_ = 0.f, sb_ = 0.f;                                                  \
+            if ((partial || pad16) && cs == SS - 1) { /* (wave-uniform) the row's last step: zero-block lanes and the */ \
+                /* padding codes of the last piece decode to -65535 -- zeros stand against them in the image, and */ \
+                /* they stay out of the norm (subtracting their squares afterwards would cost the small rows' norms */ \
+                /* all their bits) */                                                    \
+                const int nk_ = out_ ? 0 : (ch == last_valid - 1 ? 8 - pad16 : 8);       \
+                _Pragma("unroll") for (int i = 0; i < 8; i++)                            \
+                {                                                                        \
+                    sa_ = i < nk_ ? fmaf(xa_[i], xa_[i], sa_) : sa_;                     \
+                    sb_ = i < nk_ ? fmaf(xb_[i], xb_[i], sb_) : sb_;                     \
+                }                                                                        \
+            } else {                                                                     \
+                _Pragma("unroll") for (int i = 0; i < 8; i++)                            \
+                {                                                                        \
+                    sa_ = fmaf(xa_[i], xa_[i], sa_);                                     \
+                    sb_ = fmaf(xb_[i], xb_[i], sb_);                                     \
+                }                                                                        \
+            }                                                                            \
+            nrm_a += sa_;                                                                \
+            nrm_b += sb_;                                                                \
             nz_a = nz_b = 1u; /* a decoded code is odd: never a zero row */              \
             _Pragma("unroll") for (int h = 0; h < 2; h++)                                \
             {                                                                            \
@@ -720,9 +733,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
         const int src = (trow & 7) * 8;
         const float na = __shfl(nrm_a, src), nb2 = __shfl(nrm_b, src);
         const uint32_t za = __shfl(nz_a, src), zb = __shfl(nz_b, src);
-        // (16-bit rows: the padding codes of the row's last 16-byte piece decode to -65535 each -- zeros stand against
-        // them in the image, and their squares come off the norm here)
-        const float nrm = (trow < 8 ? na : nb2) - pad_norm;
+        const float nrm = trow < 8 ? na : nb2;
         const uint32_t nz = (trow < 8 ? za : zb) & 0x7FFFFFFFu;
         const uint64_t row = tile * 16 + trow;
         const float inv = __frsqrt_rn(nrm);

@@ -205,3 +205,31 @@ def test_radius_batches_share_one_sweep(bits, metric, dim, n):
         assert ix.stats()["mq_queries"] == 0
         for a, b in zip(hits, h0):
             assert (a[0] == b[0]).all() and (np.asarray(a[1]) == np.asarray(b[1])).all()
+
+
+@pytest.mark.parametrize("dim", [1, 3, 9, 36])
+@pytest.mark.parametrize("metric", [SZG_EUCLIDEAN, SZG_COSINE])
+def test_radius_batch_16bit_rows_with_padding_codes_and_small_queries(dim, metric):
+    """16-bit rows whose last 16-byte piece holds padding codes (they decode to -65535), queries and neighbours of
+    small norm: the shared sweep's row norms must not carry the padding (fuzz seeds 341 / 342: a norm formed as
+    `total - 7 x 65535^2` loses every bit of a small row's norm, and radius hits with it)."""
+    n = 3000
+    rng = np.random.default_rng(100 + dim)
+    vec = rng.uniform(-1, 1, (n, dim))
+    Q = rng.uniform(-1, 1, (12, dim)) * np.array([1e-3, 1e-2, 0.1, 1.0] * 3)[:, None]
+    for j in range(12):   # a few rows right next to each query
+        vec[rng.integers(0, n, 6)] = Q[j] * (1.0 + rng.uniform(-0.3, 0.3, (6, 1)))
+    rows = orc.encode_rows(vec, 16)
+    radii = []
+    for j in range(12):
+        od = orc.search_exact(rows, dim, 16, metric, Q[j], k=[2, 5, 40][j % 3])[1]
+        fin = [x for x in od if x == x and x > 0]
+        radii.append(float(fin[-1]) if fin else 0.5)
+    with ScanIndex(dim, 16, metric) as ix:
+        ix.load(rows)
+        hits = ix.search_radius_batch(Q, radii)
+        check(hits, rows, dim, 16, metric, Q, radii)
+        r, d, c = ix.search_topk(Q, 5)
+        for j in range(12):
+            er, ed, _ = orc.search_exact(rows, dim, 16, metric, Q[j], k=5)
+            assert [int(x) for x in r[j, : c[j]]] == [int(x) for x in er] and (d[j, : c[j]] == np.asarray(ed)).all(), j
