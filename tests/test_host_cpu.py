@@ -206,3 +206,39 @@ def test_merge_topk_randomized(oracle):
             else:   # equal distances / NaN among the best k+1: the multiset of distances is pinned
                 a, b = np.sort(got_d), np.sort(d)
                 assert ((a == b) | (np.isnan(a) & np.isnan(b))).all(), (case, qi)
+
+
+def test_bench_compact_line_keeps_the_contract_fields_and_one_short_object_per_leg():
+    """bench.py prints ONE compact JSON line (a driver may keep only a tail of stdout): the contract's fields in full,
+    one short object per extra leg, the rest goes to stderr."""
+    import importlib.util, json, os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rf = {"bound": "hbm", "achieved": 7000.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.875, "traffic": None,
+          "kernel": "k", "bytes_per_launch": 1, "sweeps_per_launch": 16.0, "avg_launch_ms": 1.0, "launches": 3}
+    obj = {
+        "metric": "m", "value": 1.0, "unit": "queries/s", "roofline": dict(rf), "cpu_baseline": {"value": 1.0},
+        "batched": {"value": 2.0, "unit": "queries/s", "queries_per_sweep": 96.0, "avg_sweep_ms": 0.46,
+                    "kernel": "szg::k<6> (mfma)", "roofline": dict(rf), "ids_identical_to_single_query_path": True,
+                    "float32_mfma_form": {"mfma_TFLOPs": 100.0}},
+        "batched_quantized": {"8bit": {"value": 3.0, "avg_pass_ms": 0.12, "roofline": dict(rf), "kernel": "x",
+                                       "ids_and_distances_identical_to_single_query_path": True},
+                              "4bit": {"error": "RuntimeError: x"}},
+        "other_workloads": {"cfg5": {"value": 4.0, "roofline": dict(rf),
+                                     "parity": {"identical_to_oracle": 2, "queries_checked": 2},
+                                     "batched": {"value": 50000.0}},
+                            "cfg2": {"error": "boom"}},
+        "host_us_breakdown": {"x": 1},
+    }
+    c = bench.compact(obj)
+    line = json.dumps(c)
+    assert json.loads(line)["roofline"] == rf                      # the contract's object untouched
+    assert c["batched"]["kernel"] == "szg::k<6>" and c["batched"]["float32_mfma_form_TFLOPs"] == 100.0
+    assert c["batched_quantized"]["8bit"] == {"value": 3.0, "avg_pass_ms": 0.12, "roofline": bench._rf(rf),
+                                              "identical_to_single_query_path": True}
+    assert c["batched_quantized"]["4bit"] == {"error": "RuntimeError: x"}
+    assert c["other_workloads"]["cfg5"]["batched_96_queries_per_s"] == 50000.0
+    assert c["other_workloads"]["cfg5"]["identical_to_oracle"] == "2/2" and c["other_workloads"]["cfg2"] == {"error": "boom"}
+    assert "host_us_breakdown" not in c and len(line) < 4000
