@@ -206,22 +206,36 @@ typedef int (*szg_allgather_fn)(void *user, const void *send, void *recv, uint64
 int szg_comm_create_host(szg_comm **out, szg_allgather_fn fn, void *user, int rank, int world);
 void szg_comm_destroy(szg_comm *c);
 /* Size the exchange staging for micro-batches of up to n_queries queries at this k ahead of time (it grows on
- * demand otherwise -- a hipHostMalloc inside the first call that needs it). */
+ * demand otherwise -- a hipHostMalloc inside the first call that needs it).  COLLECTIVE like the searches: every
+ * rank calls it with the same arguments; the ranks confirm to each other that all of them hold the staging (one
+ * status word over the staging that already exists), so a rank that cannot allocate makes EVERY rank return
+ * SZG_E_NOMEM here instead of leaving its peers waiting in a later exchange. */
 int szg_comm_reserve(szg_comm *c, int n_queries, int k);
 /* The handle's sharded searches go through `c` (borrowed: destroy it after the handle, or attach NULL first). */
 int szg_index_attach_comm(szg_index *ix, szg_comm *c);
 
 /*
  * szg_search_topk over the sharded collection.  allow_bits covers THIS rank's rows (n_queries x ceil(local rows / 64)
- * words).  out_history_dependent (nullable, [n_queries]): 1 when two of the best k+1 merged distances are equal or
- * NaN, i.e. the reference's order depends on its whole heap history, which no single rank holds.  More than 128
- * queries are pipelined in micro-batches of 256: a worker thread sweeps the next one while this thread exchanges
- * and merges.
+ * words).  More than 128 queries are pipelined in micro-batches of 256: a worker thread sweeps the next one while
+ * this thread exchanges and merges.
+ * out_history_dependent (nullable, [n_queries]): 1 when two of the best k+1 merged distances are equal or NaN, i.e.
+ * the reference's order depends on its whole heap history, which no single rank holds.  With tie_mode 0 (default)
+ * such a query is then answered EXACTLY as the unsharded collection would: the heap travels rank 0 -> 1 -> ... in
+ * visit order, each rank replaying consider() over its own rows (G more small all-gathers for the flagged queries
+ * of the call together), so N > 1 returns what N = 1 returns, order included.
+ *
+ * Failure semantics of every collective call (this one, szg_search_radius_sharded, szg_comm_merge_*): a rank whose
+ * own search or allocation fails still enters every exchange of the call and marks its contribution, so EVERY rank
+ * returns an error and none waits for a peer that never comes.  The one case left to the host's own timeout is a
+ * transport failure part-way through an exchange (HIP / RCCL error between enqueue and wait on one rank).
  */
 int szg_search_topk_sharded(szg_index *ix, const double *queries, int n_queries, int k, const uint64_t *allow_bits,
                             uint64_t *out_rows, double *out_dist, int32_t *out_count, uint8_t *out_history_dependent);
 /* szg_search_radius_batch over the sharded collection: an all-gather of the hit counts, one padded all-gather of
- * (row, distance) records, the reference's push-all / pop-all heap over the union in row order. */
+ * (row, distance) records, the reference's push-all / pop-all heap over the union in row order.
+ * `capacity` may differ between ranks: SZG_E_TRUNCATED (out_offsets complete) is a LOCAL condition -- fetch the
+ * answer again with szg_comm_last_radius and a buffer of out_offsets[n_queries] entries; never repeat the
+ * collective call on the truncated ranks only. */
 int szg_search_radius_sharded(szg_index *ix, const double *queries, int n_queries, const double *radii,
                               const uint64_t *allow_bits, uint64_t *out_rows, double *out_dist, uint64_t capacity,
                               uint64_t *out_offsets);
@@ -237,12 +251,28 @@ int szg_comm_merge_topk(szg_comm *c, int k, int n_queries, const uint64_t *rows,
 int szg_comm_merge_radius(szg_comm *c, int n_queries, const uint64_t *offsets, const uint64_t *rows,
                           const double *dist, uint64_t *out_rows, double *out_dist, uint64_t capacity,
                           uint64_t *out_offsets);
+/* The merged answer of this communicator's LAST radius call again (not collective): what a rank whose buffer was too
+ * small calls after SZG_E_TRUNCATED. */
+int szg_comm_last_radius(szg_comm *c, int n_queries, uint64_t *out_rows, double *out_dist, uint64_t capacity,
+                         uint64_t *out_offsets);
+/*
+ * The heap chain on its own (what szg_search_topk_sharded runs for its flagged queries): `replay` continues the
+ * reference's heap -- container/heap's array, heap_n entries of (row, distance), element for element -- over THIS
+ * rank's rows of flagged query j in visit order (consider()'s top-k branch, collection.go:606-619) and returns 0.
+ * Collective: rank g replays in round g.  out_* [n_flagged][k].
+ */
+typedef int (*szg_replay_fn)(void *user, int j, int k, uint64_t *heap_rows, double *heap_dist, int32_t *heap_n);
+int szg_comm_chain_topk(szg_comm *c, int k, int n_flagged, szg_replay_fn replay, void *user, uint64_t *out_rows,
+                        double *out_dist, int32_t *out_count);
 
 typedef struct szg_comm_stats {
     uint64_t exchanges;   /* all-gathers issued */
     double exchange_us;   /* wall time inside them (copies + collective + wait) */
     double host_us;       /* packing the records and merging the gathered lists */
     int rccl_ranks;       /* ncclCommCount of the communicator (0: host transport) */
+    int zero_copy;        /* RCCL: the collective reads / writes the pinned host staging itself (no H2D / D2H copies) */
+    uint64_t chained_replays; /* top-k queries whose merged answer held equal distances and was settled by the
+                                 rank-to-rank heap chain (the reference's order, collection.go:606-619) */
 } szg_comm_stats;
 int szg_comm_get_stats(szg_comm *c, szg_comm_stats *out);
 int szg_comm_reset_stats(szg_comm *c);
@@ -375,6 +405,10 @@ int szg_index_synth(szg_index *ix, uint64_t n_rows, uint64_t seed, uint64_t firs
 /* Global row index of this handle's row 0 (multi-process sharding); rows
  * returned by szg_search_* are local + base. */
 int szg_index_set_row_base(szg_index *ix, uint64_t base);
+
+/* Test hook: what = 1: the next `value` growths of this rank's exchange staging fail (SZG_E_NOMEM), as an allocation
+ * failure on ONE rank of a job would. */
+int szg_comm_debug_inject(szg_comm *c, int what, int value);
 
 #ifdef __cplusplus
 }

@@ -206,6 +206,64 @@ def all_distances(rows, dim, bits, metric, query):
     return out
 
 
+class GoHeap:
+    """The reference's result heap, element for element (small cases only: pure Python).
+
+    Go's container/heap (Push = append + up, Pop = swap(0, n) + down(0, n) + remove last) over
+    resultPriorityQueue (collection.go:536-564): Less(i, j) = priority[i] > priority[j], a max-heap on distance.
+    `items` is the heap's ARRAY -- (row, distance) pairs in container/heap's own order -- so that a replay can be
+    continued from a state another party left (the rank-to-rank chain of csrc/scan_comm.cpp)."""
+
+    def __init__(self, items=()):
+        self.a = [(int(r), float(d)) for r, d in items]
+
+    def _less(self, i, j):
+        return self.a[i][1] > self.a[j][1]
+
+    def _up(self, j):
+        while True:
+            i = (j - 1) // 2 if j > 0 else 0      # Go: (j - 1) / 2 truncates toward zero, so the parent of 0 is 0
+            if i == j or not self._less(j, i):
+                break
+            self.a[i], self.a[j] = self.a[j], self.a[i]
+            j = i
+
+    def _down(self, i0, n):
+        i = i0
+        while True:
+            j1 = 2 * i + 1
+            if j1 >= n or j1 < 0:
+                break
+            j = j1
+            if j1 + 1 < n and self._less(j1 + 1, j1):
+                j = j1 + 1
+            if not self._less(j, i):
+                break
+            self.a[i], self.a[j] = self.a[j], self.a[i]
+            i = j
+
+    def push(self, row, dist):
+        self.a.append((int(row), float(dist)))
+        self._up(len(self.a) - 1)
+
+    def pop(self):
+        n = len(self.a) - 1
+        self.a[0], self.a[n] = self.a[n], self.a[0]
+        self._down(0, n)
+        return self.a.pop()
+
+    def consider_topk(self, row, dist, k):
+        """consider()'s top-k branch for one visited record (collection.go:606-619)."""
+        if len(self.a) <= k:
+            if len(self.a) < k or self.a[0][1] > dist:
+                self.push(row, dist)
+                if len(self.a) > k:
+                    self.pop()
+
+    def items(self):
+        return list(self.a)
+
+
 def sorted_id_order(ids):
     ids = np.ascontiguousarray(ids, dtype=np.uint64)
     perm = np.zeros(ids.size, dtype=np.uint64)

@@ -34,15 +34,19 @@ EXPORTS = [
     "szg_search_radius_batch", "szg_comm_unique_id", "szg_comm_create", "szg_comm_create_host", "szg_comm_destroy",
     "szg_comm_reserve", "szg_index_attach_comm", "szg_search_topk_sharded", "szg_search_radius_sharded",
     "szg_comm_merge_topk", "szg_comm_merge_radius", "szg_comm_get_stats", "szg_comm_reset_stats",
+    "szg_comm_last_radius", "szg_comm_chain_topk", "szg_comm_debug_inject",
 ]
 SZG_COMM_ID_BYTES = 128
 # int (*szg_allgather_fn)(void *user, const void *send, void *recv, uint64_t bytes_per_rank)
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64)
+# int (*szg_replay_fn)(void *user, int j, int k, uint64_t *heap_rows, double *heap_dist, int32_t *heap_n)
+REPLAY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64),
+                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32))
 
 
 class SzgCommStats(ctypes.Structure):
     _fields_ = [("exchanges", ctypes.c_uint64), ("exchange_us", ctypes.c_double), ("host_us", ctypes.c_double),
-                ("rccl_ranks", ctypes.c_int)]
+                ("rccl_ranks", ctypes.c_int), ("zero_copy", ctypes.c_int), ("chained_replays", ctypes.c_uint64)]
 
 # include/syzgy_pager.h
 PAGER_EXPORTS = [
@@ -188,6 +192,12 @@ def load():
     L.szg_comm_get_stats.argtypes = [vp, ctypes.POINTER(SzgCommStats)]
     L.szg_comm_reset_stats.restype = ctypes.c_int
     L.szg_comm_reset_stats.argtypes = [vp]
+    L.szg_comm_last_radius.restype = ctypes.c_int
+    L.szg_comm_last_radius.argtypes = [vp, ctypes.c_int, u64p, f64p, ctypes.c_uint64, u64p]
+    L.szg_comm_chain_topk.restype = ctypes.c_int
+    L.szg_comm_chain_topk.argtypes = [vp, ctypes.c_int, ctypes.c_int, REPLAY_FN, vp, u64p, f64p, i32p]
+    L.szg_comm_debug_inject.restype = ctypes.c_int
+    L.szg_comm_debug_inject.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.szg_pager_open.restype = ctypes.c_int
     L.szg_pager_open.argtypes = [ctypes.POINTER(vp), ctypes.c_char_p, ctypes.c_int]
     L.szg_pager_close.restype = None

@@ -191,7 +191,6 @@ hipError_t launch_mq_thr(const uint64_t *lists, int kp, int n_queries, float *th
 // per query: the kp best of its candidate buffer, sorted, as one list [n_queries][kp]
 hipError_t launch_cand_select(const uint64_t *cand_buf, const uint32_t *cand_count, uint32_t cand_cap,
                               int kp, int n_queries, uint64_t *lists, hipStream_t stream);
-size_t mq_lds_bytes(int qbits, int r16, int nb);
 // The tail of a fused-selection batch in one launch (kernels_mq.hip: cand_refine_kernel): the kp best of each query's
 // collected candidates -- mode 0: by the collected key; 1 / 2 (bfloat16 sweeps, cosine / euclid): the candidates
 // within the sweep's error band of the kp-th best are scored again in float32 first, band_edge[q] tells the host
@@ -225,7 +224,6 @@ hipError_t launch_mq_score_i8(int row_bits, const MqArgs &a, int nb, int grid, h
 size_t mq_bf16_image_bytes(int row_bits, int r16, int nb);
 size_t mq_bf16_lds_bytes(int row_bits, int r16, int nb);
 hipError_t launch_mq_score_bf16(int row_bits, const MqArgs &a, int nb, int grid, hipStream_t stream);  // 32- or 16-bit rows
-hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStream_t stream);  // a.metric picks the key
 hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_rows,
                             const uint64_t *live_bits, const uint64_t *allow_bits,
                             uint32_t allow_stride, int kp, int n_queries, int blocks_per_query,

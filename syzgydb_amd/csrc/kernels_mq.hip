@@ -1,33 +1,28 @@
-// kernels_mq.hip -- multi-query sweep for gfx950: B queries per pass of the corpus.
+// kernels_mq.hip -- shared (multi-query) sweeps for gfx950: B queries per pass of the corpus.
 //
-// The single-query scan (kernels_scan.hip) is HBM-bound: every query costs one
-// full sweep.  When the caller hands over a batch (szg_search_topk with
-// n_queries > 1, the reference's concurrent Searches under RLock), the sweep is
-// shared: the corpus streams through once and the B query x row dot products
-// go to the matrix cores.
+// The single-query scan (kernels_scan.hip) is HBM-bound: every query costs one full sweep.  When the caller hands
+// over a batch (szg_search_topk with n_queries > 1, the reference's concurrent Searches under RLock,
+// collection.go:570), the sweep is shared: the corpus streams through once and the B query x row dot products go to
+// the matrix cores.
 //
-//   mq_score_kernel   v_mfma_f32_16x16x4_f32 (f32 in / f32 acc, bit-for-bit a
-//                     k-ordered fmaf chain): a wave owns a tile of 16 rows, lane l
-//                     loads 16 bytes of row (l & 15), 16-byte chunk (l >> 4) of
-//                     each 64-byte step; the same 4 floats are the B operand of 4
-//                     MFMAs per block of 16 queries, whose A operand (the
-//                     queries) comes from LDS with one ds_read_b128.  Row norms
-//                     are VALU side work.  Output: the score matrix
-//                     keys[B][n_rows] (float, the same -cos key the single-query
-//                     scan ranks by; +B*4 bytes per row of HBM writes).
-//   mq_select_kernel  per query, thresholded selection of the kp best keys
-//                     (per-wave sorted LDS lists as in the scan), one sorted list
-//                     per (query, block); the usual merge / float64 rerank /
-//                     certification tail follows.
+//   mq_score_bf16s_kernel  64-, 32- and 16-bit rows: rows and queries rounded to bfloat16 on the fly,
+//                          v_mfma_f32_16x16x32_bf16; the sweep only RANKS -- its candidates are scored again in
+//                          float32, re-ranked in float64 and certified against the bfloat16 bound.
+//   mq_score_i8(s)_kernel  8- and 4-bit rows: exact integer arithmetic, v_mfma_i32_16x16x64_i8 on the row bytes
+//                          against int8 digit planes of the query.
+//   mq_thr_radix_kernel, mq_select_kernel, cand_refine_kernel, cand_rescore_kernel, cand_select_kernel
+//                          thresholds of the fused selection, per-query selection over a score matrix or over the
+//                          collected candidates, the float32 re-score of a bfloat16 sweep's band.
 //
-// 4/8/16/32-bit rows, cosine; 64-bit rows and the Euclidean metric take the
-// single-query path.
+// A wave owns a tile of 16 rows; the D layout of the 16x16 product is column = lane & 15 (the tile's row),
+// row = (lane >> 4) * 4 + reg (the query inside its block of 16).  (Round 4 removed the float32 MFMA form,
+// v_mfma_f32_16x16x4_f32 at 62 % of its matrix roof: every width has an HBM-bound sweep now.)
 #include "kernels.h"
 #include "device_lists.h"
 
-// Built six times (parallel build, like kernels_scan.hip): -DSZG_MQ_PART=4/16/32 and 8
-// carry mq_score_kernel for one element width, -DSZG_MQ_PART=1 the int8 sweep, and the
-// default (0) the selection kernels and the dispatchers.
+// Built once per part (parallel build, like kernels_scan.hip): -DSZG_MQ_PART=1 / 2 carry the int8 sweeps for 8- / 4-bit
+// rows, 3 / 116 / 164 the bfloat16 sweep for 32- / 16- / 64-bit rows, and the default (0) the selection kernels and
+// the dispatchers.
 #ifndef SZG_MQ_PART
 #define SZG_MQ_PART 0
 #endif
@@ -92,37 +87,6 @@ __device__ __forceinline__ void stage_image(uint4 *dst, const uint4 *src, int n1
         for (int u = 0; u < U; u++) dst[i + u * nthreads] = v[u];
     }
     for (; i < n16; i += nthreads) dst[i] = src[i];
-}
-
-// Elements of one 16-byte piece as exact float32 values.  Float rows as they are;
-// quantized rows as the odd integer n = 2v - maxInt (dequantize(v) = n / maxInt up
-// to rounding; the common 1/maxInt cancels in -cos).  Elements past `dim` (row
-// padding) read as 0.
-template <int QBITS, bool CHECK = true>
-__device__ __forceinline__ void decode_dword(uint32_t w, int e0, int dim, float *x)
-{
-    constexpr int N = 32 / QBITS;  // elements per dword
-    if (QBITS == 32) {
-        x[0] = __uint_as_float(w);
-    } else if (QBITS == 16) {
-        x[0] = fmaf((float)(w & 0xFFFFu), 2.0f, -65535.0f);
-        x[1] = fmaf((float)(w >> 16), 2.0f, -65535.0f);
-    } else if (QBITS == 8) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) x[k] = fmaf((float)((w >> (8 * k)) & 0xFFu), 2.0f, -255.0f);
-    } else {  // 4-bit: byte b holds element 2b in its high nibble, 2b+1 in its low nibble
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t byte = (w >> (8 * k)) & 0xFFu;
-            x[2 * k] = fmaf((float)(byte >> 4), 2.0f, -15.0f);
-            x[2 * k + 1] = fmaf((float)(byte & 0xFu), 2.0f, -15.0f);
-        }
-    }
-    if (CHECK && QBITS != 32 && e0 + N > dim) {
-#pragma unroll
-        for (int i = 0; i < N; i++)
-            if (e0 + i >= dim) x[i] = 0.0f;
-    }
 }
 
 // Fused selection.  A (query, row) pair whose key is at or below the query's threshold goes
@@ -204,295 +168,6 @@ __device__ __forceinline__ void offer_tile_hits(const MqArgs &a, HitBuf &hb, int
                 hit_offer(a, hb, lane, (hm >> (b * 4 + r)) & 1u, qoff + b * 16 + c * 4 + r, row, keys[b][r]);
 }
 
-#if SZG_MQ_PART >= 4 && SZG_MQ_PART < 100
-// LDS image of the batch: [piece j][query block][group of 4 elements][query 16][4 floats]
-// FAST: rows are whole 64-byte steps of real elements (r16 % 4 == 0, dim a multiple of the
-// elements per piece) -- no per-piece range predicates, the row and LDS addresses advance
-// by constants.  MFMA and VALU instructions do not co-issue on this part (PMC:
-// SQ_VALU_MFMA_COEXEC_CYCLES = 0), so every VALU instruction shaved off the piece loop
-// is matrix-core time gained: 43 -> ~10 per piece.
-template <int NB, int QBITS, int METRIC, bool COLLECT, bool FAST = false>
-__global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
-{
-    constexpr int E = 128 / QBITS;  // elements per 16-byte piece
-    constexpr int G4 = E / 4;       // groups of 4 elements per piece
-    constexpr int N = 32 / QBITS;   // elements per dword
-    extern __shared__ __align__(16) uint8_t smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int nwaves = blockDim.x >> 6;
-    const int r16 = a.r16;           // 16-byte pieces per row
-    const int steps = (r16 + 3) / 4; // 64-byte steps per row
-    const RowLayout mlay{a.pitch, a.tiled, a.steps};
-    const uint32_t istep = a.tiled ? 1024u : 64u;  // bytes from one 64-byte step of a row to the next
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
-        uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        const int n = r16 * NB * G4 * 16;
-        stage_image(dst, src, n, tid, blockDim.x);
-        if (COLLECT && tid < 48)
-            reinterpret_cast<float *>(smem + (size_t)n * 16)[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
-    }
-    __syncthreads();
-    const float4 *qlds = reinterpret_cast<const float4 *>(smem);
-    const float *thr_lds = reinterpret_cast<const float *>(smem + (size_t)r16 * NB * G4 * 16 * 16);
-    HitBuf hb;
-    {
-        uint8_t *base = smem + (size_t)r16 * NB * G4 * 16 * 16 + 48 * sizeof(float);
-        hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
-        hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
-        hb.n = 0;
-    }
-
-    const int trow = lane & 15;
-    const int c = lane >> 4;
-    const uint64_t n_tiles = ((uint64_t)a.n_rows + 15) / 16;
-    const uint64_t tile_stride = (uint64_t)gridDim.x * nwaves;
-    const uint64_t tile_first = (uint64_t)blockIdx.x * nwaves + wave;
-    const uint64_t n_it = tile_first < n_tiles ? (n_tiles - tile_first + tile_stride - 1) / tile_stride : 0;
-    const uint64_t NP = n_it * (uint64_t)steps;
-
-    // issue cursor
-    uint64_t itile = tile_first;
-    int is = 0;
-    // consume cursor
-    uint64_t ctile = tile_first;
-    int cs = 0;
-
-    u32x4 ring[kRingMq];
-    f32x4 acc[NB];
-#pragma unroll
-    for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float nrm = 0.f;
-    uint32_t nz = 0;
-    float4 qn[NB];  // A operands of the group about to be multiplied (one ahead)
-#pragma unroll
-    for (int b = 0; b < NB; b++) qn[b] = qlds[((min(c, r16 - 1) * NB + b) * G4) * 16 + trow];
-
-    // FAST cursors: the lane's next piece in HBM and its A operands' slot in LDS
-    auto row_ptr = [&](uint64_t tile) -> const uint8_t * {
-        const uint64_t r = min(tile * 16 + trow, (uint64_t)a.n_rows - 1);  // past the end: a valid row, discarded
-        return a.rows + piece_offset(mlay, r, (uint32_t)c);
-    };
-    const uint8_t *iptr = row_ptr(tile_first);
-    const int qbase = c * NB * G4 * 16 + trow;  // float4 index of (this lane's chunk, step 0)
-    const int qstep = 4 * NB * G4 * 16;         // per 64-byte step
-
-#define MQF_ISSUE(u)                                                                     \
-    {                                                                                    \
-        ring[u] = load_nt(iptr);                                                         \
-        if (++is == steps) {                                                             \
-            is = 0;                                                                      \
-            itile += tile_stride;                                                        \
-            iptr = row_ptr(itile);                                                       \
-        } else {                                                                         \
-            iptr += istep;                                                               \
-        }                                                                                \
-    }
-
-#define MQF_CONSUME(u)                                                                   \
-    {                                                                                    \
-        const u32x4 v_ = ring[u];                                                        \
-        const uint32_t w_[4] = {v_.x, v_.y, v_.z, v_.w};                                 \
-        float x_[E];                                                                     \
-        _Pragma("unroll") for (int d = 0; d < 4; d++)                                    \
-            decode_dword<QBITS, false>(w_[d], 0, 0, x_ + d * N);                         \
-        _Pragma("unroll") for (int i = 0; i < E; i++) nrm = fmaf(x_[i], x_[i], nrm);     \
-        const int qcur_ = qbase + cs * qstep;                                            \
-        const int qnext_ = qbase + (cs + 1 == steps ? 0 : cs + 1) * qstep;               \
-        _Pragma("unroll") for (int g = 0; g < G4; g++)                                   \
-        {                                                                                \
-            float4 qc_[NB];                                                              \
-            _Pragma("unroll") for (int b = 0; b < NB; b++) qc_[b] = qn[b];               \
-            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
-                qn[b] = g + 1 < G4 ? qlds[qcur_ + (b * G4 + g + 1) * 16]                 \
-                                   : qlds[qnext_ + (b * G4) * 16];                       \
-            /* element-major: consecutive MFMAs feed different accumulators */           \
-            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc_[b].x, x_[4 * g], acc[b], 0, 0, 0);     \
-            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc_[b].y, x_[4 * g + 1], acc[b], 0, 0, 0); \
-            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc_[b].z, x_[4 * g + 2], acc[b], 0, 0, 0); \
-            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc_[b].w, x_[4 * g + 3], acc[b], 0, 0, 0); \
-        }                                                                                \
-        if (QBITS == 32) {                                                               \
-            nz |= v_.x | v_.y;                                                           \
-            nz |= v_.z | v_.w;                                                           \
-        }                                                                                \
-        if (++cs == steps) {                                                             \
-            if (QBITS == 32) nz &= 0x7FFFFFFFu; else nz = 1u;                            \
-            finish_tile(ctile);                                                          \
-            cs = 0;                                                                      \
-            ctile += tile_stride;                                                        \
-        }                                                                                \
-    }
-
-#define MQ_ISSUE(u)                                                                      \
-    {                                                                                    \
-        const uint64_t row_ = itile * 16 + trow;                                         \
-        const int j_ = is * 4 + c;                                                       \
-        const bool ok_ = row_ < a.n_rows && j_ < r16;                                    \
-        ring[u] = load_nt(ok_ ? a.rows + piece_offset(mlay, row_, (uint32_t)j_) : a.zero16); \
-        if (++is == steps) {                                                             \
-            is = 0;                                                                      \
-            itile += tile_stride;                                                        \
-        }                                                                                \
-    }
-
-    // One 16-byte piece: every decoded element is the B operand of one MFMA per query
-    // block; the A operands (4 consecutive elements of 16 queries) come from LDS with
-    // one ds_read_b128 per block.  Lanes whose piece is out of range hold the dummy
-    // zero piece; for quantized rows that decodes to -maxInt, so they are skipped by
-    // multiplying with a zero query (the image is zero there) and masked out of the norm.
-#define MQ_CONSUME(u)                                                                    \
-    {                                                                                    \
-        const u32x4 v_ = ring[u];                                                        \
-        const uint32_t w_[4] = {v_.x, v_.y, v_.z, v_.w};                                 \
-        const int jraw_ = cs * 4 + c;                                                    \
-        const bool in_ = jraw_ < r16;                                                    \
-        const int j_ = in_ ? jraw_ : r16 - 1;                                            \
-        float x_[E];                                                                     \
-        _Pragma("unroll") for (int d = 0; d < 4; d++)                                    \
-            decode_dword<QBITS>(w_[d], in_ ? j_ * E + d * N : a.dim, a.dim, x_ + d * N); \
-        _Pragma("unroll") for (int i = 0; i < E; i++) nrm = fmaf(x_[i], x_[i], nrm);     \
-        /* the A operands of the NEXT group of 4 elements (or of the next piece's first   \
-           group) are fetched from LDS before this group's MFMAs issue, so the reads'    \
-           latency hides behind 4*NB MFMAs instead of stalling them */                   \
-        const int csn_ = cs + 1 == steps ? 0 : cs + 1;                                   \
-        const int jn_ = min(csn_ * 4 + c, r16 - 1);                                      \
-        _Pragma("unroll") for (int g = 0; g < G4; g++)                                   \
-        {                                                                                \
-            float4 qc_[NB];                                                              \
-            _Pragma("unroll") for (int b = 0; b < NB; b++) qc_[b] = qn[b];               \
-            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
-                qn[b] = g + 1 < G4 ? qlds[((j_ * NB + b) * G4 + g + 1) * 16 + trow]      \
-                                   : qlds[((jn_ * NB + b) * G4) * 16 + trow];            \
-            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
-            {                                                                            \
-                const float4 q_ = qc_[b];                                                \
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.x, x_[4 * g], acc[b], 0, 0, 0);     \
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.y, x_[4 * g + 1], acc[b], 0, 0, 0); \
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.z, x_[4 * g + 2], acc[b], 0, 0, 0); \
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(q_.w, x_[4 * g + 3], acc[b], 0, 0, 0); \
-            }                                                                            \
-        }                                                                                \
-        if (QBITS == 32)                                                                 \
-            nz |= (v_.x | v_.y | v_.z | v_.w) & 0x7FFFFFFFu;                             \
-        else                                                                             \
-            nz |= in_ ? 1u : 0u; /* quantized elements are never zero */                 \
-        if (++cs == steps) {                                                             \
-            finish_tile(ctile);                                                          \
-            cs = 0;                                                                      \
-            ctile += tile_stride;                                                        \
-        }                                                                                \
-    }
-
-
-    // a row tile is done: row norms across the 4 chunk lanes, keys out
-    auto finish_tile = [&](uint64_t tile) {
-        nrm += __shfl_xor(nrm, 16);
-        nrm += __shfl_xor(nrm, 32);
-        nz |= __shfl_xor(nz, 16);
-        nz |= __shfl_xor(nz, 32);
-        const uint64_t row = tile * 16 + trow;
-        const float inv = __frsqrt_rn(nrm);
-        // D layout of the 16x16 product: column = lane & 15 (the tile's row),
-        // row = (lane >> 4) * 4 + reg (the query inside its block of 16)
-        if (COLLECT || row < a.n_rows) {
-            float keys[NB][4];
-            uint32_t hm = 0;
-            const bool row_ok = row < a.n_rows;
-#pragma unroll
-            for (int b = 0; b < NB; b++) {
-                // the four queries of this lane in block b are consecutive: one 16-byte LDS read
-                const float4 th = COLLECT ? *reinterpret_cast<const float4 *>(thr_lds + b * 16 + c * 4)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float thv[4] = {th.x, th.y, th.z, th.w};
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int q = b * 16 + c * 4 + r;
-                    float key;
-                    if (METRIC == kCosine) {
-                        key = -acc[b][r] * inv;
-                        if (nrm == 0.f) key = nz ? -2.0f : 1.0f;  // zero row: distance 1.0 (collection.go:828-830)
-                        if (QBITS == 32 && !(nrm <= 3.0e38f)) key = -2.0f;  // norm overflow: forced in (see RowAcc::finish)
-                    } else {  // |x - q|^2 = |x|^2 - 2 x.q + |q|^2 (the error bound knows: key_eps, mq)
-                        key = fmaf(-2.0f, acc[b][r], nrm + a.qnorm2[q < 48 ? q : 47]);
-                    }
-                    if (!(key == key)) key = 3.0e38f;
-                    if (key > 3.0e38f) key = 3.0e38f;
-                    keys[b][r] = key;
-                    if (COLLECT)
-                        hm |= (row_ok && q < a.n_queries && key <= thv[r]) ? (1u << (b * 4 + r)) : 0u;
-                    else if (q < a.n_queries)
-                        a.keys[(size_t)q * a.key_stride + row] = key;
-                }
-            }
-            if (COLLECT) offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row);
-        }
-        // gfx9 counts loads and stores in ONE vmcnt and they retire out of order with
-        // respect to each other, so with a key store possibly pending the compiler can only
-        // wait for a ring slot with vmcnt(0) -- which also waits for the load just issued
-        // and serialises the ring.  Draining here, once per tile, lets every wait inside
-        // the tile be a counted one.  (The fused-selection form stores nothing here; its rare
-        // hit flush drains itself.)
-        if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
-#pragma unroll
-        for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        nrm = 0.f;
-        nz = 0;
-    };
-
-    // Unconditional prologue (a load past the wave's share reads the dummy piece and is
-    // never consumed) and pinned issue order: the compiler can then wait for slot u with
-    // vmcnt(kRingMq - 1) instead of draining the queue.
-#define MQ_RUN_RING(ISSUE, CONSUME)                                                      \
-    {                                                                                    \
-        uint64_t issued = kRingMq, consumed = 0;                                         \
-        _Pragma("unroll") for (int u = 0; u < kRingMq; u++)                              \
-        {                                                                                \
-            ISSUE(u)                                                                     \
-            __builtin_amdgcn_sched_barrier(0);                                           \
-        }                                                                                \
-        while (consumed + 2 * kRingMq <= NP) {                                           \
-            _Pragma("unroll") for (int u = 0; u < kRingMq; u++)                          \
-            {                                                                            \
-                CONSUME(u)                                                               \
-                ISSUE(u)                                                                 \
-                __builtin_amdgcn_sched_barrier(0);                                       \
-            }                                                                            \
-            consumed += kRingMq;                                                         \
-            issued += kRingMq;                                                           \
-        }                                                                                \
-        while (consumed < NP) {                                                          \
-            _Pragma("unroll") for (int u = 0; u < kRingMq; u++)                          \
-            {                                                                            \
-                if (consumed < NP) {                                                     \
-                    CONSUME(u)                                                           \
-                    consumed++;                                                          \
-                    if (issued < NP) {                                                   \
-                        ISSUE(u)                                                         \
-                        issued++;                                                        \
-                    }                                                                    \
-                }                                                                        \
-            }                                                                            \
-        }                                                                                \
-    }
-    if (FAST)
-        MQ_RUN_RING(MQF_ISSUE, MQF_CONSUME)
-    else
-        MQ_RUN_RING(MQ_ISSUE, MQ_CONSUME)
-#undef MQF_ISSUE
-#undef MQF_CONSUME
-#undef MQ_ISSUE
-#undef MQ_CONSUME
-    if (COLLECT) hit_flush(a, hb, lane);
-}
-
-#endif  // SZG_MQ_PART >= 4 (float32 sweeps)
 
 #if SZG_MQ_PART == 3 || SZG_MQ_PART == 116
 // ---- bfloat16 shared sweep, 32-bit rows ---------------------------------------------------------------------------
@@ -508,7 +183,7 @@ __global__ __launch_bounds__(1024) void mq_score_kernel(const MqArgs a)
 //
 // A wave owns a tile of 16 rows and multiplies 32 elements of them per step with one A operand per
 // query block (image [32-element step][query block][lane = k-group*16 + query][8 bf16]).  Row
-// norms (of the float32 values) are VALU side work as in mq_score_kernel.  Any dimension: rows are walked in
+// norms (of the float32 values) are VALU side work.  Any dimension: rows are walked in
 // 128-byte steps and the chunks of a short last step that lie past the row are read as zeros.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -771,7 +446,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
             }
             if (COLLECT) offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row);
         }
-        if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores (see mq_score_kernel)
+        if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores: gfx9 counts loads and stores in ONE vmcnt, a pending store would turn every ring wait into vmcnt(0)
 #pragma unroll
         for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
         nrm_a = nrm_b = 0.f;
@@ -1044,7 +719,7 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
             }
             if (COLLECT) offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row, qoff);
         }
-        if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores (see mq_score_kernel)
+        if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores: gfx9 counts loads and stores in ONE vmcnt, a pending store would turn every ring wait into vmcnt(0)
 #pragma unroll
         for (int p = 0; p < NPL; p++)
 #pragma unroll
@@ -1834,76 +1509,10 @@ hipError_t launch_cand_refine(int mode, const uint8_t *rows, uint32_t pitch, int
     return go(&cand_refine_kernel<2>);
 }
 
-size_t mq_lds_bytes(int qbits, int r16, int nb) { return (size_t)r16 * nb * (128 / qbits) * 16 * 4; }  // image only
-
 #endif
 
-#if SZG_MQ_PART >= 4 && SZG_MQ_PART < 100
-namespace {
-template <int NB, int QBITS, int METRIC, bool COLLECT, bool FAST>
-hipError_t launch_mq_score_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
-{
-    hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void *>(&mq_score_kernel<NB, QBITS, METRIC, COLLECT, FAST>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mq_score_kernel<NB, QBITS, METRIC, COLLECT, FAST>), dim3(grid), dim3(1024), lds, stream,
-                       a);
-    return hipGetLastError();
-}
-template <int NB, int QBITS>
-hipError_t launch_mq_score_m(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
-{
-    if (a.collect) {  // the full sweep: predicate-free kernel when the row shape allows
-        const bool fast = a.r16 % 4 == 0 && a.dim % (128 / QBITS) == 0 && a.n_rows > 0;
-        if (fast) {
-            if (a.metric == kCosine)
-                return launch_mq_score_t<NB, QBITS, kCosine, true, true>(a, grid, lds, stream);
-            return launch_mq_score_t<NB, QBITS, kEuclidean, true, true>(a, grid, lds, stream);
-        }
-        if (a.metric == kCosine) return launch_mq_score_t<NB, QBITS, kCosine, true, false>(a, grid, lds, stream);
-        return launch_mq_score_t<NB, QBITS, kEuclidean, true, false>(a, grid, lds, stream);
-    }
-    if (a.metric == kCosine) return launch_mq_score_t<NB, QBITS, kCosine, false, false>(a, grid, lds, stream);
-    return launch_mq_score_t<NB, QBITS, kEuclidean, false, false>(a, grid, lds, stream);
-}
-template <int QBITS>
-hipError_t launch_mq_score_q(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
-{
-    switch (nb) {
-    case 1: return launch_mq_score_m<1, QBITS>(a, grid, lds, stream);
-    case 2: return launch_mq_score_m<2, QBITS>(a, grid, lds, stream);
-    case 3: return launch_mq_score_m<3, QBITS>(a, grid, lds, stream);
-    default: return hipErrorInvalidValue;
-    }
-}
-}  // namespace
-
-hipError_t SZG_CAT(launch_mq_score_q, SZG_MQ_PART)(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
-{
-    return launch_mq_score_q<SZG_MQ_PART>(a, nb, grid, lds, stream);
-}
-#endif  // SZG_MQ_PART >= 4 (float32 sweeps)
 
 #if SZG_MQ_PART == 0
-hipError_t launch_mq_score_q4(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
-hipError_t launch_mq_score_q8(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
-hipError_t launch_mq_score_q16(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
-hipError_t launch_mq_score_q32(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
-
-hipError_t launch_mq_score(int qbits, const MqArgs &a, int nb, int grid, hipStream_t stream)
-{
-    // + thresholds and the waves' hit buffers (fused selection)
-    const size_t lds = mq_lds_bytes(qbits, a.r16, nb) + 48 * sizeof(float) + (size_t)16 * kHitCap * 9;
-    switch (qbits) {
-    case 4: return launch_mq_score_q4(a, nb, grid, lds, stream);
-    case 8: return launch_mq_score_q8(a, nb, grid, lds, stream);
-    case 16: return launch_mq_score_q16(a, nb, grid, lds, stream);
-    case 32: return launch_mq_score_q32(a, nb, grid, lds, stream);
-    default: return hipErrorInvalidValue;
-    }
-}
-
 size_t mq_i8_image_bytes(int row_bits, int r16, int nb)
 {
     return (size_t)((r16 + 3) / 4) * kMqPlanes * (row_bits == 4 ? 2 : 1) * nb * 1024;

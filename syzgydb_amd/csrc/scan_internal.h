@@ -418,6 +418,8 @@ void first_eligible_rows(const szg_index *ix, const uint64_t *allow, int k, std:
 int search_topk_impl(szg_index *ix, const double *queries, int n_queries, int k, const uint64_t *allow_bits,
                      uint64_t *out_rows, double *out_dist, int32_t *out_count,
                      const uint64_t *const *allow_ptrs = nullptr);
+// consider()'s top-k branch over every row of the handle in visit order, continuing the heap *h (rows + row_base)
+int replay_rows_into_heap(szg_index *ix, const double *query, const uint64_t *allow, int k, GoHeap *h);
 
 // ---- scan_radius.cpp
 // radius searches for a batch of queries (own radius and filter mask each): results[i] = the hits of query i, ascending

@@ -81,26 +81,6 @@ void build_image_i8(const szg_index *ix, Ctx *c, int nq, int nb, size_t group_st
     }
 }
 
-// float32 sweep: [piece j][query block][group of 4 elements][query 16][4 floats].  Cosine: the normalised queries
-// (q / |q|, so the key is -cos; quantized rows decode to n = maxInt * d and the common factor cancels).  Euclid:
-// maxInt * q for quantized rows (key = |n - maxInt q|^2 = maxInt^2 |d - q|^2, the single-query path's unit).
-void build_image_f32(const szg_index *ix, Ctx *c, int nq, int nb)
-{
-    float *im = reinterpret_cast<float *>(c->h_mq);
-    const int E = 128 / ix->bits, G4 = E / 4;
-    for (int q = 0; q < nq; q++) {
-        const double *src = c->h_q64 + (size_t)q * ix->dim;
-        const double m1 = c->meta[q].m1;
-        double scale = m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0;
-        if (ix->metric != SZG_COSINE) scale = ix->bits <= 16 ? (double)((1u << ix->bits) - 1u) : 1.0;
-        const int b = q / 16, qi = q % 16;
-        for (int e = 0; e < ix->dim; e++) {
-            const int j = e / E, i = e % E, g4 = i / 4, m = i % 4;
-            im[((((size_t)j * nb + b) * G4 + g4) * 16 + qi) * 4 + m] = (float)(src[e] * scale);
-        }
-    }
-}
-
 // ---- one batch through ONE shared sweep --------------------------------------------------------------------------
 
 namespace {
@@ -131,7 +111,7 @@ MqPlan mq_plan(const szg_index *ix, const Shard *sh, int kp, int kp_wide, int nq
     p.bf16 = mq_uses_bf16(ix);
     p.groups = p.i8 ? (nq + 16 * nb - 1) / (16 * nb) : 1;
     p.group_stride = p.i8 ? ((szg::mq_i8_image_bytes(ix->bits, r16, nb) + 3 * 48 * sizeof(float) + 255) & ~(size_t)255) : 0;
-    p.img = p.bf16 ? szg::mq_bf16_image_bytes(ix->bits, r16, nb) : p.i8 ? p.group_stride * p.groups : szg::mq_lds_bytes(ix->bits, r16, nb);
+    p.img = p.bf16 ? szg::mq_bf16_image_bytes(ix->bits, r16, nb) : p.group_stride * p.groups;
     const uint64_t hits = std::max<uint64_t>((uint64_t)ix->mq_hits, 16ull * kp);
     p.prefix = ((sh->n_rows * (uint64_t)kp + hits - 1) / hits + 15) & ~15ull;
     p.prefix = std::max<uint64_t>(p.prefix, 16ull * kp);
@@ -204,7 +184,7 @@ static int upload_mq_image(szg_index *ix, Ctx *c, int nq, int nb, bool bf16, boo
     memset(c->h_mq, 0, img);
     if (bf16) build_image_bf16(ix, c, nq, nb);
     else if (i8) build_image_i8(ix, c, nq, nb, group_stride);
-    else build_image_f32(ix, c, nq, nb);
+    else return fail(SZG_E_INVALID, "no shared sweep for this row width");
     HIPCHK(hipMemcpyAsync(c->d_mq, c->h_mq, img, hipMemcpyHostToDevice, st));
     return SZG_OK;
 }
@@ -276,8 +256,7 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
     const uint32_t words = (uint32_t)shard_words(sh);
     auto launch_score = [&](const szg::MqArgs &x, hipStream_t s2) -> hipError_t {
         if (p.bf16) return szg::launch_mq_score_bf16(ix->bits, x, nb, sh->cu_count, s2);
-        return p.i8 ? szg::launch_mq_score_i8(ix->bits, x, nb, sh->cu_count, s2)
-                    : szg::launch_mq_score(ix->bits, x, nb, sh->cu_count, s2);
+        return szg::launch_mq_score_i8(ix->bits, x, nb, sh->cu_count, s2);
     };
     // The sweep wants every CU to itself (one big block and up to 150 KiB of LDS per CU), so the batch's kernels go
     // onto the shard's scan stream one after the other; uploads -- and for the HBM-bound sweeps (mq_overlap) the
@@ -394,7 +373,8 @@ int enqueue_collect_mq(szg_index *ix, Shard *sh, Ctx *c, int nq, int nb, bool ha
     if (nq > szg::kMqMaxQueries || groups > 2 || (groups == 2 && nb != 3))
         return fail(SZG_E_INVALID, "shared radius sweep: batch too large for the image");
     const size_t group_stride = i8 ? ((szg::mq_i8_image_bytes(ix->bits, r16, nb) + 3 * 48 * sizeof(float) + 255) & ~(size_t)255) : 0;
-    const size_t img = bf16 ? szg::mq_bf16_image_bytes(ix->bits, r16, nb) : i8 ? group_stride * groups : szg::mq_lds_bytes(ix->bits, r16, nb);
+    if (!bf16 && !i8) return fail(SZG_E_INVALID, "no shared sweep for this row width");
+    const size_t img = bf16 ? szg::mq_bf16_image_bytes(ix->bits, r16, nb) : group_stride * groups;
     int rc = upload_mq_image(ix, c, nq, nb, bf16, i8, img, group_stride, c->work);
     if (rc) return rc;
     if (!c->d_thr) HIPCHK(hipMalloc((void **)&c->d_thr, 256 * sizeof(float)));
@@ -420,8 +400,7 @@ int enqueue_collect_mq(szg_index *ix, Shard *sh, Ctx *c, int nq, int nb, bool ha
         }
         if (ix->timing) HIPCHK(hipEventRecord(c->ev_scan0, st));
         if (bf16) HIPCHK(szg::launch_mq_score_bf16(ix->bits, a, nb, sh->cu_count, st));
-        else if (i8) HIPCHK(szg::launch_mq_score_i8(ix->bits, a, nb, sh->cu_count, st));
-        else HIPCHK(szg::launch_mq_score(ix->bits, a, nb, sh->cu_count, st));
+        else HIPCHK(szg::launch_mq_score_i8(ix->bits, a, nb, sh->cu_count, st));
         if (ix->timing) {
             HIPCHK(hipEventRecord(c->ev_scan1, st));
             c->timed_scan = true;

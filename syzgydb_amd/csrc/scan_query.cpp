@@ -220,7 +220,7 @@ double key_eps(const szg_index *ix, double key, const QMeta &m)
            1e-37;
 }
 
-// ---- multi-query sweep (32-bit rows, cosine): B queries share one pass ------------
+// ---- shared sweeps: B queries share one pass of the corpus ------------
 
 bool mq_uses_i8(const szg_index *ix) { return (ix->bits == 8 || ix->bits == 4) && ix->mq_i8; }
 // the bfloat16 sweep: 32- and 16-bit rows of any dimension; not the experimental tiled layout
@@ -269,13 +269,13 @@ void prep_mq_int(const szg_index *ix, const double *q, QMeta *meta, int32_t *Qou
 
 int mq_blocks(const szg_index *ix, int nq)
 {   // query blocks of 16 the batch gets (nq = the queries left in the call), or 0 when the shared sweep does not apply
-    if (!ix->multi_query || ix->bits == 64 || nq < ix->mq_min) return 0;
-    const bool bf16 = mq_uses_bf16(ix);
+    if (!ix->multi_query || nq < ix->mq_min) return 0;
+    const bool bf16 = mq_uses_bf16(ix), i8 = mq_uses_i8(ix);
+    if (!bf16 && !i8) return 0;  // (switched off, or the experimental tiled layout of wide rows): one sweep per query
     int nb = std::min((nq + 15) / 16, std::min(ix->mq_blocks_max, bf16 ? 6 : 3));
     auto fits = [&](int n) {  // the image (+ tables, hit buffers, staging) must fit LDS
         if (bf16) return szg::mq_bf16_lds_bytes(ix->bits, ix->map.r16, n) <= 160u * 1024u;
-        return (mq_uses_i8(ix) ? szg::mq_i8_lds_bytes(ix->bits, ix->map.r16, n)
-                               : szg::mq_lds_bytes(ix->bits, ix->map.r16, n)) <= 150u * 1024u;
+        return szg::mq_i8_lds_bytes(ix->bits, ix->map.r16, n) <= 150u * 1024u;
     };
     while (nb > 0 && !fits(nb)) nb--;
     return nb;

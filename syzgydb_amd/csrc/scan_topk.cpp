@@ -354,10 +354,10 @@ int run_collect(szg_index *ix, Shard *sh, Ctx *c, int slot, float thr_key, bool 
 // consider(), :583-629): float64 distances for all rows on the device, then the
 // heap on the host in visit order.  Bit-faithful in every case, used only when
 // history_dependent() says the fast answer could differ.
-int run_full_replay(szg_index *ix, std::vector<Ctx *> &ctx, int slot, const uint64_t *allow, int k,
-                    std::vector<HeapItem> *res)
+// (h: the heap to continue -- empty for a search of this handle alone; row_add: what makes a row of this handle global)
+static int replay_all_rows(szg_index *ix, std::vector<Ctx *> &ctx, int slot, const uint64_t *allow, int k, GoHeap &h,
+                           uint64_t row_add)
 {
-    GoHeap h;
     for (size_t s = 0; s < ix->shards.size(); s++) {
         Shard *sh = ix->shards[s];
         if (sh->n_rows == 0) continue;
@@ -382,11 +382,50 @@ int run_full_replay(szg_index *ix, std::vector<Ctx *> &ctx, int slot, const uint
         for (size_t r = 0; r < n; r++) {
             if (!((live[r >> 6] >> (r & 63)) & 1)) continue;       // removed record
             if (aw && !((aw[r >> 6] >> (r & 63)) & 1)) continue;   // collection.go:592-594
-            h.consider_topk(sh->first + r, c->h_out[r].dist, k);
+            h.consider_topk(sh->first + r + row_add, c->h_out[r].dist, k);
         }
     }
+    return SZG_OK;
+}
+
+int run_full_replay(szg_index *ix, std::vector<Ctx *> &ctx, int slot, const uint64_t *allow, int k,
+                    std::vector<HeapItem> *res)
+{
+    GoHeap h;
+    const int rc = replay_all_rows(ix, ctx, slot, allow, k, h, 0);
+    if (rc) return rc;
     h.drain(res);
     return SZG_OK;
+}
+
+// consider()'s top-k branch over every row of this handle in visit order, CONTINUING the heap `h` (rows global:
+// + row_base) -- one link of the rank-to-rank chain that settles equal distances across shards (scan_comm.cpp)
+int replay_rows_into_heap(szg_index *ix, const double *query, const uint64_t *allow, int k, GoHeap *h)
+{
+    std::vector<Ctx *> ctx(ix->shards.size(), nullptr);
+    struct Release {
+        szg_index *ix;
+        std::vector<Ctx *> &ctx;
+        ~Release()
+        {
+            for (size_t s = 0; s < ctx.size(); s++)
+                if (ctx[s]) ctx_release(ix->shards[s], ctx[s]);
+        }
+    } release{ix, ctx};
+    for (size_t s = 0; s < ix->shards.size(); s++) {
+        Shard *sh = ix->shards[s];
+        if (sh->n_rows == 0) continue;
+        Ctx *c = ctx[s] = ctx_acquire(sh);
+        HIPCHK(hipSetDevice(sh->device));
+        memcpy(c->h_q64, query, sizeof(double) * ix->dim);
+        HIPCHK(hipMemcpyAsync(c->d_q64, c->h_q64, sizeof(double) * ix->dim, hipMemcpyHostToDevice, c->work));
+    }
+    const int rc = replay_all_rows(ix, ctx, 0, allow, k, *h, ix->row_base);
+    if (rc == SZG_OK) {
+        std::lock_guard<std::mutex> lk(ix->stats_mu);
+        ix->stats.full_replays++;
+    }
+    return rc;
 }
 
 // The first k eligible rows of a query in visit order are pushed by consider() whatever their

@@ -210,7 +210,7 @@ class ScanIndex:
                 return out_rows[:n], out_dist[:n]
             return out_rows[:n], out_dist[:n], n
 
-    def _radius_csr(self, fn, name, queries, radii, allow):
+    def _radius_csr(self, fn, name, queries, radii, allow, refetch=None):
         q = np.ascontiguousarray(queries, dtype=np.float64)
         if q.ndim == 1:
             q = q.reshape(1, -1)
@@ -227,7 +227,13 @@ class ScanIndex:
             rc = fn(self._h, _f64(q), nq, _f64(rad), allow_p, _u64(out_rows), _f64(out_dist), cap, _u64(off))
             if rc == _lib.SZG_E_TRUNCATED:
                 cap = int(off[nq])
-                continue
+                if refetch is None:
+                    continue
+                # a sharded call: the merged answer is kept by the communicator -- fetching it again is local (the
+                # collective itself must never be repeated by some ranks only)
+                out_rows = np.empty(max(cap, 1), dtype=np.uint64)
+                out_dist = np.empty(max(cap, 1), dtype=np.float64)
+                rc = refetch(nq, _u64(out_rows), _f64(out_dist), cap, _u64(off))
             check(rc, name)
             del keep
             return [(out_rows[int(off[i]):int(off[i + 1])], out_dist[int(off[i]):int(off[i + 1])]) for i in range(nq)]
@@ -265,7 +271,9 @@ class ScanIndex:
 
     def search_radius_sharded(self, queries, radii, allow=None):
         """Collective: radius searches over every rank's rows; a list of (rows GLOBAL, dist) per query."""
-        return self._radius_csr(self._L.szg_search_radius_sharded, "szg_search_radius_sharded", queries, radii, allow)
+        comm = self._comm
+        return self._radius_csr(self._L.szg_search_radius_sharded, "szg_search_radius_sharded", queries, radii, allow,
+                                refetch=lambda nq, r, d, cap, off: self._L.szg_comm_last_radius(comm._h, nq, r, d, cap, off))
 
     # -- diagnostics ----------------------------------------------------------
     def set_timing(self, enabled):

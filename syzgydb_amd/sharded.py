@@ -194,22 +194,56 @@ class Comm:
                                                    [np.zeros(0, np.uint64)]))
         dist = np.ascontiguousarray(np.concatenate([np.asarray(d, dtype=np.float64) for _, d in hits] or
                                                    [np.zeros(0, np.float64)]))
+        # The buffer's size is this rank's own business: a too-small one makes the call return SZG_E_TRUNCATED with
+        # the offsets complete, and the answer -- kept by the communicator -- is fetched again LOCALLY.  (Repeating
+        # the collective on the truncated ranks only would pair their all-gathers with the other ranks' next ones.)
         cap = max(1 << 12, 4 * int(off[nq]))
-        while True:
+        out_rows = np.zeros(cap, dtype=np.uint64)
+        out_dist = np.zeros(cap, dtype=np.float64)
+        out_off = np.zeros(nq + 1, dtype=np.uint64)
+        rc = self._L.szg_comm_merge_radius(
+            self._h, nq, _p(off, ctypes.c_uint64), _p(rows, ctypes.c_uint64) if rows.size else None,
+            _p(dist, ctypes.c_double) if dist.size else None, _p(out_rows, ctypes.c_uint64),
+            _p(out_dist, ctypes.c_double), cap, _p(out_off, ctypes.c_uint64))
+        if rc == _lib.SZG_E_TRUNCATED:
+            cap = int(out_off[nq])
             out_rows = np.zeros(cap, dtype=np.uint64)
             out_dist = np.zeros(cap, dtype=np.float64)
-            out_off = np.zeros(nq + 1, dtype=np.uint64)
-            rc = self._L.szg_comm_merge_radius(
-                self._h, nq, _p(off, ctypes.c_uint64), _p(rows, ctypes.c_uint64) if rows.size else None,
-                _p(dist, ctypes.c_double) if dist.size else None, _p(out_rows, ctypes.c_uint64),
-                _p(out_dist, ctypes.c_double), cap, _p(out_off, ctypes.c_uint64))
-            if rc == _lib.SZG_E_TRUNCATED:
-                # (every rank sees the same totals, so every rank repeats the collective)
-                cap = int(out_off[nq])
-                continue
-            _lib.check(rc, "szg_comm_merge_radius")
-            return [(out_rows[int(out_off[i]):int(out_off[i + 1])], out_dist[int(out_off[i]):int(out_off[i + 1])])
-                    for i in range(nq)]
+            rc = self._L.szg_comm_last_radius(self._h, nq, _p(out_rows, ctypes.c_uint64), _p(out_dist, ctypes.c_double),
+                                              cap, _p(out_off, ctypes.c_uint64))
+        _lib.check(rc, "szg_comm_merge_radius")
+        return [(out_rows[int(out_off[i]):int(out_off[i + 1])], out_dist[int(out_off[i]):int(out_off[i + 1])])
+                for i in range(nq)]
+
+    def chain_topk(self, k, n_flagged, replay):
+        """Collective: the rank-to-rank heap chain for n_flagged queries whose merged answer held equal distances.
+        replay(j, heap) -> heap continues the reference's heap -- a list of (row, distance) in container/heap's array
+        order -- over THIS rank's rows of flagged query j in visit order.  Returns (rows [n,k], dist, count)."""
+        def thunk(_user, j, kk, hrows, hdist, hn):
+            try:
+                heap = [(int(hrows[i]), float(hdist[i])) for i in range(hn[0])]
+                heap = replay(int(j), heap)
+                if len(heap) > kk:
+                    return 1
+                for i, (r, d) in enumerate(heap):
+                    hrows[i], hdist[i] = r, d
+                hn[0] = len(heap)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = _lib.REPLAY_FN(thunk)
+        out_rows = np.empty((n_flagged, k), dtype=np.uint64)
+        out_dist = np.empty((n_flagged, k), dtype=np.float64)
+        out_count = np.empty(n_flagged, dtype=np.int32)
+        _lib.check(self._L.szg_comm_chain_topk(self._h, int(k), int(n_flagged), cb, None, _p(out_rows, ctypes.c_uint64),
+                                               _p(out_dist, ctypes.c_double), _p(out_count, ctypes.c_int32)),
+                   "szg_comm_chain_topk")
+        return out_rows, out_dist, out_count
+
+    def debug_inject(self, what, value):
+        _lib.check(self._L.szg_comm_debug_inject(self._h, int(what), int(value)), "szg_comm_debug_inject")
 
 
 class ShardedSearcher:

@@ -158,8 +158,8 @@ def test_shared_sweep_euclidean_far_from_origin():
 @pytest.mark.parametrize("dim,n", [(768, 3000), (1536, 1500), (100, 4000), (37, 900), (64, 2000), (128, 2500), (3, 500)])
 def test_shared_sweep_int8_mfma(bits, metric, dim, n):
     """8- and 4-bit rows take the exact integer sweep (v_mfma_i32_16x16x64_i8 on the queries'
-    int8 digit planes; 4-bit rows as two nibble operands per piece); same bar, and the float32
-    MFMA sweep (mq_i8=0) must agree with it."""
+    int8 digit planes; 4-bit rows as two nibble operands per piece); same bar, and with the sweep switched off
+    (mq_i8=0: one sweep per query) the answers are the same."""
     rows = orc.synth_rows(331 + dim, 0, n, dim, bits)
     Q = orc.synth_vectors(332 + dim, 0, 48, dim)
     Q[7] *= 25.0
@@ -171,7 +171,7 @@ def test_shared_sweep_int8_mfma(bits, metric, dim, n):
             ix.set_option("mq_i8", i8)
             ix.reset_stats()
             check(ix, rows, dim, Q, 10, bits=bits, metric=metric)
-            assert ix.stats()["mq_queries"] == 48
+            assert ix.stats()["mq_queries"] == (48 if i8 else 0)
             check(ix, rows, dim, Q[:17], 33, allow=allow, bits=bits, metric=metric)
 
 
