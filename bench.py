@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec of the exact (brute-force) scan behind Collection.Search.
 
-    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--mode ranks|inproc]
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--mode ranks|inproc] [--parallelism rows|replicas]
 
 A "step" is one exact query over the whole synthetic corpus (one sweep of the packed
 rows through the fused HIP scan; merges, float64 rerank and result assembly included).
@@ -18,6 +18,16 @@ query goes to every shard, "scaling": "strong"):
   --mode inproc  ONE process, one handle with devices=[0..N-1] -- the form the Go binding
                  uses (go/syzgy_gpu.go): shards and merge inside the library.
 
+  --parallelism replicas   (N > 1, --mode ranks) the zero-collective alternative SURVEY.md 8e names for a corpus
+                 that fits one card: every rank holds ALL rows and answers its slice of the K queries (concurrent
+                 Searches under RLock, collection.go:570, one replica per GPU); no exchange in the data path.  The
+                 default stays rows sharded + all-gather (north_star); the line says which mode a number used.
+
+The timed region -- EXACTLY K steps between barrier + synchronize on both sides, results on the host -- is repeated
+R = --repeats times (default 5) on FRESH query sets; "value" is the MEDIAN repeat (ms_per_step x steps = that
+repeat's call), "spread" carries min / max / repeats: one 9 ms call on one box of a pool that differs by +-4 % is not
+a measurement.
+
 Rank 0 prints ONE JSON line: metric/value/unit/..., plus
   "roofline":     HBM roofline of the fused scan kernel from HIP events recorded on the
                   library's scan stream inside the timed region;
@@ -25,7 +35,8 @@ Rank 0 prints ONE JSON line: metric/value/unit/..., plus
                   toolchain in this image) on this box's host cores, bounded sample (N=1);
   "batched":      the shared multi-query sweep on the matrix cores (its own fixed query set);
   "sketch_prepass": the optional 8-bit sketch pre-pass on the headline workload (same answers);
-  "batched_quantized": the shared sweep on 16- / 8- / 4-bit copies of the headline shape (960 queries per call);
+  "batched_quantized": the shared sweep on 64- / 16- / 8- / 4-bit copies of the headline shape (960 queries per call);
+  "lone_call":    sequential ONE-query szg_search_topk calls -- the shape the unchanged Go Search API has;
   "host_us_per_query", "ranks", "rccl_ranks", "other_workloads" (cfg2/cfg3/cfg4/cfg5 per-GPU
                   shards: queries/s and one short roofline object each, peak 8000 GB/s).
 The printed line is the compact form; the full objects (kernels, launch times, PMC traffic, host time
@@ -72,7 +83,7 @@ def log(*a):
 
 
 def _rf(r):
-    return {key: r[key] for key in ("bound", "achieved", "unit", "frac") if key in r}
+    return {key: r[key] for key in ("bound", "achieved", "unit", "frac", "traffic") if key in r}
 
 
 def compact(obj):
@@ -82,10 +93,15 @@ def compact(obj):
     if "batched" in o:
         b = o["batched"]
         o["batched"] = {"value": b["value"], "unit": b["unit"], "queries_per_sweep": b["queries_per_sweep"],
-                        "avg_sweep_ms": b["avg_sweep_ms"], "kernel": b["kernel"].split(" ")[0], "roofline": _rf(b["roofline"]),
+                        "avg_sweep_ms": b["avg_sweep_ms"], "kernel": b.get("kernel", "").split(" ")[0],
+                        "roofline": _rf(b.get("roofline", {})),
                         "ids_identical_to_single_query_path": b["ids_identical_to_single_query_path"]}
-        if "float32_mfma_form" in b:
-            o["batched"]["float32_mfma_form_TFLOPs"] = b["float32_mfma_form"]["mfma_TFLOPs"]
+        if "end_to_end_hbm_frac" in b:
+            o["batched"]["end_to_end_hbm_frac"] = b["end_to_end_hbm_frac"]
+    if "lone_call" in o:
+        o["lone_call"] = {key: o["lone_call"][key] for key in ("ms", "queries_per_s", "hbm_frac")}
+    if "spread" in o:
+        o["spread"] = {key: o["spread"][key] for key in ("min", "max", "repeats")}
     if "sketch_prepass" in o:
         k = o["sketch_prepass"]
         o["sketch_prepass"] = {"option": "sketch=1 (off by default; DESIGN.md 4.5)", "value": k["value"], "unit": k["unit"],
@@ -147,6 +163,19 @@ def recorded_traffic(workload, rows, sweeps_per_launch):
                 "profiles/traffic.json (separate rocprofv3 --pmc passes, not this run)")
     except Exception:
         return None, None
+
+
+def recorded_pass_traffic(key, rows):
+    """HBM bytes per PASS of a shared sweep as recorded by the PMC passes under profiles/ (traffic.json, keys
+    mq_<bits>bit), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            e = json.load(f)[key]
+        if int(e["rows"]) != int(rows):
+            return None
+        return int(e["hbm_bytes_per_pass"])
+    except Exception:
+        return None
 
 
 def free_port():
@@ -348,14 +377,16 @@ def batched_leg(bits, n_rows, dim, metric, k, devices, seed):
         s_rows, s_dist, _ = ix.search_topk(qb[:32], k)
         pass_ms = st["scan_ms"] / max(st["timed_launches"], 1)
         gbps = n_rows * ix.row_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms else 0.0
-        kern = ("szg::mq_score_bf16s_kernel (v_mfma_f32_16x16x32_bf16, 16-bit codes decoded on the fly)" if bits == 16
-                else "szg::mq_score_i8s_kernel (v_mfma_i32_16x16x64_i8, exact integer)")
+        kern = {16: "szg::mq_score_bf16s_kernel<6,cosine,collect,16> (v_mfma_f32_16x16x32_bf16, 16-bit codes decoded on the fly)",
+                64: "szg::mq_score_bf16s_kernel<6,cosine,collect,64> (v_mfma_f32_16x16x32_bf16, float64 narrowed on the fly)"}.get(
+                    bits, "szg::mq_score_i8s_kernel (v_mfma_i32_16x16x64_i8, exact integer)")
         return {"workload": "%d x %d, %d-bit, cosine, k=%d, 960 queries in one call" % (n_rows, dim, bits, k),
                 "value": round(960 / elapsed, 1), "unit": "queries/s",
                 "queries_per_pass": round(st["mq_queries"] / max(st["mq_launches"], 1), 2),
                 "avg_pass_ms": round(pass_ms, 5), "kernel": kern,
                 "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(gbps / HBM_PEAK_GBS, 4), "traffic": None},
+                             "frac": round(gbps / HBM_PEAK_GBS, 4),
+                             "traffic": recorded_pass_traffic("mq_%dbit" % bits, n_rows)},
                 "escalations": int(st["escalations"]),
                 "ids_and_distances_identical_to_single_query_path":
                     bool((b_rows[:32] == s_rows).all() and (b_dist[:32] == s_dist).all())}
@@ -370,6 +401,10 @@ def main():
                     help="'all' = the headline plus every other config's roofline (the default at N=1 too)")
     ap.add_argument("--mode", default="ranks", choices=["ranks", "inproc"],
                     help="N>1: one process per GPU + RCCL all-gather, or one process driving N devices")
+    ap.add_argument("--parallelism", default="rows", choices=["rows", "replicas"],
+                    help="N>1 ranks: rows sharded over the GPUs + all-gather (default), or every rank holds all rows "
+                         "and answers its slice of the queries (no collective)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of K steps on fresh queries; value = the median")
     ap.add_argument("--rows", type=int, default=0, help="override the workload's row count")
     ap.add_argument("--exchange-every", type=int, default=0,
                     help="N>1 ranks: queries per all-gather micro-batch (0 = 256, or steps/4 for short runs)")
@@ -383,9 +418,15 @@ def main():
     if args.workload == "all":
         args.workload, args.no_extras = "headline", False
 
+    if os.environ.get("SZG_BENCH_FORCE_DIST") == "1" and "RANK" not in os.environ:
+        # the N>1 code path with ONE rank (a 1-GPU box): a rendezvous of its own
+        os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                           "MASTER_PORT": str(free_port())})
+        args.gpus = 1
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and args.mode == "ranks" and env_world is None:
         spawn_ranks(args.gpus)  # does not return
+    args.repeats = max(1, args.repeats)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -419,6 +460,7 @@ def main():
     # SZG_BENCH_FORCE_DIST=1: take the N>1 code path (process group, all-gather, merge)
     # with a single rank -- lets a 1-GPU box exercise the RCCL plumbing
     dist_path = world > 1 or os.environ.get("SZG_BENCH_FORCE_DIST") == "1"
+    replicas = args.parallelism == "replicas" and args.mode == "ranks" and world > 1
     rccl_ranks = None
     if dist_path:
         import torch
@@ -441,6 +483,9 @@ def main():
     if inproc:
         devices = [0] * args.gpus if one_gpu else list(range(args.gpus))
         lo, hi = 0, n_rows
+    elif replicas:
+        devices = [local_rank]
+        lo, hi = 0, n_rows            # every rank holds the whole corpus
     else:
         devices = [local_rank]
         lo, hi = shard_range(n_rows, rank, world)
@@ -450,8 +495,12 @@ def main():
     ix.set_row_base(lo)
     log("[rank %d] corpus rows [%d, %d) x %d B resident on device(s) %s in %.2f s" % (
         rank, lo, hi, ix.row_bytes, devices, time.time() - t0))
-    queries = synth_vectors(seed + 1, 0, args.warmup + args.steps, dim)
-    qw, qt = queries[: args.warmup], queries[args.warmup:]
+    queries = synth_vectors(seed + 1, 0, args.warmup + args.steps * args.repeats, dim)
+    qw = queries[: args.warmup]
+    q_rep = [queries[args.warmup + r * args.steps: args.warmup + (r + 1) * args.steps] for r in range(args.repeats)]
+    qt = q_rep[0]
+    # replicas: this rank's slice of the K queries of a repeat (contiguous, the remainder spread over the first ranks)
+    my_lo, my_hi = (rank * args.steps // world, (rank + 1) * args.steps // world) if replicas else (0, args.steps)
 
     # the headline is one query per sweep (HBM roofline); the shared multi-query
     # sweep is measured separately below and reported under "batched"
@@ -472,7 +521,7 @@ def main():
     chunk = args.steps if args.steps <= 128 else 256
     searcher = None
     transport = None
-    if dist_path:
+    if dist_path and not replicas:
         # The exchange lives in the library (csrc/scan_comm.cpp): its own RCCL communicator on this rank's card,
         # the 128-byte id handed round through the process group once.  Should RCCL refuse inside the library on
         # ANY rank, every rank falls back to the group's own all-gather as host transport (and says so below).
@@ -501,13 +550,17 @@ def main():
             comm.reserve(min(max(args.steps, args.warmup, 1), 256), k)  # staging of the largest micro-batch, up front
 
     def run(q):
+        if replicas:
+            q = q[my_lo:my_hi]
+            if len(q) == 0:
+                return np.zeros((0, max(k, 1)), np.uint64), np.zeros((0, max(k, 1)))
         if radius > 0:
-            if dist_path:
+            if searcher is not None:
                 outs = searcher.search_radius_batch(q, radius)
             else:
                 outs = radius_searches(ix, q, radius)
             return [o[0] for o in outs], [o[1] for o in outs]
-        if dist_path:
+        if searcher is not None:
             r, d, _, _ = searcher.search_stream(q, k)
             return r, d
         r, d, _ = ix.search_topk(q, k)
@@ -540,36 +593,56 @@ def main():
     ix.reset_stats()
     if searcher is not None:
         searcher.comm.reset_stats()
-    sync()
-    t0 = time.perf_counter()
-    res_rows, res_dist = run(qt)  # returns when every result is on the host
-    if torch is not None and (backend == "nccl" or not dist_path) and torch.cuda.is_available():
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0   # this rank's K steps, device idle; the MAX over ranks follows the barrier
-    if dist is not None:
-        dist.barrier()
+    # R timed regions of EXACTLY K steps each, every one on queries nobody has seen, each bracketed by barrier +
+    # synchronize on both sides and reduced to the MAX over ranks; the median repeat is the value
+    rep_elapsed, rep_mine, rep_scan_ms = [], [], []
+    res_rows = res_dist = None
+    scan_ms_before = 0.0
+    for rep in range(args.repeats):
+        sync()
+        t0 = time.perf_counter()
+        rr, rd = run(q_rep[rep])  # returns when every result is on the host
+        if torch is not None and (backend == "nccl" or not dist_path) and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        el = time.perf_counter() - t0   # this rank's K steps, device idle
+        rep_mine.append(el)
+        scan_ms_now = ix.stats()["scan_ms"]
+        rep_scan_ms.append(scan_ms_now - scan_ms_before)   # HIP-event time of this repeat's sweeps
+        scan_ms_before = scan_ms_now
+        if dist is not None:
+            dist.barrier()
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        rep_elapsed.append(el)
+        if rep == 0:
+            res_rows, res_dist = rr, rd   # (the parity legs check the first repeat's queries)
+    order = sorted(range(args.repeats), key=lambda i: rep_elapsed[i])
+    med = order[len(order) // 2]
+    elapsed = rep_elapsed[med]
     stats = ix.stats()
     ix.set_timing(False)
     if radius > 0:
         hits_per_query = float(np.mean([len(r) for r in res_rows]))
-    my_elapsed = elapsed
+    my_elapsed = rep_mine[med]
+    n_timed = max(args.steps * args.repeats, 1)     # queries behind the cumulative statistics
     per_rank = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         mine = roofline_of(stats, hi - lo, ix.row_bytes, bits, metric, "")
-        cst = searcher.comm.stats()
-        row = {"rank": rank, "device": devices[0], "rows": hi - lo, "elapsed_s": round(my_elapsed, 6),
+        cst = searcher.comm.stats() if searcher is not None else {"host_us": 0.0, "exchanges": 0, "exchange_us": 0.0,
+                                                                  "status_rounds": 0, "chain_rounds": 0, "zero_copy": 0}
+        row = {"rank": rank, "device": devices[0], "rows": hi - lo, "queries": my_hi - my_lo,
+               "elapsed_s": round(my_elapsed, 6),
                "scan_GBps": mine["achieved"], "avg_launch_ms": mine["avg_launch_ms"],
-               "sweeps_ms": round(stats["scan_ms"], 4),
-               # everything in this rank's timed region that is not a sweep: pipeline fill / drain, host work
-               # that did not hide behind sweeps, the exchange
-               "fixed_overhead_ms": round(1e3 * my_elapsed - stats["scan_ms"], 4),
+               "sweeps_ms": round(rep_scan_ms[med], 4),
+               # everything in this rank's timed region (the median repeat) that is not a sweep: pipeline fill /
+               # drain, host work that did not hide behind sweeps, the exchange
+               "fixed_overhead_ms": round(1e3 * my_elapsed - rep_scan_ms[med], 4),
                "host_us_per_query": round((stats["host_prep_us"] + stats["host_finish_us"] + stats["host_enqueue_us"] +
-                                           cst["host_us"]) / max(args.steps, 1), 2),
-               "exchanges": int(cst["exchanges"]),
-               "exchange_ms_per_batch": round(1e-3 * cst["exchange_us"] / max(cst["exchanges"], 1), 3)}
+                                           cst["host_us"]) / n_timed, 2),
+               "exchanges_per_call": round(cst["exchanges"] / float(args.repeats), 2),
+               "exchange_ms_per_batch": round(1e-3 * cst["exchange_us"] / max(cst["exchanges"], 1), 3),
+               "status_rounds": int(cst["status_rounds"]), "zero_copy_staging": int(cst["zero_copy"])}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, row)
 
@@ -583,9 +656,9 @@ def main():
             rf["traffic"], src = recorded_traffic(args.workload, n_rows, rf["sweeps_per_launch"])
             if src:
                 rf["traffic_source"] = src
-        host_us = (stats["host_prep_us"] + stats["host_finish_us"] + stats["host_enqueue_us"]) / max(args.steps, 1)
+        host_us = (stats["host_prep_us"] + stats["host_finish_us"] + stats["host_enqueue_us"]) / n_timed
         if searcher is not None:
-            host_us += searcher.comm.stats()["host_us"] / max(args.steps, 1)
+            host_us += searcher.comm.stats()["host_us"] / n_timed
         out = {
             "metric": "queries/sec, exact scan 1M x 768 cosine k=10" if args.workload == "headline"
             else "queries/sec, exact scan (%s)" % args.workload,
@@ -595,6 +668,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+            "repeats": args.repeats,
+            "spread": {"min": round(args.steps / max(rep_elapsed), 2), "max": round(args.steps / min(rep_elapsed), 2),
+                       "repeats": args.repeats, "what": "queries/s of each timed region of K steps; value = the median"},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -609,37 +685,42 @@ def main():
                 "radius": radius if radius > 0 else None,
                 "queries_per_sweep": 1,
                 "mode": "inproc" if inproc else ("ranks" if dist_path else "single"),
-                "parallelism": "rows sharded over %d GPU(s)%s" % (
+                "parallelism": ("replicas: each of the %d GPUs holds all rows and answers its slice of the queries, "
+                                "no collective in the data path" % n_dev) if replicas else
+                "rows sharded over %d GPU(s)%s" % (
                     n_dev, (", one handle with %d device shards in one process" % n_dev) if inproc else
                     (", one process per GPU, 1 %s all-gather per %d queries (inside the library)" % (
                         "RCCL" if backend == "nccl" else backend, chunk) if dist_path else "")),
             },
             "roofline": rf,
             "host_us_per_query": round(host_us, 2),
-            "host_us_breakdown": {"prepare": round(stats["host_prep_us"] / max(args.steps, 1), 2),
-                                  "enqueue_hip_calls": round(stats["host_enqueue_us"] / max(args.steps, 1), 2),
-                                  "assemble": round(stats["host_finish_us"] / max(args.steps, 1), 2),
-                                  "exchange_pack_merge": round(searcher.comm.stats()["host_us"] / max(args.steps, 1), 2)
+            "host_us_breakdown": {"prepare": round(stats["host_prep_us"] / n_timed, 2),
+                                  "enqueue_hip_calls": round(stats["host_enqueue_us"] / n_timed, 2),
+                                  "assemble": round(stats["host_finish_us"] / n_timed, 2),
+                                  "exchange_pack_merge": round(searcher.comm.stats()["host_us"] / n_timed, 2)
                                   if searcher is not None else 0.0},
             "escalations": int(stats["escalations"]),
             "full_replays": int(stats["full_replays"]),
         }
         if not dist_path:
-            out["fixed_overhead_ms"] = round(1e3 * elapsed - stats["scan_ms"], 4)  # timed region minus the sweeps
+            out["fixed_overhead_ms"] = round(1e3 * elapsed - rep_scan_ms[med], 4)  # timed region minus the sweeps
         if hits_per_query is not None:
             out["hits_per_query"] = round(hits_per_query, 1)
         if dist_path:
             out["rccl_ranks"] = rccl_ranks if backend == "nccl" else 0
-            out["rccl_ranks_in_library"] = int(searcher.comm.stats()["rccl_ranks"])  # ncclCommCount of the library's communicator
-            out["exchange_backend"] = backend
-            out["exchange_transport"] = transport
+            if searcher is not None:
+                out["rccl_ranks_in_library"] = int(searcher.comm.stats()["rccl_ranks"])  # ncclCommCount of the library's communicator
+                out["exchange_backend"] = backend
+                out["exchange_transport"] = transport
+            else:
+                out["exchange_transport"] = "none (replicas)"
             out["fixed_overhead_ms"] = max(r["fixed_overhead_ms"] for r in per_rank)
             out["ranks"] = per_rank
         if inproc:
             out["roofline"]["note"] = "per device shard; the N shards sweep concurrently"
 
     # ---- N>1 parity: the oracle on every rank's own rows, merged on rank 0 -------------
-    if dist_path and not args.no_cpu and radius == 0 and args.verify > 0:
+    if dist_path and not replicas and not args.no_cpu and radius == 0 and args.verify > 0:
         import oracle as orc
         orc.build()
         nv = min(2, args.verify, len(qt))
@@ -701,33 +782,31 @@ def main():
                 "kernel": "szg::mq_score_bf16s_kernel<6,cosine,collect,32> (v_mfma_f32_16x16x32_bf16)",
                 "f32_equivalent_TFLOPs": round(tf, 2),
                 "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(gbps / HBM_PEAK_GBS, 4), "traffic": None},
+                             "frac": round(gbps / HBM_PEAK_GBS, 4),
+                             "traffic": recorded_pass_traffic("mq_32bit", n_rows)},
+                # the whole pipeline against the same roof: queries/s / queries per pass x bytes per pass
+                "end_to_end_hbm_frac": round(1024 / b_elapsed / max(per_sweep, 1e-9) * n_rows * ix.row_bytes / 1e9 / HBM_PEAK_GBS, 4),
             })
-            # the float32 MFMA form of the same sweep (mq_bf16 = 0), for comparison
-            ix.set_option("multi_query", 1)
-            ix.set_option("mq_bf16", 0)
-            ix.search_topk(qb[:96], k)
-            ix.set_timing(True)
-            ix.reset_stats()
-            ix.search_topk(qb[:480], k)
-            fst = ix.stats()
-            ix.set_timing(False)
-            ix.set_option("mq_bf16", 1)
-            ix.set_option("multi_query", 0)
-            f_ms = fst["scan_ms"] / max(fst["timed_launches"], 1)
-            f_tf = 2.0 * n_rows * dim * (fst["mq_queries"] / max(fst["mq_launches"], 1)) / (f_ms * 1e-3) / 1e12
-            out["batched"]["float32_mfma_form"] = {
-                "kernel": "szg::mq_score_kernel<3,32,cosine,collect> (v_mfma_f32_16x16x4_f32)",
-                "avg_sweep_ms": round(f_ms, 5), "mfma_TFLOPs": round(f_tf, 2), "mfma_peak_TFLOPs": MFMA_F32_PEAK_TF,
-                "frac": round(f_tf / MFMA_F32_PEAK_TF, 4)}
-        else:
-            out["batched"].update({
-                "kernel": "szg::mq_score_kernel<3,32,cosine,collect> (v_mfma_f32_16x16x4_f32)",
-                "mfma_TFLOPs": round(tf, 2),
-                "mfma_peak_TFLOPs": MFMA_F32_PEAK_TF,
-                "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                             "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None},
-            })
+
+    # ---- a lone Search: ONE query per call, calls one after the other (the unchanged Go API's shape) ---------------
+    if world == 1 and not inproc and radius == 0 and not args.no_extras:
+        ix.set_option("multi_query", 0)
+        ql = synth_vectors(seed + 4, 0, 96, dim)
+        for i in range(16):
+            ix.search_topk(ql[i], k)
+        lone = []
+        for i in range(16, 96):
+            t0 = time.perf_counter()
+            ix.search_topk(ql[i], k)
+            lone.append(time.perf_counter() - t0)
+        lone.sort()
+        l_med = lone[len(lone) // 2]
+        out["lone_call"] = {
+            "what": "sequential szg_search_topk calls of ONE query each (80 calls, median): prepare, upload, sweep, "
+                    "merge, float64 re-rank, copy back, result assembly -- nothing to overlap with",
+            "ms": round(1e3 * l_med, 4), "queries_per_s": round(1.0 / l_med, 1),
+            "hbm_frac": round(n_rows * ix.row_bytes / l_med / 1e9 / HBM_PEAK_GBS, 4),
+            "ms_min": round(1e3 * lone[0], 4), "ms_p90": round(1e3 * lone[int(len(lone) * 0.9)], 4)}
 
     # ---- 8-bit sketch pre-pass (optional path, off by default): the same queries, ONE per sweep --------
     if world == 1 and not inproc and bits == 32 and metric == 1 and radius == 0 and not args.no_extras and n_rows >= 65536:
@@ -765,13 +844,13 @@ def main():
         }
 
     # ---- recall / parity spot check + CPU baseline (rank 0, N=1) -----------------
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and (world == 1 or replicas) and not args.no_cpu:
         import oracle as orc
         orc.build()
         cores = host_cores()
         sample_rows = min(n_rows, 100_000)
         rows_host = ix.read_rows(0, sample_rows)  # the same bytes the GPU scans
-        if not inproc:
+        if not inproc and world == 1:
             t0 = time.time()
             kk = k if radius == 0 else 10
             # single-thread rate first, to size the all-core sample
@@ -800,7 +879,7 @@ def main():
                 1.0 / fsecs * (fs_rows / float(n_rows)), 4)
             log("cpu_baseline leg: %.1f s" % (time.time() - t0))
         # parity on the FULL corpus for a few queries: ids identical, distances bit-equal
-        nv = min(args.verify, len(qt))
+        nv = min(args.verify, len(qt), len(res_rows))   # (replicas: rank 0 holds the answers of its own slice)
         if nv > 0 and radius == 0 and n_rows <= 2_000_000:
             t0 = time.time()
             rows_all = rows_host if sample_rows == n_rows else ix.read_rows(0, n_rows)
@@ -831,7 +910,7 @@ def main():
         out["other_workloads"] = extras
         if args.workload == "headline":
             bq = {}
-            for b in (16, 8, 4):
+            for b in (64, 16, 8, 4):
                 try:
                     bq["%dbit" % b] = batched_leg(b, n_rows, dim, metric, k, devices, SEED + 40 + b)
                 except Exception as e:

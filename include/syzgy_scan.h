@@ -266,13 +266,15 @@ int szg_comm_chain_topk(szg_comm *c, int k, int n_flagged, szg_replay_fn replay,
                         double *out_dist, int32_t *out_count);
 
 typedef struct szg_comm_stats {
-    uint64_t exchanges;   /* all-gathers issued */
-    double exchange_us;   /* wall time inside them (copies + collective + wait) */
+    uint64_t exchanges;   /* data all-gathers of the searches (ONE per top-k micro-batch, two per radius batch) */
+    double exchange_us;   /* wall time inside all all-gathers (copies + collective + wait) */
     double host_us;       /* packing the records and merging the gathered lists */
     int rccl_ranks;       /* ncclCommCount of the communicator (0: host transport) */
     int zero_copy;        /* RCCL: the collective reads / writes the pinned host staging itself (no H2D / D2H copies) */
     uint64_t chained_replays; /* top-k queries whose merged answer held equal distances and was settled by the
                                  rank-to-rank heap chain (the reference's order, collection.go:606-619) */
+    uint64_t status_rounds;   /* one-word all-gathers in which the ranks agreed on their staging (only when it grows) */
+    uint64_t chain_rounds;    /* all-gathers of the heap chain (world per call that has flagged queries) */
 } szg_comm_stats;
 int szg_comm_get_stats(szg_comm *c, szg_comm_stats *out);
 int szg_comm_reset_stats(szg_comm *c);

@@ -46,7 +46,8 @@ REPLAY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes
 
 class SzgCommStats(ctypes.Structure):
     _fields_ = [("exchanges", ctypes.c_uint64), ("exchange_us", ctypes.c_double), ("host_us", ctypes.c_double),
-                ("rccl_ranks", ctypes.c_int), ("zero_copy", ctypes.c_int), ("chained_replays", ctypes.c_uint64)]
+                ("rccl_ranks", ctypes.c_int), ("zero_copy", ctypes.c_int), ("chained_replays", ctypes.c_uint64),
+                ("status_rounds", ctypes.c_uint64), ("chain_rounds", ctypes.c_uint64)]
 
 # include/syzgy_pager.h
 PAGER_EXPORTS = [

@@ -223,7 +223,7 @@ hipError_t launch_mq_score_i8(int row_bits, const MqArgs &a, int nb, int grid, h
 // (zeros where the row has ended).
 size_t mq_bf16_image_bytes(int row_bits, int r16, int nb);
 size_t mq_bf16_lds_bytes(int row_bits, int r16, int nb);
-hipError_t launch_mq_score_bf16(int row_bits, const MqArgs &a, int nb, int grid, hipStream_t stream);  // 32- or 16-bit rows
+hipError_t launch_mq_score_bf16(int row_bits, const MqArgs &a, int nb, int grid, hipStream_t stream);  // 64-, 32- or 16-bit rows
 hipError_t launch_mq_select(const float *keys, size_t key_stride, uint32_t n_rows,
                             const uint64_t *live_bits, const uint64_t *allow_bits,
                             uint32_t allow_stride, int kp, int n_queries, int blocks_per_query,

@@ -169,8 +169,8 @@ __device__ __forceinline__ void offer_tile_hits(const MqArgs &a, HitBuf &hb, int
 }
 
 
-#if SZG_MQ_PART == 3 || SZG_MQ_PART == 116
-// ---- bfloat16 shared sweep, 32-bit rows ---------------------------------------------------------------------------
+#if SZG_MQ_PART == 3 || SZG_MQ_PART == 116 || SZG_MQ_PART == 164
+// ---- bfloat16 shared sweep: 32-, 16- and 64-bit rows ---------------------------------------------------------------------------
 //
 // The sweep only has to RANK: what it keeps is re-scored in float64 and certified against the
 // bound of its own arithmetic (key_eps, bf16 branch), so its products need not carry 24 bits.
@@ -213,7 +213,7 @@ constexpr int kRingBPrefix = SZG_MQB_RING_PREFIX;
 template <int NB, int METRIC, bool COLLECT, int QBITS>
 __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArgs a)
 {
-    constexpr int KS = QBITS == 16 ? 2 : 1;  // 32-element MFMA K-steps per 128-byte step of a row
+    constexpr int KS = QBITS == 16 ? 2 : 1;  // 32-element MFMA K-steps per 128-byte step of a row (64-bit rows: half a one)
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
     const int SS = (a.r16 + 7) / 8;             // 128-byte steps per row, the last one possibly short
     const int last_valid = a.r16 - 8 * (SS - 1);  // 16-byte chunks of the last step that belong to the row (1..8)
     const bool partial = last_valid < 8;
-    const int n16 = SS * KS * NB * 64;
+    const int n16 = (QBITS == 64 ? (SS + 1) / 2 : SS * KS) * NB * 64;  // a KiB per K-step and query block
     const int pad16 = QBITS == 16 ? a.r16 * 8 - a.dim : 0;  // 16-bit rows: padding codes in the row's last 16-byte piece
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
@@ -252,6 +252,8 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
     uint2 *w_b = reinterpret_cast<uint2 *>(stage + 512 + r8 * 64 + ch * 8);
     uint4 *w16_a = reinterpret_cast<uint4 *>(stage + r8 * 64 + (ch & 3) * 16);  // QBITS = 16: 8 bf16 per chunk, half a step at a time
     uint4 *w16_b = reinterpret_cast<uint4 *>(stage + 512 + r8 * 64 + (ch & 3) * 16);
+    uint32_t *w64_a = reinterpret_cast<uint32_t *>(stage + r8 * 64 + ch * 4);  // QBITS = 64: 2 bf16 per chunk, 16 elements per step
+    uint32_t *w64_b = reinterpret_cast<uint32_t *>(stage + 512 + r8 * 64 + ch * 4);
     const v4i32b *r_op = reinterpret_cast<const v4i32b *>(stage + trow * 64 + c * 16);
 
     const uint64_t n_tiles = ((uint64_t)a.n_rows + 15) / 16;
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
     for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     float nrm_a = 0.f, nrm_b = 0.f;
     uint32_t nz_a = 0, nz_b = 0;
+    [[maybe_unused]] uint32_t nzl_a = 0, nzl_b = 0;  // 64-bit rows: the low words (whose bit 31 is data, not a sign)
     v4i32b qn[NB];
 
     const uint8_t *iptr_a, *iptr_b;
@@ -333,6 +336,45 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
                 qn[b] = qimg[qnext_ + b * 64];                                           \
                 acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qc_),          \
                                                                  __builtin_bit_cast(bf16x8, bop_), acc[b], 0, 0, 0); \
+            }                                                                            \
+        } else if constexpr (QBITS == 64) {                                              \
+            /* two float64 elements per 16-byte chunk: narrowed to float32 (v_cvt_f32_f64; beyond the float32 range */ \
+            /* -> inf or 0, and the row is forced into the candidates by its norm, as for float32 rows), the norm and */ \
+            /* the bfloat16 operand are made of the float32 values.  A 128-byte step is HALF a K-step: the wave */ \
+            /* stages two steps side by side in its KiB and multiplies after the second (or after a last odd one, */ \
+            /* whose missing half is zeroed). */                                         \
+            const float xa0_ = (float)__hiloint2double((int)va_.y, (int)va_.x);          \
+            const float xa1_ = (float)__hiloint2double((int)va_.w, (int)va_.z);          \
+            const float xb0_ = (float)__hiloint2double((int)vb_.y, (int)vb_.x);          \
+            const float xb1_ = (float)__hiloint2double((int)vb_.w, (int)vb_.z);          \
+            nrm_a = fmaf(xa0_, xa0_, nrm_a);                                             \
+            nrm_a = fmaf(xa1_, xa1_, nrm_a);                                             \
+            nrm_b = fmaf(xb0_, xb0_, nrm_b);                                             \
+            nrm_b = fmaf(xb1_, xb1_, nrm_b);                                             \
+            nz_a |= va_.y | va_.w;                                                       \
+            nzl_a |= va_.x | va_.z;                                                      \
+            nz_b |= vb_.y | vb_.w;                                                       \
+            nzl_b |= vb_.x | vb_.z;                                                      \
+            const int half_ = cs & 1;                                                    \
+            const bool last_ = cs == SS - 1;                                             \
+            w64_a[half_ * 8] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{xa0_, xa1_}, bf16x2)); \
+            w64_b[half_ * 8] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{xb0_, xb1_}, bf16x2)); \
+            if (last_ && half_ == 0) { /* (wave-uniform) an odd number of steps: no second half */ \
+                w64_a[8] = 0u;                                                           \
+                w64_b[8] = 0u;                                                           \
+            }                                                                            \
+            if (last_ || half_ == 1) {                                                   \
+                __builtin_amdgcn_wave_barrier();                                         \
+                const v4i32b bop_ = *r_op;                                               \
+                __builtin_amdgcn_wave_barrier();                                         \
+                const int qnext_ = lane + (last_ ? 0 : (cs >> 1) + 1) * (NB * 64);       \
+                _Pragma("unroll") for (int b = 0; b < NB; b++)                           \
+                {                                                                        \
+                    const v4i32b qc_ = qn[b];                                            \
+                    qn[b] = qimg[qnext_ + b * 64];                                       \
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qc_),      \
+                                                                     __builtin_bit_cast(bf16x8, bop_), acc[b], 0, 0, 0); \
+                }                                                                        \
             }                                                                            \
         } else {                                                                         \
             const uint32_t wa_[4] = {va_.x, va_.y, va_.z, va_.w}, wb_[4] = {vb_.x, vb_.y, vb_.z, vb_.w};    \
@@ -404,12 +446,20 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
             nrm_b += __shfl_xor(nrm_b, o);
             nz_a |= __shfl_xor(nz_a, o);
             nz_b |= __shfl_xor(nz_b, o);
+            if constexpr (QBITS == 64) {
+                nzl_a |= __shfl_xor(nzl_a, o);
+                nzl_b |= __shfl_xor(nzl_b, o);
+            }
         }
         const int src = (trow & 7) * 8;
         const float na = __shfl(nrm_a, src), nb2 = __shfl(nrm_b, src);
         const uint32_t za = __shfl(nz_a, src), zb = __shfl(nz_b, src);
         const float nrm = trow < 8 ? na : nb2;
-        const uint32_t nz = (trow < 8 ? za : zb) & 0x7FFFFFFFu;
+        uint32_t nz = (trow < 8 ? za : zb) & 0x7FFFFFFFu;
+        if constexpr (QBITS == 64) {
+            const uint32_t zla = __shfl(nzl_a, src), zlb = __shfl(nzl_b, src);
+            nz |= trow < 8 ? zla : zlb;
+        }
         const uint64_t row = tile * 16 + trow;
         const float inv = __frsqrt_rn(nrm);
         if (COLLECT || row < a.n_rows) {
@@ -451,6 +501,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
         for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
         nrm_a = nrm_b = 0.f;
         nz_a = nz_b = 0;
+        nzl_a = nzl_b = 0;
     };
 
     {
@@ -492,7 +543,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
     if (COLLECT) hit_flush(a, hb, lane);
 }
 
-#endif  // SZG_MQ_PART == 3 || 116
+#endif  // SZG_MQ_PART == 3 || 116 || 164
 
 #if SZG_MQ_PART == 1 || SZG_MQ_PART == 2
 // ---- exact integer shared sweep, 8-bit rows (part 1) and 4-bit rows (part 2) ---------------------------------------
@@ -518,7 +569,10 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
     // sum Q x into sum Q n on the host side of the constants table.
     constexpr int T = RB == 4 ? 2 : 1;
     constexpr int NPL = kMqPlanes;  // digit planes of the query (radix 128)
-    constexpr bool PF = RB == 8 || NPL <= 2;  // prefetch the A operands one step ahead (register budget)
+    // prefetch the A operands one step ahead -- where the registers are there: with three query blocks the prefetched
+    // set (48 VGPRs for 4-bit rows) pushed these kernels over the 168 registers of 12 waves per CU and they spilled
+    // 8-21 of them (round 3's builds; -Rpass-analysis=kernel-resource-usage, scripts/kernel_resources.sh)
+    constexpr bool PF = NB < 3;
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -838,7 +892,10 @@ __device__ __forceinline__ void pretest_consts(float thr, float qs, float qn, fl
 #define SZG_S6_RING 3
 #endif
 template <int RB, int STEPS>
-constexpr int i8s_waves() { return RB == 8 && STEPS == 12 ? SZG_S12_WAVES : SZG_MQ8_WAVES; }
+constexpr int i8s_waves()
+{   // (4-bit rows of 12 steps -- 1 536 dims -- at 12 waves per CU spilled 2-4 of their 168 registers: 8 waves, 256)
+    return STEPS == 12 ? SZG_S12_WAVES : SZG_MQ8_WAVES;
+}
 template <int RB, int STEPS>
 constexpr int i8s_ring()
 {
@@ -1158,13 +1215,19 @@ __device__ __forceinline__ void rescore_piece(const uint8_t *row, const float *q
         }
         n = min(8, dim - piece * 8);  // (the last piece's padding codes decode to -65535: not part of the row)
         nz |= 1u;
+    } else if (row_bits == 64) {  // two float64 elements, narrowed to float32 as the sweep narrows them
+        x[0] = (float)__hiloint2double((int)w.y, (int)w.x);
+        x[1] = (float)__hiloint2double((int)w.w, (int)w.z);
+        x[2] = x[3] = x[4] = x[5] = x[6] = x[7] = 0.f;
+        n = 2;
+        nz |= ((w.y | w.w) & 0x7FFFFFFFu) | w.x | w.z;
     } else {
         x[0] = __uint_as_float(w.x); x[1] = __uint_as_float(w.y); x[2] = __uint_as_float(w.z); x[3] = __uint_as_float(w.w);
         x[4] = x[5] = x[6] = x[7] = 0.f;
         n = 4;
         nz |= (w.x | w.y | w.z | w.w) & 0x7FFFFFFFu;
     }
-    const float *y = qf + (size_t)piece * (row_bits == 16 ? 8 : 4);
+    const float *y = qf + (size_t)piece * (row_bits == 16 ? 8 : (row_bits == 64 ? 2 : 4));
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         if (i < n) {
@@ -1193,7 +1256,7 @@ __global__ __launch_bounds__(256) void cand_rescore_kernel(const uint8_t *rows, 
     const double sc = qscale[q];
     // whole 16-byte pieces: a 32-bit row's padding is stored as zeros, the query's staged as zeros (16-bit rows come
     // here with whole pieces only)
-    const int epp = row_bits == 16 ? 8 : 4, pieces = (dim + epp - 1) / epp;
+    const int epp = row_bits == 16 ? 8 : (row_bits == 64 ? 2 : 4), pieces = (dim + epp - 1) / epp;
     for (int i = tid; i < epp * pieces; i += blockDim.x) qf[i] = i < dim ? (float)(q64[(size_t)q * dim + i] * sc) : 0.0f;
     __syncthreads();
     uint64_t *cb = cand_buf + (size_t)q * cand_cap;
@@ -1356,7 +1419,7 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
     for (uint32_t i = tid; i < n; i += kRefineThreads) cand[i] = src[i];
     if (MODE > 0) {
         const double sc = qscale[q];
-        const int epp0 = row_bits == 16 ? 8 : 4;
+        const int epp0 = row_bits == 16 ? 8 : (row_bits == 64 ? 2 : 4);
         for (int i = tid; i < epp0 * ((dim + epp0 - 1) / epp0); i += kRefineThreads)
             qf[i] = i < dim ? (float)(q64[(size_t)q * dim + i] * sc) : 0.0f;  // (padding: zeros, as in the rows)
     }
@@ -1380,7 +1443,7 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
     float edge = 3.0e38f;  // fewer than kp candidates: everything collected is in the band
     if (kth != kInvalidCand) {
         const float t = key_from_ordered((uint32_t)(kth >> 32));
-        const float c = 1.01f * 0x1p-7f, nu = ((float)dim + 16.0f) * 0x1p-24f;  // key_eps (scan_query.cpp), bfloat16 branch
+        const float c = 1.01f * 0x1p-7f, nu = ((float)dim + (row_bits == 64 ? 20.0f : 16.0f)) * 0x1p-24f;  // key_eps (scan_query.cpp), bfloat16 branch
         float eps;
         if (MODE == 1) {
             eps = c + 4.0f * nu + 1e-6f;
@@ -1407,7 +1470,7 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
         return;
     }
     // float32 keys for the band: one wave per candidate
-    const int epp = row_bits == 16 ? 8 : 4, pieces = (dim + epp - 1) / epp;
+    const int epp = row_bits == 16 ? 8 : (row_bits == 64 ? 2 : 4), pieces = (dim + epp - 1) / epp;
     for (uint32_t ci = wave; ci < nb; ci += NW) {
         const uint32_t row = (uint32_t)band[ci];
         const uint8_t *rp = rows + (size_t)row * pitch;
@@ -1471,7 +1534,7 @@ hipError_t launch_cand_rescore(int metric, const uint8_t *rows, uint32_t pitch, 
                                const double *qscale, uint64_t *cand_buf, const uint32_t *cand_count,
                                uint32_t cand_cap, int n_queries, int row_bits, hipStream_t stream)
 {
-    if (row_bits != 32 && row_bits != 16) return hipErrorInvalidValue;
+    if (row_bits != 32 && row_bits != 16 && row_bits != 64) return hipErrorInvalidValue;
     const dim3 grid(SZG_RESCORE_BLOCKS, n_queries);  // x 4 waves: one candidate per wave and trip
     const size_t lds = (size_t)((dim + 7) & ~7) * sizeof(float);
     if (metric == kCosine)
@@ -1494,7 +1557,7 @@ hipError_t launch_cand_refine(int mode, const uint8_t *rows, uint32_t pitch, int
                               uint64_t *lists, float *band_edge, int row_bits, hipStream_t stream)
 {
     if (!cand_refine_applies(kp, cand_cap, dim, mode > 0)) return hipErrorInvalidValue;
-    if (mode > 0 && row_bits != 32 && row_bits != 16) return hipErrorInvalidValue;
+    if (mode > 0 && row_bits != 32 && row_bits != 16 && row_bits != 64) return hipErrorInvalidValue;
     const size_t lds = ((size_t)kRefineMaxCands + (size_t)(kRefineThreads / 64) * kp + kp + kRefineMaxBand) * sizeof(uint64_t) +
                        (mode > 0 ? (size_t)((dim + 7) & ~7) * sizeof(float) : 0);
     auto go = [&](auto kern) -> hipError_t {
@@ -1522,8 +1585,10 @@ size_t mq_i8_lds_bytes(int row_bits, int r16, int nb, int groups)
     return (size_t)groups * (mq_i8_image_bytes(row_bits, r16, nb) + kMq8TableRows * 48 * sizeof(float)) + (size_t)SZG_MQ8_WAVES * 64 * 9;
 }
 size_t mq_bf16_image_bytes(int row_bits, int r16, int nb)
-{   // a KiB per 32-element K-step and query block; a 128-byte step of a row holds one (32-bit rows) or two (16-bit)
-    return (size_t)((r16 + 7) / 8) * (row_bits == 16 ? 2 : 1) * nb * 1024;
+{   // a KiB per 32-element K-step and query block; a 128-byte step of a row holds one (32-bit rows), two (16-bit) or
+    // half a one (64-bit)
+    const size_t steps = (size_t)((r16 + 7) / 8);
+    return (row_bits == 64 ? (steps + 1) / 2 : steps * (row_bits == 16 ? 2 : 1)) * nb * 1024;
 }
 size_t mq_bf16_lds_bytes(int row_bits, int r16, int nb)
 {   // + thresholds, |q|^2 table and the waves' hit buffers
@@ -1532,11 +1597,13 @@ size_t mq_bf16_lds_bytes(int row_bits, int r16, int nb)
 }
 hipError_t launch_mq_score_bf16_rows32(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
 hipError_t launch_mq_score_bf16_rows16(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
+hipError_t launch_mq_score_bf16_rows64(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
 hipError_t launch_mq_score_bf16(int row_bits, const MqArgs &a, int nb, int grid, hipStream_t stream)
 {
     const size_t lds = mq_bf16_lds_bytes(row_bits, a.r16, nb);
     if (row_bits == 32) return launch_mq_score_bf16_rows32(a, nb, grid, lds, stream);
     if (row_bits == 16) return launch_mq_score_bf16_rows16(a, nb, grid, lds, stream);
+    if (row_bits == 64) return launch_mq_score_bf16_rows64(a, nb, grid, lds, stream);
     return hipErrorInvalidValue;
 }
 hipError_t launch_mq_score_i8_rows8(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
@@ -1550,9 +1617,9 @@ hipError_t launch_mq_score_i8(int row_bits, const MqArgs &a, int nb, int grid, h
 }
 #endif  // SZG_MQ_PART == 0
 
-#if SZG_MQ_PART == 3 || SZG_MQ_PART == 116
+#if SZG_MQ_PART == 3 || SZG_MQ_PART == 116 || SZG_MQ_PART == 164
 namespace {
-constexpr int kBfRowBits = SZG_MQ_PART == 3 ? 32 : 16;
+constexpr int kBfRowBits = SZG_MQ_PART == 3 ? 32 : (SZG_MQ_PART == 116 ? 16 : 64);
 template <int NB, int METRIC, bool COLLECT>
 hipError_t launch_mq_score_bf16_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
@@ -1577,8 +1644,10 @@ hipError_t launch_mq_score_bf16_m(const MqArgs &a, int grid, size_t lds, hipStre
 
 #if SZG_MQ_PART == 3
 hipError_t launch_mq_score_bf16_rows32(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
-#else
+#elif SZG_MQ_PART == 116
 hipError_t launch_mq_score_bf16_rows16(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
+#else
+hipError_t launch_mq_score_bf16_rows64(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
 #endif
 {
     if (a.tiled || a.n_rows == 0 || !a.zero16) return hipErrorInvalidValue;
@@ -1592,7 +1661,7 @@ hipError_t launch_mq_score_bf16_rows16(const MqArgs &a, int nb, int grid, size_t
     default: return hipErrorInvalidValue;
     }
 }
-#endif  // SZG_MQ_PART == 3 || 116
+#endif  // SZG_MQ_PART == 3 || 116 || 164
 
 #if SZG_MQ_PART == 1 || SZG_MQ_PART == 2
 namespace {

@@ -179,8 +179,9 @@ int comm_reserve(szg_comm *cm, size_t words)
     return SZG_OK;
 }
 
-// all-gather of `words` int64 per rank: h_mine -> h_all [world][words]
-int comm_exchange(szg_comm *cm, size_t words)
+// all-gather of `words` int64 per rank: h_mine -> h_all [world][words].  kind: 0 = a data exchange of a search (what
+// szg_comm_stats.exchanges counts), 1 = a status round, 2 = a round of the heap chain
+int comm_exchange(szg_comm *cm, size_t words, int kind = 0)
 {
     const double t0 = now_us();
     if (cm->nccl) {
@@ -201,7 +202,9 @@ int comm_exchange(szg_comm *cm, size_t words)
         const int rc = cm->host_fn(cm->host_user, cm->h_mine, cm->h_all, (uint64_t)(words * sizeof(int64_t)));
         if (rc != 0) return fail(SZG_E_DEVICE, "exchange callback failed");
     }
-    cm->stats.exchanges++;
+    if (kind == 0) cm->stats.exchanges++;
+    else if (kind == 1) cm->stats.status_rounds++;
+    else cm->stats.chain_rounds++;
     cm->stats.exchange_us += now_us() - t0;
     return SZG_OK;
 }
@@ -217,7 +220,7 @@ int comm_agree(szg_comm *cm, size_t words)
     const std::string lerr = lrc ? g_last_error : std::string();
     if (!cm->h_mine || cm->cap < 1) return lrc ? lrc : fail(SZG_E_NOMEM, "exchange staging");  // (never had any: creation failed)
     cm->h_mine[0] = lrc == SZG_OK ? (int64_t)cm->cap : -1;
-    const int xrc = comm_exchange(cm, 1);
+    const int xrc = comm_exchange(cm, 1, 1);
     if (xrc) return xrc;
     int64_t least = INT64_MAX;
     for (int g = 0; g < cm->world; g++) least = std::min(least, cm->h_all[g]);
@@ -401,7 +404,7 @@ int comm_chain_topk(szg_comm *cm, int k, int n_flagged, szg_replay_fn replay, vo
         } else {
             memset(cm->h_mine, 0, sizeof(int64_t) * (size_t)n_flagged * w);
         }
-        rc = comm_exchange(cm, (size_t)n_flagged * w);
+        rc = comm_exchange(cm, (size_t)n_flagged * w, 2);
         if (rc) return rc;
     }
     GoHeap h;
@@ -526,7 +529,7 @@ int szg_comm_create(szg_comm **out, const uint8_t *id, int rank, int world, int 
     auto selftest = [&]() -> int {
         for (int i = 0; i < 8; i++) cm->h_mine[i] = rank * 8 + i;
         for (size_t i = 0; i < (size_t)8 * world; i++) cm->h_all[i] = -7;
-        int x = comm_exchange(cm, 8);
+        int x = comm_exchange(cm, 8, 1);
         for (int g = 0; g < world && x == SZG_OK; g++)
             for (int i = 0; i < 8; i++)
                 if (cm->h_all[(size_t)g * 8 + i] != g * 8 + i) x = fail(SZG_E_DEVICE, "all-gather self-test returned foreign data");
@@ -543,6 +546,7 @@ int szg_comm_create(szg_comm **out, const uint8_t *id, int rank, int world, int 
     if (rc) return bail(rc);
     cm->agreed = cm->cap;  // every rank allocates this minimal staging or fails its creation
     cm->stats.exchanges = 0;
+    cm->stats.status_rounds = 0;
     cm->stats.exchange_us = 0;
     cm->stats.zero_copy = cm->zero_copy ? 1 : 0;
     *out = cm;

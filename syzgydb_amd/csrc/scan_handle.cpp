@@ -70,7 +70,7 @@ Ctx *ctx_acquire(Shard *sh)
     sh->cv.wait(lk, [&] { return !sh->free_ctx.empty(); });
     Ctx *c = sh->free_ctx.back();
     sh->free_ctx.pop_back();
-    c->work = c->stream;
+    c->work = c->tail = c->stream;
     return c;
 }
 Ctx *ctx_try_acquire(Shard *sh)
@@ -79,7 +79,7 @@ Ctx *ctx_try_acquire(Shard *sh)
     if (sh->free_ctx.empty()) return nullptr;
     Ctx *c = sh->free_ctx.back();
     sh->free_ctx.pop_back();
-    c->work = c->stream;
+    c->work = c->tail = c->stream;
     return c;
 }
 void ctx_release(Shard *sh, Ctx *c)

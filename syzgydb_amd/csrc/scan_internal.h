@@ -168,6 +168,8 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipStream_t work = nullptr;    // where this batch's uploads and post-processing go: `stream`, or the shard's scan
                                    // stream for a call that is a single batch (set at acquire time)
+    hipStream_t tail = nullptr;    // where the one-sweep pipeline's merges, re-rank and copy-back go: `work`, or `stream`
+                                   // for the first part of a short call (its tail then runs beside the last sweeps)
     hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr, ev_all0 = nullptr, ev_all1 = nullptr;
     hipEvent_t ev_scan_done = nullptr;   // this batch's scans have finished (scan stream)
     hipEvent_t ev_up = nullptr;          // this batch's uploads have finished (ctx stream)

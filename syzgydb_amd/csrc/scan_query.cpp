@@ -163,7 +163,9 @@ double key_eps(const szg_index *ix, double key, const QMeta &m)
         // (|x| + |g|)^2 <= (2|g| + sqrt(key))^2 -- an absolute bound, far looser than the
         // difference form's when rows sit far from the origin; certification then simply
         // escalates more often.
-        const double u = 0x1p-24, n = (double)ix->dim + 16.0;
+        // (64-bit rows are narrowed to float32 element by element first: one more rounding of 2^-24 per operand,
+        // i.e. u |x||g| on the dot product and 2u |x|^2 on the norm -- four more units of n cover both)
+        const double u = 0x1p-24, n = (double)ix->dim + 16.0 + (ix->bits == 64 ? 4.0 : 0.0);
         if (m.mq_bf16) {
             // bfloat16 sweep: each operand is rounded to 8 significant bits -- a bfloat16 keeps 7 fraction bits, so the
             // spacing at 1 is 2^-7 and round-to-nearest moves a value by at most 2^-8 of itself (the query once more
@@ -223,11 +225,11 @@ double key_eps(const szg_index *ix, double key, const QMeta &m)
 // ---- shared sweeps: B queries share one pass of the corpus ------------
 
 bool mq_uses_i8(const szg_index *ix) { return (ix->bits == 8 || ix->bits == 4) && ix->mq_i8; }
-// the bfloat16 sweep: 32- and 16-bit rows of any dimension; not the experimental tiled layout
+// the bfloat16 sweep: 64-, 32- and 16-bit rows of any dimension; not the experimental tiled layout
 bool mq_uses_bf16(const szg_index *ix)
 {
     if (!ix->mq_bf16 || ix->layout.tiled) return false;
-    return ix->bits == 32 || ix->bits == 16;
+    return ix->bits == 64 || ix->bits == 32 || ix->bits == 16;
 }
 
 // round to nearest even, as v_cvt_pk_bf16_f32 does (NaN stays NaN)

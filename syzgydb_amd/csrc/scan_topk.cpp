@@ -210,13 +210,20 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
     rc = launch_scans_chained(ix, sh, c, args, g);
     if (rc) return rc;
 
+    // the tail: on the batch's own stream -- or, for the first part of a short call, on the context's stream behind
+    // one event, so that it (and the host's assembly of these queries) runs beside the call's last sweeps
+    hipStream_t tl = c->tail;
+    if (tl != c->work) {
+        HIPCHK(hipEventRecord(c->ev_scan_done, c->work));
+        HIPCHK(hipStreamWaitEvent(tl, c->ev_scan_done, 0));
+    }
     int n_lists = g.grid;
     uint64_t *src = c->d_lists_a, *dst = c->d_lists_b;
     const int fan = szg::merge_fan(kp);
     {
         SiteScope t_(6);
         while (n_lists > 1) {
-            HIPCHK(szg::launch_merge(src, n_lists, kp, nq, dst, c->work));
+            HIPCHK(szg::launch_merge(src, n_lists, kp, nq, dst, tl));
             n_lists = (n_lists + fan - 1) / fan;
             std::swap(src, dst);
         }
@@ -224,16 +231,16 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
     {
         SiteScope t_(7);
         HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, src,
-                                  nullptr, (uint32_t)kp, nq, c->d_out, c->work));
+                                  nullptr, (uint32_t)kp, nq, c->d_out, tl));
     }
     {
         SiteScope t_(8);
         HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp * nq,
-                              hipMemcpyDeviceToHost, c->work));
+                              hipMemcpyDeviceToHost, tl));
     }
     if (ix->timing >= 2) {
         SiteScope t_(10);
-        HIPCHK(hipEventRecord(c->ev_all1, c->work));
+        HIPCHK(hipEventRecord(c->ev_all1, tl));
     }
     return SZG_OK;
 }
@@ -525,6 +532,8 @@ int enqueue_sentinels(szg_index *ix, Shard *sh, Ctx *c, const std::vector<std::v
 // The queries travel in batches ("tickets": up to 16 with one sweep each, or up to 96 sharing one sweep), as many in
 // flight as the shards have free contexts.  stage() prepares and enqueues a batch on every shard; finish() waits
 // for it and runs the reference's result assembly per query (settle()).
+constexpr int kShortCallLast = 4;  // queries of a short call whose tail is left for after the final sweep
+
 struct TopkCall {
     szg_index *ix;
     const double *queries;
@@ -539,6 +548,7 @@ struct TopkCall {
     int kp = 0;
     bool replay_all = false;  // K beyond the fused selection: every query takes the exact replay
     bool single_batch = false;  // the whole call is one batch of sweeps (a short call)
+    bool early_tail = false;    // ... whose first part's merges / re-rank / copy-back / assembly run beside its last sweeps
 
     const uint64_t *mask_of(int qi) const
     {
@@ -578,7 +588,10 @@ bool TopkCall::acquire(Ticket &t, bool may_block)
         // onto the shard's scan stream in order.  On the context's own stream every hand-over to and from the scan
         // stream is a cross-queue event wait, and those cost 20-100 us each on this platform (rocprofv3 timeline of
         // 20-query calls on a 125 K-row shard: the sweeps of a call's batches sat 24-105 us apart).
-        if (single_batch && ix->serialize_scans) c->work = ix->shards[s]->scan_stream;
+        if (single_batch && ix->serialize_scans) {
+            c->work = c->tail = ix->shards[s]->scan_stream;
+            if (early_tail) c->tail = c->stream;
+        }
         t.ctx[s] = c;
     }
     return true;
@@ -691,7 +704,9 @@ int TopkCall::wait_shards(Ticket &t)
         Shard *sh = ix->shards[s];
         if (sh->n_rows == 0) continue;
         hipError_t e = hipSetDevice(sh->device);
-        if (e == hipSuccess) e = hipStreamSynchronize(t.ctx[s]->work);
+        // (an early tail: the batch is complete when ITS stream is -- the scan stream may be sweeping the call's
+        // next part by now)
+        if (e == hipSuccess) e = hipStreamSynchronize(t.ctx[s]->tail != t.ctx[s]->work ? t.ctx[s]->tail : t.ctx[s]->work);
         if (e == hipSuccess && t.ctx[s]->sent_own_stream) e = hipStreamSynchronize(t.ctx[s]->stream);
         if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "hipStreamSynchronize", e);
         if (rc == SZG_OK) rc = finish_timing(ix, t.ctx[s]);
@@ -976,9 +991,21 @@ int TopkCall::run()
                                    szg::mq_i8_lds_bytes(ix->bits, ix->map.r16, 3, 2) <= 160u * 1024u
                                ? 2 : 1;
         t.nq = nb ? std::min(left, 16 * nb * groups) : std::min(B1, left);
-        // a short call with one sweep per query is ONE batch (its launches of <= 16 sweeps back to back)
-        single_batch = !nb && q0 == 0 && ix->short_call > 0 && n_queries <= std::min(ix->short_call, kMaxBatch);
-        if (single_batch) t.nq = n_queries;
+        // A short call with one sweep per query is ONE run of sweeps on the scan stream (launches of <= 16 back to
+        // back, uploads ahead of them, no event on the critical path).  From 8 queries on it travels as two tickets:
+        // the merges, re-rank, copy-back and host assembly of all but the last few queries run on the context's own
+        // stream and the calling thread WHILE the last sweeps run; only those last queries' tail is left after the
+        // final sweep (what a 20-query call on an eighth of the headline corpus pays: ~0.16 -> ~0.1 ms).
+        if (q0 == 0) single_batch = !nb && ix->short_call > 0 && n_queries <= std::min(ix->short_call, kMaxBatch);
+        early_tail = false;
+        if (single_batch) {
+            t.nq = left;
+            const int last = std::min(kShortCallLast, n_queries / 2);
+            if (q0 == 0 && n_queries >= 8 && ix->serialize_scans) {
+                t.nq = n_queries - last;
+                early_tail = true;
+            }
+        }
         // one sweep per query: the call's FIRST batch is small, so that the card starts sweeping after a few
         // microseconds of preparation instead of a whole batch's (the next batch is prepared while it sweeps)
         // ... and its LAST one too: what is left to do once the last sweep has ended is that batch's merges,

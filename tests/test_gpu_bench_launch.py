@@ -51,7 +51,8 @@ def test_inproc_mode_and_unchanged_single_gpu_form():
     assert one["roofline"]["bound"] == "hbm" and one["cpu_baseline"]["kind"] == "port"
     assert one["batched"]["ids_identical_to_single_query_path"]
     assert one["batched"]["roofline"]["bound"] == "hbm" and one["batched"]["roofline"]["achieved"] > 0   # bfloat16 sweep
-    assert one["batched"]["float32_mfma_form_TFLOPs"] > 0
+    assert one["repeats"] == 5 and one["spread"]["min"] <= one["value"] <= one["spread"]["max"]   # the median repeat
+    assert one["lone_call"]["ms"] > 0 and 0 < one["lone_call"]["hbm_frac"] < 1
     assert one["parity"]["ids_identical"] == one["parity"]["queries_checked"]
 
 
@@ -61,7 +62,7 @@ def test_ranks_form_reports_transport_and_fixed_overhead():
     assert "host transport" in out["exchange_transport"]
     assert out["fixed_overhead_ms"] >= 0
     for r in out["ranks"]:
-        assert r["exchanges"] == 1                      # 20 queries: one local call, ONE all-gather
+        assert r["exchanges_per_call"] == 1             # 20 queries: one local call, ONE all-gather
         assert r["fixed_overhead_ms"] >= 0 and r["sweeps_ms"] > 0
     assert out["parity"]["ids_identical"] == out["parity"]["queries_checked"] > 0
 
@@ -84,5 +85,20 @@ def test_rccl_exchange_inside_the_library_single_rank():
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
     assert out["rccl_ranks"] == 1 and out["rccl_ranks_in_library"] == 1
     assert out["exchange_transport"].startswith("rccl")
-    assert out["ranks"][0]["exchanges"] == 2            # 300 queries: two micro-batches of <= 256, pipelined
+    assert out["ranks"][0]["exchanges_per_call"] == 2   # 300 queries: two micro-batches of <= 256, pipelined
+    assert out["ranks"][0]["zero_copy_staging"] in (0, 1)
     assert out["parity"]["ids_identical"] == out["parity"]["queries_checked"] > 0
+
+
+def test_replicas_mode_answers_query_slices_without_a_collective():
+    """SURVEY.md 8e's zero-collective alternative: every rank holds all rows and answers its slice of the K queries
+    (rehearsed with two ranks on one card; gloo only carries the barriers and the timing reduction)."""
+    out = run_bench(["--gpus", "2", "--parallelism", "replicas", "--steps", "21", "--warmup", "4", "--rows", "100000",
+                     "--settle-seconds", "0.2", "--cpu-seconds", "1", "--repeats", "3"],
+                    {"SZG_BENCH_ONE_GPU": "1", "SZG_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and "replicas" in out["config"]["parallelism"]
+    assert out["exchange_transport"] == "none (replicas)"
+    assert sorted(r["queries"] for r in out["ranks"]) == [10, 11]        # 21 queries split over the two replicas
+    assert all(r["rows"] == 100000 and r["exchanges_per_call"] == 0 for r in out["ranks"])
+    assert out["parity"]["ids_identical"] == out["parity"]["queries_checked"] > 0
+    assert out["repeats"] == 3 and out["value"] > 0

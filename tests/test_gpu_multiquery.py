@@ -386,3 +386,57 @@ def test_long_calls_with_and_without_the_finisher_thread(bits, dim, metric):
             o_rows, o_dist, _ = orc.search_exact(rows, dim, bits, metric, Q[qi], k=3)
             assert [int(x) for x in r1e[qi, : c1e[qi]]] == [int(x) for x in o_rows], qi
             assert (d1e[qi, : c1e[qi]] == np.asarray(o_dist)).all(), qi
+
+
+# ---- bfloat16 shared sweep on 64-bit rows: the reference's DEFAULT quantization (collection.go:254-256) -------------
+
+@pytest.mark.parametrize("metric", [SZG_COSINE, SZG_EUCLIDEAN])
+@pytest.mark.parametrize("dim,n", [(768, 2500), (384, 3000), (16, 6000), (17, 5000), (31, 4000), (48, 4000), (100, 3000),
+                                   (1000, 1500), (3, 2500), (1, 900), (33, 3000), (2, 2000)])
+def test_bf16_sweep_64bit_rows(metric, dim, n):
+    """64-bit rows (quantization.go:8-9, 29-30: the float64 as it is) through the shared sweep: two float64 per
+    16-byte chunk narrowed to float32 and rounded to bfloat16 on the fly, a 128-byte step of a row being HALF a
+    K-step of the matrix instruction (odd step counts, short last steps, an odd dimension's padding element);
+    candidates re-scored in float32, re-ranked in float64: ids and distances are the reference loop's."""
+    rows = orc.synth_rows(6400 + dim, 0, n, dim, 64)
+    Q = orc.synth_vectors(6401 + dim, 0, 50, dim)
+    allow = np.arange(n) % 5 != 1
+    with ScanIndex(dim, 64, metric) as ix:
+        ix.load(rows)
+        check(ix, rows, dim, Q, 10, bits=64, metric=metric)
+        st = ix.stats()
+        if DEFAULT_TUNABLES:
+            assert st["mq_queries"] == 50 and st["mq_bf16_sweeps"] == st["mq_launches"] >= 1
+        check(ix, rows, dim, Q[:20], 7, allow=allow, bits=64, metric=metric)
+        ix.set_option("mq_fused", 0)          # the score-matrix form (lists of bfloat16 keys, wide slack)
+        check(ix, rows, dim, Q[:20], 10, bits=64, metric=metric)
+        ix.set_option("mq_fused", 1)
+        ix.set_option("multi_query", 0)
+        ix.reset_stats()
+        check(ix, rows, dim, Q[:9], 10, bits=64, metric=metric)
+        assert ix.stats()["mq_queries"] == 0
+
+
+@pytest.mark.parametrize("metric", [SZG_COSINE, SZG_EUCLIDEAN])
+def test_bf16_sweep_64bit_rows_beyond_float32(metric):
+    """float64 rows the sweep's float32 cannot hold: elements of 1e200 (the narrowed value is inf), 1e-200 (it is 0),
+    rows that differ only beyond float32's 24 bits, NaN and Inf elements, zero rows.  The sweep forces what it cannot
+    rank into the candidates; the float64 re-rank and the reference's selection decide."""
+    dim, n = 40, 4000
+    rng = np.random.default_rng(64)
+    vec = rng.uniform(-1, 1, (n, dim))
+    vec[5] *= 1e200
+    vec[6] *= 1e-200
+    vec[7] = 0.0
+    vec[100:140] = vec[99] * (1.0 + np.arange(1, 41)[:, None] * 1e-12)   # equal in float32, not in float64
+    vec[200, 3] = np.nan
+    vec[201, 4] = np.inf
+    vec[2000] = vec[99] * 1e200
+    rows = orc.encode_rows(vec, 64)
+    Q = np.vstack([vec[99] + 1e-3 * rng.standard_normal(dim) for _ in range(6)] +
+                  [rng.uniform(-1, 1, dim) for _ in range(14)] + [vec[6] * 1e200, vec[5] * 1e-200])
+    with ScanIndex(dim, 64, metric) as ix:
+        ix.load(rows)
+        check(ix, rows, dim, Q, 12, bits=64, metric=metric)
+        if DEFAULT_TUNABLES:
+            assert ix.stats()["mq_queries"] == len(Q)

@@ -169,7 +169,8 @@ def test_empty_collection_and_empty_batch():
 @pytest.mark.parametrize("bits,metric,dim,n", [(4, SZG_COSINE, 384, 6000), (8, SZG_COSINE, 768, 2500), (8, SZG_EUCLIDEAN, 100, 5000),
                                                (16, SZG_COSINE, 64, 4000), (16, SZG_EUCLIDEAN, 36, 3000),
                                                (32, SZG_COSINE, 96, 7000), (32, SZG_EUCLIDEAN, 33, 4000),
-                                               (32, SZG_COSINE, 2, 5000)])
+                                               (32, SZG_COSINE, 2, 5000),
+                                               (64, SZG_COSINE, 48, 4000), (64, SZG_EUCLIDEAN, 17, 3000)])
 def test_radius_batches_share_one_sweep(bits, metric, dim, n):
     """A radius batch of 2+ queries takes ONE shared sweep (the radius is the collect threshold, widened by the
     sweep's own error bound); answers identical to the oracle's and to the one-sweep-per-query form's -- with

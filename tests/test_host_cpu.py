@@ -222,7 +222,10 @@ def test_bench_compact_line_keeps_the_contract_fields_and_one_short_object_per_l
         "metric": "m", "value": 1.0, "unit": "queries/s", "roofline": dict(rf), "cpu_baseline": {"value": 1.0},
         "batched": {"value": 2.0, "unit": "queries/s", "queries_per_sweep": 96.0, "avg_sweep_ms": 0.46,
                     "kernel": "szg::k<6> (mfma)", "roofline": dict(rf), "ids_identical_to_single_query_path": True,
-                    "float32_mfma_form": {"mfma_TFLOPs": 100.0}},
+                    "end_to_end_hbm_frac": 0.6},
+        "lone_call": {"what": "long text " * 20, "ms": 0.5, "queries_per_s": 2000.0, "hbm_frac": 0.77, "ms_min": 0.49,
+                      "ms_p90": 0.52},
+        "spread": {"min": 1.0, "max": 1.1, "repeats": 5, "what": "text"},
         "batched_quantized": {"8bit": {"value": 3.0, "avg_pass_ms": 0.12, "roofline": dict(rf), "kernel": "x",
                                        "ids_and_distances_identical_to_single_query_path": True},
                               "4bit": {"error": "RuntimeError: x"}},
@@ -235,7 +238,9 @@ def test_bench_compact_line_keeps_the_contract_fields_and_one_short_object_per_l
     c = bench.compact(obj)
     line = json.dumps(c)
     assert json.loads(line)["roofline"] == rf                      # the contract's object untouched
-    assert c["batched"]["kernel"] == "szg::k<6>" and c["batched"]["float32_mfma_form_TFLOPs"] == 100.0
+    assert c["batched"]["kernel"] == "szg::k<6>" and c["batched"]["end_to_end_hbm_frac"] == 0.6
+    assert c["lone_call"] == {"ms": 0.5, "queries_per_s": 2000.0, "hbm_frac": 0.77}
+    assert c["spread"] == {"min": 1.0, "max": 1.1, "repeats": 5}
     assert c["batched_quantized"]["8bit"] == {"value": 3.0, "avg_pass_ms": 0.12, "roofline": bench._rf(rf),
                                               "identical_to_single_query_path": True}
     assert c["batched_quantized"]["4bit"] == {"error": "RuntimeError: x"}
