@@ -536,7 +536,9 @@ int szg_comm_create(szg_comm **out, const uint8_t *id, int rank, int world, int 
         return x;
     };
     if (rc == SZG_OK) rc = selftest();
-    if (rc == SZG_OK && getenv("SZG_COMM_STAGED") == nullptr) {
+    // (opt-in, SZG_COMM_ZERO_COPY=1: with one rank it measured the same 18-22 us per exchange as the staged form, and
+    // no node with two cards was ever available to measure the collective proper writing over PCIe)
+    if (rc == SZG_OK && getenv("SZG_COMM_ZERO_COPY") != nullptr) {
         cm->zero_copy = true;
         if (selftest() != SZG_OK) {  // (every rank has issued the same two collectives either way)
             cm->zero_copy = false;

@@ -13,6 +13,8 @@ int ctx_alloc(szg_index *ix, Shard *sh, Ctx **out)
     HIPCHK(hipEventCreate(&c->ev_scan1));
     HIPCHK(hipEventCreate(&c->ev_all0));
     HIPCHK(hipEventCreate(&c->ev_all1));
+    HIPCHK(hipEventCreate(&c->ev_p0));
+    HIPCHK(hipEventCreate(&c->ev_p1));
     HIPCHK(hipEventCreateWithFlags(&c->ev_scan_done, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
     const size_t B = kMaxBatch;
@@ -31,7 +33,7 @@ void ctx_free(Ctx *c)
 {
     if (!c) return;
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    for (hipEvent_t e : {c->ev_scan0, c->ev_scan1, c->ev_all0, c->ev_all1, c->ev_scan_done, c->ev_up})
+    for (hipEvent_t e : {c->ev_scan0, c->ev_scan1, c->ev_all0, c->ev_all1, c->ev_scan_done, c->ev_up, c->ev_p0, c->ev_p1})
         if (e) (void)hipEventDestroy(e);
     (void)hipHostFree(c->h_qsw);
     (void)hipHostFree(c->h_q64);
@@ -70,7 +72,8 @@ Ctx *ctx_acquire(Shard *sh)
     sh->cv.wait(lk, [&] { return !sh->free_ctx.empty(); });
     Ctx *c = sh->free_ctx.back();
     sh->free_ctx.pop_back();
-    c->work = c->tail = c->stream;
+    c->work = c->stream;
+    c->early_n = 0;
     return c;
 }
 Ctx *ctx_try_acquire(Shard *sh)
@@ -79,7 +82,8 @@ Ctx *ctx_try_acquire(Shard *sh)
     if (sh->free_ctx.empty()) return nullptr;
     Ctx *c = sh->free_ctx.back();
     sh->free_ctx.pop_back();
-    c->work = c->tail = c->stream;
+    c->work = c->stream;
+    c->early_n = 0;
     return c;
 }
 void ctx_release(Shard *sh, Ctx *c)

@@ -168,8 +168,12 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipStream_t work = nullptr;    // where this batch's uploads and post-processing go: `stream`, or the shard's scan
                                    // stream for a call that is a single batch (set at acquire time)
-    hipStream_t tail = nullptr;    // where the one-sweep pipeline's merges, re-rank and copy-back go: `work`, or `stream`
-                                   // for the first part of a short call (its tail then runs beside the last sweeps)
+    int early_n = 0;               // a short call (one batch on the scan stream): the merges, re-rank and copy-back of its
+                                   // first early_n queries go onto `stream` behind one event and run -- like the host's
+                                   // assembly of those queries -- beside the call's last sweeps (0 = one tail for all)
+    hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;  // HIP-event timing of the early part's sweeps
+    bool timed_part = false;
+    int timed_part_n = 0;
     hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr, ev_all0 = nullptr, ev_all1 = nullptr;
     hipEvent_t ev_scan_done = nullptr;   // this batch's scans have finished (scan stream)
     hipEvent_t ev_up = nullptr;          // this batch's uploads have finished (ctx stream)
@@ -408,7 +412,10 @@ int enqueue_queries(szg_index *ix, Shard *sh, Ctx *c, const double *q, int nq, c
                     bool with_single_form = true);
 void fill_scan_args(const szg_index *ix, const Shard *sh, const Ctx *c, bool has_allow, int slot, int nq,
                     szg::ScanArgs *a);
-int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg::ScanArgs> &a, const LaunchGeom &g);
+// (after: the stream that goes on once the sweeps are done -- default c->work; part 1: the early part of a short call,
+// timed with its own event pair)
+int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg::ScanArgs> &a, const LaunchGeom &g,
+                         hipStream_t after = nullptr, int part = 0);
 int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allow);
 // float64 distances of the staged sentinel rows (d_sent) on `stream`, results to h_sent_out
 int launch_sentinel_rerank(szg_index *ix, Shard *sh, Ctx *c, int nq, hipStream_t stream);

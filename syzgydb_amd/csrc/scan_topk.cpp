@@ -108,8 +108,9 @@ void fill_scan_args(const szg_index *ix, const Shard *sh, const Ctx *c, bool has
 // Launch the fused scan for each of the batch's queries (n = a->size()) as the
 // next links of the shard's scan chain; the ctx stream resumes after the last.
 int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg::ScanArgs> &a,
-                         const LaunchGeom &g)
+                         const LaunchGeom &g, hipStream_t after, int part)
 {
+    if (!after) after = c->work;
     const int n = (int)a.size();
     {
         std::lock_guard<std::mutex> lk(sh->chain_mu);
@@ -120,7 +121,7 @@ int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg
         }
         if (ix->timing) {
             SiteScope t_(2);
-            HIPCHK(hipEventRecord(c->ev_scan0, st));
+            HIPCHK(hipEventRecord(part ? c->ev_p0 : c->ev_scan0, st));
         }
         {
             SiteScope t_(3);
@@ -129,14 +130,19 @@ int launch_scans_chained(szg_index *ix, Shard *sh, Ctx *c, const std::vector<szg
         }
         if (ix->timing) {
             SiteScope t_(4);
-            HIPCHK(hipEventRecord(c->ev_scan1, st));
-            c->timed_scan = true;
-            c->timed_n = n;
+            HIPCHK(hipEventRecord(part ? c->ev_p1 : c->ev_scan1, st));
+            if (part) {
+                c->timed_part = true;
+                c->timed_part_n = n;
+            } else {
+                c->timed_scan = true;
+                c->timed_n = n;
+            }
         }
-        if (st != c->work) {
+        if (st != after) {
             SiteScope t_(5);
             HIPCHK(hipEventRecord(c->ev_scan_done, st));
-            HIPCHK(hipStreamWaitEvent(c->work, c->ev_scan_done, 0));
+            HIPCHK(hipStreamWaitEvent(after, c->ev_scan_done, 0));
         }
     }
     std::lock_guard<std::mutex> lk(ix->stats_mu);
@@ -195,52 +201,53 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
     auto pass_rate = [&](int j) { return mask_pass_rate(sh, c, has_allow, j); };
     const bool masked = has_allow || sh->has_dead;
     const int qpl = std::max(1, ix->queries_per_launch);
-    std::vector<szg::ScanArgs> args((nq + qpl - 1) / qpl);
-    for (int j = 0; j < nq; j += qpl) {  // one sweep per query, results side by side
-        szg::ScanArgs &a = args[j / qpl];
-        fill_scan_args(ix, sh, c, has_allow, j, std::min(qpl, nq - j), &a);
-        if (masked && ix->mask_dense) {
-            double lowest = 1.0;
-            for (int i = j; i < std::min(nq, j + qpl); i++) lowest = std::min(lowest, pass_rate(i));
-            a.mask_dense = lowest >= 0.5 ? 1 : 0;
+    // One part -- or, for a short call (c->early_n), two: the sweeps of queries [0, early_n), whose merges, re-rank and
+    // copy-back leave the scan stream for the context's own (one event), and the last few queries, whose tail is all
+    // that is left to do after the call's final sweep.
+    const int early = c->early_n > 0 && c->early_n < nq ? c->early_n : 0;
+    for (int part = early ? 1 : 0; part >= 0; part--) {
+        const int q0 = part ? 0 : early, q1 = part ? early : nq, nqp = q1 - q0;
+        hipStream_t tl = part ? c->stream : c->work;
+        std::vector<szg::ScanArgs> args((nqp + qpl - 1) / qpl);
+        for (int j = q0; j < q1; j += qpl) {  // one sweep per query, results side by side
+            szg::ScanArgs &a = args[(j - q0) / qpl];
+            fill_scan_args(ix, sh, c, has_allow, j, std::min(qpl, q1 - j), &a);
+            if (masked && ix->mask_dense) {
+                double lowest = 1.0;
+                for (int i = j; i < std::min(q1, j + qpl); i++) lowest = std::min(lowest, pass_rate(i));
+                a.mask_dense = lowest >= 0.5 ? 1 : 0;
+            }
+            a.kp = kp;
+            a.block_lists = c->d_lists_a + (size_t)j * g.grid * kp;
         }
-        a.kp = kp;
-        a.block_lists = c->d_lists_a + (size_t)j * g.grid * kp;
-    }
-    rc = launch_scans_chained(ix, sh, c, args, g);
-    if (rc) return rc;
+        rc = launch_scans_chained(ix, sh, c, args, g, tl, part);
+        if (rc) return rc;
 
-    // the tail: on the batch's own stream -- or, for the first part of a short call, on the context's stream behind
-    // one event, so that it (and the host's assembly of these queries) runs beside the call's last sweeps
-    hipStream_t tl = c->tail;
-    if (tl != c->work) {
-        HIPCHK(hipEventRecord(c->ev_scan_done, c->work));
-        HIPCHK(hipStreamWaitEvent(tl, c->ev_scan_done, 0));
-    }
-    int n_lists = g.grid;
-    uint64_t *src = c->d_lists_a, *dst = c->d_lists_b;
-    const int fan = szg::merge_fan(kp);
-    {
-        SiteScope t_(6);
-        while (n_lists > 1) {
-            HIPCHK(szg::launch_merge(src, n_lists, kp, nq, dst, tl));
-            n_lists = (n_lists + fan - 1) / fan;
-            std::swap(src, dst);
+        int n_lists = g.grid;
+        uint64_t *src = c->d_lists_a + (size_t)q0 * g.grid * kp, *dst = c->d_lists_b + (size_t)q0 * g.grid * kp;
+        const int fan = szg::merge_fan(kp);
+        {
+            SiteScope t_(6);
+            while (n_lists > 1) {
+                HIPCHK(szg::launch_merge(src, n_lists, kp, nqp, dst, tl));
+                n_lists = (n_lists + fan - 1) / fan;
+                std::swap(src, dst);
+            }
         }
-    }
-    {
-        SiteScope t_(7);
-        HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, src,
-                                  nullptr, (uint32_t)kp, nq, c->d_out, tl));
-    }
-    {
-        SiteScope t_(8);
-        HIPCHK(hipMemcpyAsync(c->h_out, c->d_out, sizeof(szg::RerankOut) * kp * nq,
-                              hipMemcpyDeviceToHost, tl));
+        {
+            SiteScope t_(7);
+            HIPCHK(szg::launch_rerank(ix->bits, ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64 + (size_t)q0 * ix->dim,
+                                      src, nullptr, (uint32_t)kp, nqp, c->d_out + (size_t)q0 * kp, tl));
+        }
+        {
+            SiteScope t_(8);
+            HIPCHK(hipMemcpyAsync(c->h_out + (size_t)q0 * kp, c->d_out + (size_t)q0 * kp, sizeof(szg::RerankOut) * kp * nqp,
+                                  hipMemcpyDeviceToHost, tl));
+        }
     }
     if (ix->timing >= 2) {
         SiteScope t_(10);
-        HIPCHK(hipEventRecord(c->ev_all1, tl));
+        HIPCHK(hipEventRecord(c->ev_all1, c->work));
     }
     return SZG_OK;
 }
@@ -248,8 +255,15 @@ int enqueue_topk(szg_index *ix, Shard *sh, Ctx *c, int kp, int nq, bool has_allo
 int finish_timing(szg_index *ix, Ctx *c)
 {
     if (!ix->timing) return SZG_OK;
-    float ms_scan = 0, ms_all = 0;
+    float ms_scan = 0, ms_all = 0, ms_part = 0;
     if (c->timed_scan) HIPCHK(hipEventElapsedTime(&ms_scan, c->ev_scan0, c->ev_scan1));
+    if (c->timed_part) {  // the early part of a short call
+        HIPCHK(hipEventElapsedTime(&ms_part, c->ev_p0, c->ev_p1));
+        ms_scan += ms_part;
+        c->timed_n = (c->timed_scan ? c->timed_n : 0) + c->timed_part_n;
+        c->timed_scan = true;
+        c->timed_part = false;
+    }
     if (ix->timing >= 2) HIPCHK(hipEventElapsedTime(&ms_all, c->ev_all0, c->ev_all1));
     std::lock_guard<std::mutex> lk(ix->stats_mu);
     if (c->timed_scan) {
@@ -548,7 +562,8 @@ struct TopkCall {
     int kp = 0;
     bool replay_all = false;  // K beyond the fused selection: every query takes the exact replay
     bool single_batch = false;  // the whole call is one batch of sweeps (a short call)
-    bool early_tail = false;    // ... whose first part's merges / re-rank / copy-back / assembly run beside its last sweeps
+    int early_n = 0;            // ... whose first early_n queries' merges / re-rank / copy-back / assembly run beside its
+                                // last sweeps (Ctx::early_n)
 
     const uint64_t *mask_of(int qi) const
     {
@@ -568,9 +583,9 @@ struct TopkCall {
     int wait_shards(Ticket &t);
     int stage_single_form(Ticket &t, int j);
     void gather(Ticket &t, std::vector<std::vector<Cand>> *all, std::vector<double> *thr_min,
-                std::vector<uint8_t> *nan_first);
+                std::vector<uint8_t> *nan_first, int j0, int j1);
     int settle(Ticket &t, int j, std::vector<Cand> &cands, double thr_min, bool nan_first, double *t_dev,
-               std::vector<HeapItem> *res);
+               std::vector<HeapItem> *res, bool *defer = nullptr);
     int finish(Ticket &t);
 };
 
@@ -589,8 +604,8 @@ bool TopkCall::acquire(Ticket &t, bool may_block)
         // stream is a cross-queue event wait, and those cost 20-100 us each on this platform (rocprofv3 timeline of
         // 20-query calls on a 125 K-row shard: the sweeps of a call's batches sat 24-105 us apart).
         if (single_batch && ix->serialize_scans) {
-            c->work = c->tail = ix->shards[s]->scan_stream;
-            if (early_tail) c->tail = c->stream;
+            c->work = ix->shards[s]->scan_stream;
+            c->early_n = early_n;
         }
         t.ctx[s] = c;
     }
@@ -704,10 +719,8 @@ int TopkCall::wait_shards(Ticket &t)
         Shard *sh = ix->shards[s];
         if (sh->n_rows == 0) continue;
         hipError_t e = hipSetDevice(sh->device);
-        // (an early tail: the batch is complete when ITS stream is -- the scan stream may be sweeping the call's
-        // next part by now)
-        if (e == hipSuccess) e = hipStreamSynchronize(t.ctx[s]->tail != t.ctx[s]->work ? t.ctx[s]->tail : t.ctx[s]->work);
-        if (e == hipSuccess && t.ctx[s]->sent_own_stream) e = hipStreamSynchronize(t.ctx[s]->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(t.ctx[s]->work);
+        if (e == hipSuccess && (t.ctx[s]->sent_own_stream || t.ctx[s]->early_n > 0)) e = hipStreamSynchronize(t.ctx[s]->stream);
         if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "hipStreamSynchronize", e);
         if (rc == SZG_OK) rc = finish_timing(ix, t.ctx[s]);
         Ctx *c = t.ctx[s];
@@ -736,9 +749,9 @@ int TopkCall::wait_shards(Ticket &t)
 // every query's candidates, the lists' lower bound and the first-k NaN flag -- taken before anything else, since the
 // escalation and replay paths reuse the contexts' output buffers
 void TopkCall::gather(Ticket &t, std::vector<std::vector<Cand>> *all, std::vector<double> *thr_min,
-                      std::vector<uint8_t> *nan_first)
+                      std::vector<uint8_t> *nan_first, int j0, int j1)
 {
-    for (int j = 0; j < t.nq; j++) {
+    for (int j = j0; j < j1; j++) {
         for (size_t s = 0; s < n_sh; s++) {
             Shard *sh = ix->shards[s];
             if (sh->n_rows == 0) continue;
@@ -758,8 +771,10 @@ void TopkCall::gather(Ticket &t, std::vector<std::vector<Cand>> *all, std::vecto
 // One query of a finished batch: consider() replayed over its candidates, certification against the rows the lists
 // left out, escalation (a collect sweep) when that fails, the exact replay when the reference's answer depends on its
 // heap history.  *t_dev accumulates the time spent waiting on device passes.
+// defer (non-null): no device pass may be started now (the call's last sweeps are still running and own the
+// contexts' buffers) -- a query that needs one is reported back and settled again once everything has been gathered
 int TopkCall::settle(Ticket &t, int j, std::vector<Cand> &cands, double thr_min, bool nan_first, double *t_dev,
-                     std::vector<HeapItem> *res)
+                     std::vector<HeapItem> *res, bool *defer)
 {
     const uint64_t *allow = mask_of(t.first + j);
     int rc = SZG_OK;
@@ -791,6 +806,10 @@ int TopkCall::settle(Ticket &t, int j, std::vector<Cand> &cands, double thr_min,
     if (ix->force_escalate && thr_min < INFINITY) certified = false;
     if (nan_first && ix->tie_mode == 0) certified = true;  // answered by the replay below
     if (!certified) {
+        if (defer) {
+            *defer = true;
+            return SZG_OK;
+        }
         {
             std::lock_guard<std::mutex> lk(ix->stats_mu);
             ix->stats.escalations++;
@@ -829,6 +848,10 @@ int TopkCall::settle(Ticket &t, int j, std::vector<Cand> &cands, double thr_min,
         // (a zero cosine query is at distance exactly 1.0 from every row, collection.go:828-830: one big tie, whether or
         // not the candidate list is long enough to show two of its members)
         if (nan_first || zero_query || history_dependent(d.data(), d.size(), k)) {
+            if (defer) {
+                *defer = true;
+                return SZG_OK;
+            }
             {
                 std::lock_guard<std::mutex> lk(ix->stats_mu);
                 ix->stats.full_replays++;
@@ -855,15 +878,56 @@ int TopkCall::finish(Ticket &t)
         release(t);
         return SZG_OK;
     }
-    int rc = wait_shards(t);
-    const double t_fin0 = now_us();
     double t_dev = 0;  // time spent waiting on escalation / replay passes (device work)
+    double t_early = 0;  // host time of the early phase
     std::vector<std::vector<Cand>> all(t.nq);
     std::vector<double> thr_min(t.nq, INFINITY);
     std::vector<uint8_t> nan_first(t.nq, 0);  // a NaN distance among the query's first k eligible rows
-    if (rc == SZG_OK && !replay_all) gather(t, &all, &thr_min, &nan_first);
+    std::vector<uint8_t> done(t.nq, 0);
     std::vector<HeapItem> res;
+    auto emit = [&](int j) {
+        const int qi = t.first + j;
+        for (int i = 0; i < k; i++) {
+            const bool have = i < (int)res.size();
+            out_rows[(size_t)qi * k + i] = have ? res[i].row + ix->row_base : UINT64_MAX;
+            out_dist[(size_t)qi * k + i] = have ? res[i].priority : 0.0;
+        }
+        if (out_count) out_count[qi] = (int32_t)res.size();
+    };
+    int rc = SZG_OK;
+    // A short call's early part (Ctx::early_n): those queries' lists and the sentinel rows' distances are complete once
+    // the contexts' own streams are; they are assembled here while the scan streams run the call's last sweeps.  A
+    // query that needs a device pass of its own (escalation, exact replay) waits for the second phase.
+    int early = 0;
+    for (size_t s = 0; s < n_sh; s++)
+        if (t.ctx[s] && t.ctx[s]->early_n > 0) early = t.ctx[s]->early_n;
+    if (early > 0 && early < t.nq && !replay_all) {
+        for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
+            if (!t.ctx[s]) continue;
+            hipError_t e = hipSetDevice(ix->shards[s]->device);
+            if (e == hipSuccess) e = hipStreamSynchronize(t.ctx[s]->stream);
+            if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "hipStreamSynchronize", e);
+        }
+        const double te0 = now_us();
+        if (rc == SZG_OK) gather(t, &all, &thr_min, &nan_first, 0, early);
+        for (int j = 0; j < early && rc == SZG_OK; j++) {
+            bool deferred = false;
+            rc = settle(t, j, all[j], thr_min[j], nan_first[j] != 0, &t_dev, &res, &deferred);
+            if (rc == SZG_OK && !deferred) {
+                emit(j);
+                done[j] = 1;
+            }
+        }
+        t_early = now_us() - te0;
+    } else {
+        early = 0;
+    }
+    if (rc == SZG_OK) rc = wait_shards(t);
+    else (void)wait_shards(t);
+    const double t_fin0 = now_us() - t_early;
+    if (rc == SZG_OK && !replay_all) gather(t, &all, &thr_min, &nan_first, early, t.nq);
     for (int j = 0; j < t.nq && rc == SZG_OK; j++) {
+        if (done[j]) continue;
         const int qi = t.first + j;
         if (replay_all) {
             const double td = now_us();
@@ -877,12 +941,7 @@ int TopkCall::finish(Ticket &t)
             rc = settle(t, j, all[j], thr_min[j], nan_first[j] != 0, &t_dev, &res);
         }
         if (rc) break;
-        for (int i = 0; i < k; i++) {
-            const bool have = i < (int)res.size();
-            out_rows[(size_t)qi * k + i] = have ? res[i].row + ix->row_base : UINT64_MAX;
-            out_dist[(size_t)qi * k + i] = have ? res[i].priority : 0.0;
-        }
-        if (out_count) out_count[qi] = (int32_t)res.size();
+        emit(j);
     }
     {
         std::lock_guard<std::mutex> lk(ix->stats_mu);
@@ -991,20 +1050,16 @@ int TopkCall::run()
                                    szg::mq_i8_lds_bytes(ix->bits, ix->map.r16, 3, 2) <= 160u * 1024u
                                ? 2 : 1;
         t.nq = nb ? std::min(left, 16 * nb * groups) : std::min(B1, left);
-        // A short call with one sweep per query is ONE run of sweeps on the scan stream (launches of <= 16 back to
-        // back, uploads ahead of them, no event on the critical path).  From 8 queries on it travels as two tickets:
-        // the merges, re-rank, copy-back and host assembly of all but the last few queries run on the context's own
-        // stream and the calling thread WHILE the last sweeps run; only those last queries' tail is left after the
-        // final sweep (what a 20-query call on an eighth of the headline corpus pays: ~0.16 -> ~0.1 ms).
-        if (q0 == 0) single_batch = !nb && ix->short_call > 0 && n_queries <= std::min(ix->short_call, kMaxBatch);
-        early_tail = false;
+        // A short call with one sweep per query is ONE batch on the scan stream (launches of <= 16 sweeps back to
+        // back, uploads ahead of them, no event on the critical path).  From 8 queries on, the merges, re-rank,
+        // copy-back and host assembly of all but its last few queries run on the context's own stream and the
+        // calling thread WHILE the last sweeps run; only those last queries' tail is left after the final sweep.
+        single_batch = !nb && q0 == 0 && ix->short_call > 0 && n_queries <= std::min(ix->short_call, kMaxBatch);
+        early_n = 0;
         if (single_batch) {
-            t.nq = left;
-            const int last = std::min(kShortCallLast, n_queries / 2);
-            if (q0 == 0 && n_queries >= 8 && ix->serialize_scans) {
-                t.nq = n_queries - last;
-                early_tail = true;
-            }
+            t.nq = n_queries;
+            static const bool no_early = getenv("SZG_NO_EARLY_TAIL") != nullptr;  // (A/B hook of scripts/dev_short.py)
+            if (n_queries >= 8 && ix->serialize_scans && !no_early) early_n = n_queries - std::min(kShortCallLast, n_queries / 2);
         }
         // one sweep per query: the call's FIRST batch is small, so that the card starts sweeping after a few
         // microseconds of preparation instead of a whole batch's (the next batch is prepared while it sweeps)
