@@ -978,6 +978,27 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
             __builtin_amdgcn_sched_barrier(0);
         }
         if (grp == 0) __syncthreads();  // the query images are complete (the rows do not depend on them)
+        // The A operands travel one PHASE ahead of the matrix instructions that use them.  A phase is the G = NPL x NB
+        // operands of one (step, nibble half); while the G MFMAs of phase ph issue (G x 16 cycles), the G ds_read_b128
+        // of phase ph + 1 are in flight into the other half of a double buffer.  Round 3's form left the reads to the
+        // compiler, which issued each one or two instructions ahead of the MFMA that needs it (84 reads, 72 MFMAs and
+        // an `s_waitcnt lgkmcnt` before nearly every one of them in the 4-bit 6-step kernel): every wave paid the LDS
+        // latency once per couple of MFMAs and the other two waves of its SIMD were all that hid it.  sched_barriers pin
+        // the order read-group / MFMA-group; the decode of the row bytes shares the MFMA groups' regions, where the
+        // scheduler slots it into the matrix instructions' shadows.  (Needs an even number of phases per tile, so that
+        // the buffer halves are compile-time facts: 8-bit rows of 3 steps keep the plain form.)  Same box, 1M x 768
+        // 4-bit: 0.092 -> 0.084 ms per pass.
+        constexpr int G = NPL * NB, PHASES = STEPS * T;
+        constexpr bool PIPE = PHASES % 2 == 0;
+        v4i32 qbuf[2][G];
+        auto read_phase = [&](int ph, v4i32 (&dst)[G]) {
+            const int st_ = ph / T, t_ = ph % T;
+#pragma unroll
+            for (int p = 0; p < NPL; p++)
+#pragma unroll
+                for (int b = 0; b < NB; b++) dst[p * NB + b] = qimg[st_ * QSTEP + ((p * T + t_) * NB + b) * 64];
+        };
+        if (PIPE) read_phase(0, qbuf[0]);
         for (uint64_t it = 0; it < n_it; it++, tile += tile_stride) {
             // (past the wave's last tile: its own tile again -- D loads nobody consumes)
             const uint8_t *nxt = it + 1 < n_it ? row_ptr(tile + tile_stride) : cur;
@@ -990,30 +1011,68 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
                 __builtin_amdgcn_sched_barrier(0);
                 const uint32_t raw_[4] = {v_.x, v_.y, v_.z, v_.w};
                 v4i32 bop_[T];
+                if constexpr (PIPE) {
+                    // region 0: the first operand of the step, and the NEXT phase's reads
 #pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    if (RB == 8) {
-                        const int wn_ = (int)(raw_[d] ^ 0x80808080u);
-                        bop_[0][d] = wn_;
-                        SQ = __builtin_amdgcn_sdot4(wn_, wn_, SQ, false);
-                        SV = __builtin_amdgcn_sdot4(wn_, 0x01010101, SV, false);
-                    } else {
-                        const int wn_ = (int)(raw_[d] ^ 0x88888888u);
-                        bop_[0][d] = (int)((raw_[d] >> 4) & 0x0F0F0F0Fu);
-                        bop_[T - 1][d] = (int)(raw_[d] & 0x0F0F0F0Fu);
-                        SQ = __builtin_amdgcn_sdot8(wn_, wn_, SQ, false);
-                        SV = __builtin_amdgcn_sdot8(wn_, 0x11111111, SV, false);
-                    }
-                }
+                    for (int d = 0; d < 4; d++)
+                        bop_[0][d] = RB == 8 ? (int)(raw_[d] ^ 0x80808080u) : (int)((raw_[d] >> 4) & 0x0F0F0F0Fu);
+                    read_phase((st * T + 1) % PHASES, qbuf[(st * T + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // region 1: G MFMAs of phase st * T, with the rest of the decode in their shadows
 #pragma unroll
-                for (int t = 0; t < T; t++)
+                    for (int g = 0; g < G; g++)
+                        acc[g / NB][g % NB] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qbuf[(st * T) & 1][g], bop_[0],
+                                                                                  acc[g / NB][g % NB], 0, 0, 0);
+                    if constexpr (RB == 8) {
 #pragma unroll
-                    for (int p = 0; p < NPL; p++)
-#pragma unroll
-                        for (int b = 0; b < NB; b++) {
-                            const v4i32 qc_ = qimg[st * QSTEP + ((p * T + t) * NB + b) * 64];
-                            acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qc_, bop_[t], acc[p][b], 0, 0, 0);
+                        for (int d = 0; d < 4; d++) {
+                            SQ = __builtin_amdgcn_sdot4(bop_[0][d], bop_[0][d], SQ, false);
+                            SV = __builtin_amdgcn_sdot4(bop_[0][d], 0x01010101, SV, false);
                         }
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < 4; d++) bop_[T - 1][d] = (int)(raw_[d] & 0x0F0F0F0Fu);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // region 2: the reads of the phase after next;  region 3: the low nibbles' MFMAs + the norm
+                        read_phase((st * T + 2) % PHASES, qbuf[(st * T + 2) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int g = 0; g < G; g++)
+                            acc[g / NB][g % NB] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qbuf[(st * T + 1) & 1][g], bop_[T - 1],
+                                                                                      acc[g / NB][g % NB], 0, 0, 0);
+#pragma unroll
+                        for (int d = 0; d < 4; d++) {
+                            const int wn_ = (int)(raw_[d] ^ 0x88888888u);
+                            SQ = __builtin_amdgcn_sdot8(wn_, wn_, SQ, false);
+                            SV = __builtin_amdgcn_sdot8(wn_, 0x11111111, SV, false);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        if (RB == 8) {
+                            const int wn_ = (int)(raw_[d] ^ 0x80808080u);
+                            bop_[0][d] = wn_;
+                            SQ = __builtin_amdgcn_sdot4(wn_, wn_, SQ, false);
+                            SV = __builtin_amdgcn_sdot4(wn_, 0x01010101, SV, false);
+                        } else {
+                            const int wn_ = (int)(raw_[d] ^ 0x88888888u);
+                            bop_[0][d] = (int)((raw_[d] >> 4) & 0x0F0F0F0Fu);
+                            bop_[T - 1][d] = (int)(raw_[d] & 0x0F0F0F0Fu);
+                            SQ = __builtin_amdgcn_sdot8(wn_, wn_, SQ, false);
+                            SV = __builtin_amdgcn_sdot8(wn_, 0x11111111, SV, false);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < T; t++)
+#pragma unroll
+                        for (int p = 0; p < NPL; p++)
+#pragma unroll
+                            for (int b = 0; b < NB; b++) {
+                                const v4i32 qc_ = qimg[st * QSTEP + ((p * T + t) * NB + b) * 64];
+                                acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qc_, bop_[t], acc[p][b], 0, 0, 0);
+                            }
+                }
             }
             // ---- the tile is done: row norms across the 4 chunk lanes, then the hit test in two stages.  On a large
             // shard a tile of 16 rows x 48 queries holds a hit a few times in a hundred (a radius batch: far less), so
@@ -1032,7 +1091,17 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
             const float inv = __frsqrt_rn(norm);
             const uint64_t row = tile * 16 + trow;
             const bool row_ok = row < a.n_rows;
-            float g[NB][4];  // d2 = sum Q n of the pair, the float the key is made of
+            // (d2 = sum Q n of a pair, the float its key is made of, is formed again in the rare second stage rather than
+            // kept: twelve registers that the prefetched operands of the next tile need more)
+            auto pair_d2 = [&](int b, int r, float qc) -> float {
+                // planes combined as integers: |plane sums| < 2^24 and |dot| < 2^31 for these row shapes, so the one
+                // conversion rounds exactly as fmaf(128, float(acc0), float(acc1)) does (the generic kernel's form,
+                // which the prefix pass made the thresholds with)
+                int di = acc[0][b][r];
+#pragma unroll
+                for (int p = 1; p < NPL; p++) di = di * 128 + acc[p][b][r];
+                return fmaf(2.0f, (float)di, qc);
+            };
             float best = -__builtin_inff();
 #pragma unroll
             for (int b = 0; b < NB; b++) {
@@ -1044,14 +1113,8 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
                 const float psv[4] = {ps4.x, ps4.y, ps4.z, ps4.w}, pwv[4] = {pw4.x, pw4.y, pw4.z, pw4.w};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    // planes combined as integers: |plane sums| < 2^24 and |dot| < 2^31 for these row shapes, so the
-                    // one conversion rounds exactly as fmaf(128, float(acc0), float(acc1)) does (the generic
-                    // kernel's form, which the prefix pass made the thresholds with)
-                    int di = acc[0][b][r];
-#pragma unroll
-                    for (int p = 1; p < NPL; p++) di = di * 128 + acc[p][b][r];
-                    g[b][r] = fmaf(2.0f, (float)di, qcv[r]);
-                    const float e = METRIC == kCosine ? fmaf(g[b][r], inv, pwv[r]) : fmaf(g[b][r], psv[r], pwv[r]);
+                    const float g = pair_d2(b, r, qcv[r]);
+                    const float e = METRIC == kCosine ? fmaf(g, inv, pwv[r]) : fmaf(g, psv[r], pwv[r]);
                     best = fmaxf(best, e);
                 }
             }
@@ -1063,14 +1126,15 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
                 for (int b = 0; b < NB; b++) {
                     const int q0 = b * 16 + c * 4;
                     const float4 qs4 = *reinterpret_cast<const float4 *>(qtab + q0);
+                    const float4 qc4 = *reinterpret_cast<const float4 *>(qtab + 48 + q0);
                     const float4 qn4 = METRIC == kCosine ? make_float4(0.f, 0.f, 0.f, 0.f)
                                                          : *reinterpret_cast<const float4 *>(qtab + 96 + q0);
                     const float4 th4 = *reinterpret_cast<const float4 *>(thr_lds + q0);
-                    const float qsv[4] = {qs4.x, qs4.y, qs4.z, qs4.w};
+                    const float qsv[4] = {qs4.x, qs4.y, qs4.z, qs4.w}, qcv[4] = {qc4.x, qc4.y, qc4.z, qc4.w};
                     const float qnv[4] = {qn4.x, qn4.y, qn4.z, qn4.w}, thv[4] = {th4.x, th4.y, th4.z, th4.w};
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const float d2 = g[b][r];
+                        const float d2 = pair_d2(b, r, qcv[r]);
                         float key;
                         if (METRIC == kCosine)
                             key = -(d2 * qsv[r]) * inv;
