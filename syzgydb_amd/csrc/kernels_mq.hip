@@ -159,15 +159,21 @@ __device__ __forceinline__ void offer_tile_hits(const MqArgs &a, HitBuf &hb, int
                                                 const float (&keys)[NB][4], uint64_t row, int qoff = 0)
 {
     if (!__ballot(hm != 0)) return;
-    const uint32_t un = wave_or_u32(hm);
+    // ONE copy of the offer (and of the flush inside it), walked over the slots that hold a hit somewhere in the wave:
+    // `un` is wave-uniform, so the loop and the slot's key select are scalar-controlled.  (Round 3 unrolled the NB x 4
+    // slots -- 24 inlined offers with a flush each, thousands of instructions in the middle of every sweep's loop: the
+    // register allocator split the load ring's live ranges around them and copied freshly loaded registers at the
+    // loop's end, which waits for every load in flight.)
+    uint32_t un = wave_or_u32(hm);
+    while (un) {
+        const int s = __builtin_ctz(un);
+        un &= un - 1u;
+        float key = keys[0][0];
 #pragma unroll
-    for (int b = 0; b < NB; b++)
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-            if (un & (1u << (b * 4 + r)))
-                hit_offer(a, hb, lane, (hm >> (b * 4 + r)) & 1u, qoff + b * 16 + c * 4 + r, row, keys[b][r]);
+        for (int i = 1; i < NB * 4; i++) key = s == i ? keys[i >> 2][i & 3] : key;
+        hit_offer(a, hb, lane, (hm >> s) & 1u, qoff + (s >> 2) * 16 + c * 4 + (s & 3), row, key);
+    }
 }
-
 
 #if SZG_MQ_PART == 3 || SZG_MQ_PART == 116 || SZG_MQ_PART == 164
 // ---- bfloat16 shared sweep: 32-, 16- and 64-bit rows ---------------------------------------------------------------------------
@@ -438,128 +444,6 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
         }                                                                                \
     }
 
-    // ---- 32- and 16-bit rows: the step travels in two halves, one step apart ----------------------------------------
-    // MQS_STAGE(u) takes ring slot u: decode, norm contributions (kept aside), the wave's KiB of LDS turned into the
-    // MFMA operand layout -- ds_write, ds_read issued back to back, NOT waited for.  MQS_MMA multiplies the step
-    // staged ONE ITERATION EARLIER (operands bopP, by then long in registers) while the LDS round trip of the step
-    // just staged is in flight.  Round 3's form waited for each step's write -> read before its own MFMAs: two (16-bit
-    // rows: four) exposed LDS latencies per 128-byte step with one other wave per SIMD to cover them.  LDS
-    // instructions of a wave execute in order, so the second half's write may follow the first half's read at once.
-    [[maybe_unused]] v4i32b bopN[KS > 0 ? KS : 1], bopP[KS > 0 ? KS : 1];
-    [[maybe_unused]] float sN_a = 0.f, sN_b = 0.f, sP_a = 0.f, sP_b = 0.f;
-    [[maybe_unused]] uint32_t zN_a = 0, zN_b = 0, zP_a = 0, zP_b = 0;
-    [[maybe_unused]] int kN = 0, kP = 0;          // first K-step of the staged / the pending step
-    [[maybe_unused]] bool lastN = false, lastP = false;  // ... it is its row's last step
-
-#define MQS_STAGE(u)                                                                     \
-    {                                                                                    \
-        const u32x4 va_ = ring_a[u], vb_ = ring_b[u];                                    \
-        kN = cs * KS;                                                                    \
-        lastN = cs == SS - 1;                                                            \
-        if constexpr (QBITS == 32) {                                                     \
-            const float xa_[4] = {__uint_as_float(va_.x), __uint_as_float(va_.y), __uint_as_float(va_.z),   \
-                                  __uint_as_float(va_.w)};                               \
-            const float xb_[4] = {__uint_as_float(vb_.x), __uint_as_float(vb_.y), __uint_as_float(vb_.z),   \
-                                  __uint_as_float(vb_.w)};                               \
-            sN_a = xa_[0] * xa_[0];                                                      \
-            sN_b = xb_[0] * xb_[0];                                                      \
-            _Pragma("unroll") for (int i = 1; i < 4; i++) sN_a = fmaf(xa_[i], xa_[i], sN_a);     \
-            _Pragma("unroll") for (int i = 1; i < 4; i++) sN_b = fmaf(xb_[i], xb_[i], sN_b);     \
-            zN_a = va_.x | va_.y | va_.z | va_.w;                                        \
-            zN_b = vb_.x | vb_.y | vb_.z | vb_.w;                                        \
-            const bf16x2 t0_ = __builtin_convertvector(f32x2{xa_[0], xa_[1]}, bf16x2);   \
-            const bf16x2 t1_ = __builtin_convertvector(f32x2{xa_[2], xa_[3]}, bf16x2);   \
-            const bf16x2 t2_ = __builtin_convertvector(f32x2{xb_[0], xb_[1]}, bf16x2);   \
-            const bf16x2 t3_ = __builtin_convertvector(f32x2{xb_[2], xb_[3]}, bf16x2);   \
-            *w_a = make_uint2(__builtin_bit_cast(uint32_t, t0_), __builtin_bit_cast(uint32_t, t1_)); \
-            *w_b = make_uint2(__builtin_bit_cast(uint32_t, t2_), __builtin_bit_cast(uint32_t, t3_)); \
-            __builtin_amdgcn_wave_barrier();                                             \
-            bopN[0] = *r_op;                                                             \
-            __builtin_amdgcn_wave_barrier();                                             \
-        } else {                                                                         \
-            const uint32_t wa_[4] = {va_.x, va_.y, va_.z, va_.w}, wb_[4] = {vb_.x, vb_.y, vb_.z, vb_.w};    \
-            const bool out_ = partial && cs == SS - 1 && past; /* read from the zero block: not part of the row */ \
-            uint32_t pa_[4], pb_[4];                                                     \
-            float xa_[8], xb_[8];                                                        \
-            _Pragma("unroll") for (int i = 0; i < 4; i++)                                \
-            {                                                                            \
-                xa_[2 * i] = fmaf((float)(wa_[i] & 0xFFFFu), 2.0f, -65535.0f);           \
-                xa_[2 * i + 1] = fmaf((float)(wa_[i] >> 16), 2.0f, -65535.0f);           \
-                xb_[2 * i] = fmaf((float)(wb_[i] & 0xFFFFu), 2.0f, -65535.0f);           \
-                xb_[2 * i + 1] = fmaf((float)(wb_[i] >> 16), 2.0f, -65535.0f);           \
-                pa_[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{xa_[2 * i], xa_[2 * i + 1]}, bf16x2)); \
-                pb_[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{xb_[2 * i], xb_[2 * i + 1]}, bf16x2)); \
-            }                                                                            \
-            float sa_ = 0.f, sb_ = 0.f;                                                  \
-            if ((partial || pad16) && cs == SS - 1) { /* (wave-uniform) the row's last step: zero-block lanes and the */ \
-                /* padding codes of the last piece decode to -65535 -- zeros stand against them in the image, and */ \
-                /* they stay out of the norm (subtracting their squares afterwards would cost the small rows' norms */ \
-                /* all their bits) */                                                    \
-                const int nk_ = out_ ? 0 : (ch == last_valid - 1 ? 8 - pad16 : 8);       \
-                _Pragma("unroll") for (int i = 0; i < 8; i++)                            \
-                {                                                                        \
-                    sa_ = i < nk_ ? fmaf(xa_[i], xa_[i], sa_) : sa_;                     \
-                    sb_ = i < nk_ ? fmaf(xb_[i], xb_[i], sb_) : sb_;                     \
-                }                                                                        \
-            } else {                                                                     \
-                _Pragma("unroll") for (int i = 0; i < 8; i++)                            \
-                {                                                                        \
-                    sa_ = fmaf(xa_[i], xa_[i], sa_);                                     \
-                    sb_ = fmaf(xb_[i], xb_[i], sb_);                                     \
-                }                                                                        \
-            }                                                                            \
-            sN_a = sa_;                                                                  \
-            sN_b = sb_;                                                                  \
-            zN_a = zN_b = 1u; /* a decoded code is odd: never a zero row */              \
-            _Pragma("unroll") for (int h = 0; h < 2; h++)                                \
-            {                                                                            \
-                if ((ch >> 2) == h) {                                                    \
-                    *w16_a = make_uint4(pa_[0], pa_[1], pa_[2], pa_[3]);                 \
-                    *w16_b = make_uint4(pb_[0], pb_[1], pb_[2], pb_[3]);                 \
-                }                                                                        \
-                __builtin_amdgcn_wave_barrier();                                         \
-                bopN[h] = *r_op;                                                         \
-                __builtin_amdgcn_wave_barrier();                                         \
-            }                                                                            \
-        }                                                                                \
-        if (++cs == SS) cs = 0;                                                          \
-    }
-
-    // the MFMAs of the pending step (A operands fetched one K-step ahead), its share of the norms, the tile finish
-#define MQS_MMA()                                                                        \
-    {                                                                                    \
-        _Pragma("unroll") for (int h = 0; h < KS; h++)                                   \
-        {                                                                                \
-            const int kn_ = kP + h + 1;                                                  \
-            const int qnext_ = lane + ((lastP && h == KS - 1) ? 0 : kn_) * (NB * 64);    \
-            _Pragma("unroll") for (int b = 0; b < NB; b++)                               \
-            {                                                                            \
-                const v4i32b qc_ = qn[b];                                                \
-                qn[b] = qimg[qnext_ + b * 64];                                           \
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qc_),          \
-                                                                 __builtin_bit_cast(bf16x8, bopP[h]), acc[b], 0, 0, 0); \
-            }                                                                            \
-        }                                                                                \
-        nrm_a += sP_a;                                                                   \
-        nrm_b += sP_b;                                                                   \
-        nz_a |= zP_a;                                                                    \
-        nz_b |= zP_b;                                                                    \
-        if (lastP) {                                                                     \
-            finish_tile(ctile);                                                          \
-            ctile += tile_stride;                                                        \
-        }                                                                                \
-    }
-#define MQS_ROTATE()                                                                     \
-    {                                                                                    \
-        _Pragma("unroll") for (int h = 0; h < KS; h++) bopP[h] = bopN[h];                \
-        sP_a = sN_a;                                                                     \
-        sP_b = sN_b;                                                                     \
-        zP_a = zN_a;                                                                     \
-        zP_b = zN_b;                                                                     \
-        kP = kN;                                                                         \
-        lastP = lastN;                                                                   \
-    }
-
     auto finish_tile = [&](uint64_t tile) {
         // row norms: over the 8 chunk lanes of each row, then to the lanes of the MFMA result (column = row)
 #pragma unroll
@@ -626,56 +510,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
         nzl_a = nzl_b = 0;
     };
 
-    if constexpr (QBITS != 64) {
-        uint64_t issued = R, staged = 0;
-#pragma unroll
-        for (int u = 0; u < R; u++) {
-            MQS_ISSUE(u)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();  // the query image is complete (the rows do not depend on it)
-#pragma unroll
-        for (int b = 0; b < NB; b++) qn[b] = qimg[lane + b * 64];
-        if (NP > 0) {
-            MQS_STAGE(0)
-            MQS_ROTATE()
-            staged = 1;
-            if (issued < NP) {
-                MQS_ISSUE(0)
-                issued++;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // steady state: stage step s + 1 (slot (s + 1) % R), multiply step s, refill the slot
-            while (issued + R <= NP) {
-#pragma unroll
-                for (int u = 0; u < R; u++) {
-                    MQS_STAGE((u + 1) % R)
-                    MQS_MMA()
-                    MQS_ROTATE()
-                    MQS_ISSUE((u + 1) % R)
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                staged += R;
-                issued += R;
-            }
-            while (staged < NP) {
-#pragma unroll
-                for (int u = 0; u < R; u++) {
-                    if (staged < NP) {
-                        MQS_STAGE((u + 1) % R)
-                        MQS_MMA()
-                        MQS_ROTATE()
-                        staged++;
-                        if (issued < NP) {
-                            MQS_ISSUE((u + 1) % R)
-                            issued++;
-                        }
-                    }
-                }
-            }
-            MQS_MMA()  // the last step (its tile's last: the finish is in there)
-        }
-    } else {
+    {
         uint64_t issued = R, consumed = 0;
 #pragma unroll
         for (int u = 0; u < R; u++) {
@@ -711,9 +546,6 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
     }
 #undef MQS_ISSUE
 #undef MQS_CONSUME
-#undef MQS_STAGE
-#undef MQS_MMA
-#undef MQS_ROTATE
     if (COLLECT) hit_flush(a, hb, lane);
 }
 
