@@ -165,12 +165,16 @@ __device__ __forceinline__ void offer_tile_hits(const MqArgs &a, HitBuf &hb, int
     // register allocator split the load ring's live ranges around them and copied freshly loaded registers at the
     // loop's end, which waits for every load in flight.)
     uint32_t un = wave_or_u32(hm);
+    // (the keys as ONE register vector, indexed by the scalar slot number: v_movrels / s_set_gpr_idx, no memory.  A
+    // chain of selects over the array was turned into a table in scratch memory, written by every tile.)
+    typedef float keyvec __attribute__((ext_vector_type(NB <= 2 ? 8 : (NB <= 4 ? 16 : 32))));
+    keyvec kv;
+#pragma unroll
+    for (int i = 0; i < NB * 4; i++) kv[i] = keys[i >> 2][i & 3];
     while (un) {
         const int s = __builtin_ctz(un);
         un &= un - 1u;
-        float key = keys[0][0];
-#pragma unroll
-        for (int i = 1; i < NB * 4; i++) key = s == i ? keys[i >> 2][i & 3] : key;
+        const float key = kv[s];
         hit_offer(a, hb, lane, (hm >> s) & 1u, qoff + (s >> 2) * 16 + c * 4 + (s & 3), row, key);
     }
 }
