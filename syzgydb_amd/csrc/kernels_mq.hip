@@ -20,6 +20,9 @@
 #include "kernels.h"
 #include "device_lists.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 // Built once per part (parallel build, like kernels_scan.hip): -DSZG_MQ_PART=1 / 2 carry the int8 sweeps for 8- / 4-bit
 // rows, 3 / 116 / 164 the bfloat16 sweep for 32- / 16- / 64-bit rows, and the default (0) the selection kernels and
 // the dispatchers.
@@ -554,6 +557,218 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
 }
 
 #endif  // SZG_MQ_PART == 3 || 116 || 164
+
+#if SZG_MQ_PART == 116
+// ---- 16-bit rows without the LDS stage: the codes arrive in the MFMA operand layout ---------------------------------
+//
+// A 16-byte chunk of a 16-bit row is eight codes -- exactly one lane's share (eight bfloat16) of the B operand of
+// v_mfma_f32_16x16x32_bf16.  So lane (row = lane & 15, k-group = lane >> 4) loads ITS chunk of K-step k (64 bytes of the
+// row) straight from HBM, decodes (n = 2v - 65535), rounds to bfloat16 in registers and multiplies: no ds_write /
+// ds_read / wait between the load and the matrix instruction.  The staged kernel above reads 128-byte segments of 8
+// rows per instruction, which streams better (scripts/readbw: 6.95 against 6.2 TB/s for 64-byte segments of 16 rows),
+// but on 16-bit rows its chain -- 56 VALU of decode, then write -> read -> wait TWICE per step, then the MFMAs --
+// held the sweep at 4.2-5.0 TB/s with two waves per SIMD to hide it and no register-allocation-proof way to
+// software-pipeline it (round 4: the allocator answered every staged-operand pipeline with copies of the load ring at
+// the loop's end, i.e. vmcnt(0)).  Here the chain is load -> 28 VALU -> 6 MFMAs.
+#ifndef SZG_MQD_RING
+#define SZG_MQD_RING 3  // 16-byte loads per lane in flight (3 x 1 KiB per wave; 3..6 measure within 2 %)
+#endif
+#ifndef SZG_MQD_WAVES
+#define SZG_MQD_WAVES 12  // waves per block (one block per CU): no staging KiB per wave, <= 168 registers: three per SIMD
+#endif
+constexpr int kMqdThreads = 64 * SZG_MQD_WAVES;
+template <int NB, int METRIC, bool COLLECT>
+__global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArgs a)
+{
+    constexpr int D = COLLECT ? SZG_MQD_RING : 8;  // (the threshold pass: a few tiles per wave, latency-bound)
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int KT = (a.r16 + 3) / 4;               // K-steps (32 elements, 64 bytes of a row) per row, the last possibly short
+    const int last_valid = a.r16 - 4 * (KT - 1);  // 16-byte chunks of the last K-step that belong to the row (1..4)
+    const bool partial = last_valid < 4;
+    const int n16 = KT * NB * 64;
+    const int pad16 = a.r16 * 8 - a.dim;          // padding codes in the row's last 16-byte piece
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        stage_image(dst, src, n16, tid, blockDim.x);
+        // table: [0, 96) thresholds, [96, 192) |q|^2
+        if (COLLECT && tid < kMqMaxQueries)
+            reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
+        if (METRIC != kCosine && tid >= 128 && tid < 128 + kMqMaxQueries)
+            reinterpret_cast<float *>(smem + (size_t)n16 * 16)[tid - 32] = a.qnorm2[tid - 128];
+    }
+    const v4i32b *qimg = reinterpret_cast<const v4i32b *>(smem);
+    const float *thr_lds = reinterpret_cast<const float *>(smem + (size_t)n16 * 16);
+    HitBuf hb;
+    {
+        uint8_t *base = smem + (size_t)n16 * 16 + 2 * kMqMaxQueries * sizeof(float);
+        hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
+        hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
+        hb.n = 0;
+    }
+    const int trow = lane & 15, c = lane >> 4;
+    const uint64_t n_tiles = ((uint64_t)a.n_rows + 15) / 16;
+    const uint64_t tile_stride = (uint64_t)gridDim.x * nwaves;
+    const uint64_t tile_first = (uint64_t)blockIdx.x * nwaves + wave;
+    const uint64_t n_it = tile_first < n_tiles ? (n_tiles - tile_first + tile_stride - 1) / tile_stride : 0;
+    const uint64_t NP = n_it * (uint64_t)KT;
+    const bool past = c >= last_valid;  // this lane's chunk of a short last K-step lies beyond the row: the zero block
+
+    uint64_t itile = tile_first, ctile = tile_first;
+    int is = 0, cs = 0;
+    u32x4 ring[D];
+    f32x4 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float nrm = 0.f;
+    v4i32b qn[NB];
+    auto row_ptr = [&](uint64_t tile) -> const uint8_t * {
+        const uint64_t r = min(tile * 16 + trow, (uint64_t)a.n_rows - 1);  // past the end: a valid row, discarded
+        return a.rows + (size_t)r * a.pitch + (size_t)c * 16;
+    };
+    const uint8_t *iptr = row_ptr(tile_first);
+
+#define MQD_ISSUE(u)                                                                     \
+    {                                                                                    \
+        const bool z_ = partial && is == KT - 1 && past;                                 \
+        ring[u] = load_nt(z_ ? a.zero16 : iptr); /* (plain: the line's other half is the next K-step's) */ \
+        if (++is == KT) {                                                                \
+            is = 0;                                                                      \
+            itile += tile_stride;                                                        \
+            iptr = row_ptr(itile);                                                       \
+        } else {                                                                         \
+            iptr += 64;                                                                  \
+        }                                                                                \
+    }
+
+    // (Tried: the decode in packed float32 pairs -- v_pk_fma_f32 for n = 2v - 65535 and for the norm, 20 instead of 28
+    // vector instructions per K-step -- measured 3-5 % SLOWER on the same box; 8 instead of 12 waves, rings of 3..6:
+    // all within 2 % of each other.  profiles/r04_bf16_16bit_experiments.txt.)
+#define MQD_CONSUME(u)                                                                   \
+    {                                                                                    \
+        const u32x4 v_ = ring[u];                                                        \
+        const uint32_t w_[4] = {v_.x, v_.y, v_.z, v_.w};                                 \
+        float x_[8];                                                                     \
+        v4i32b bop_;                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; i++)                                    \
+        {                                                                                \
+            x_[2 * i] = fmaf((float)(w_[i] & 0xFFFFu), 2.0f, -65535.0f);                 \
+            x_[2 * i + 1] = fmaf((float)(w_[i] >> 16), 2.0f, -65535.0f);                 \
+            bop_[i] = (int)__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x_[2 * i], x_[2 * i + 1]}, bf16x2)); \
+        }                                                                                \
+        float s_ = 0.f;                                                                  \
+        if ((partial || pad16) && cs == KT - 1) { /* (wave-uniform) the row's last K-step: zero-block lanes and the */ \
+            /* padding codes of the last piece decode to -65535 -- zeros stand against them in the image, and they */ \
+            /* stay out of the norm */                                                   \
+            const int nk_ = past ? 0 : (c == last_valid - 1 ? 8 - pad16 : 8);            \
+            _Pragma("unroll") for (int i = 0; i < 8; i++) s_ = i < nk_ ? fmaf(x_[i], x_[i], s_) : s_; \
+        } else {                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 8; i++) s_ = fmaf(x_[i], x_[i], s_);   \
+        }                                                                                \
+        nrm += s_;                                                                       \
+        const int qnext_ = lane + (cs + 1 == KT ? 0 : cs + 1) * (NB * 64);               \
+        _Pragma("unroll") for (int b = 0; b < NB; b++)                                   \
+        {                                                                                \
+            const v4i32b qc_ = qn[b];                                                    \
+            qn[b] = qimg[qnext_ + b * 64];                                               \
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qc_),              \
+                                                             __builtin_bit_cast(bf16x8, bop_), acc[b], 0, 0, 0); \
+        }                                                                                \
+        if (++cs == KT) {                                                                \
+            finish_tile(ctile);                                                          \
+            cs = 0;                                                                      \
+            ctile += tile_stride;                                                        \
+        }                                                                                \
+    }
+
+    auto finish_tile = [&](uint64_t tile) {
+        // row norms: over the row's 4 k-group lanes (the MFMA result's column = the row, as the operand's)
+        nrm += __shfl_xor(nrm, 16);
+        nrm += __shfl_xor(nrm, 32);
+        const uint64_t row = tile * 16 + trow;
+        const float inv = __frsqrt_rn(nrm);
+        if (COLLECT || row < a.n_rows) {
+            float keys[NB][4];
+            uint32_t hm = 0;
+            const bool row_ok = row < a.n_rows;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const float4 th = COLLECT ? *reinterpret_cast<const float4 *>(thr_lds + b * 16 + c * 4)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float thv[4] = {th.x, th.y, th.z, th.w};
+                const float4 qn4 = METRIC == kCosine ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                                     : *reinterpret_cast<const float4 *>(thr_lds + kMqMaxQueries + b * 16 + c * 4);
+                const float qnv[4] = {qn4.x, qn4.y, qn4.z, qn4.w};
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int q = b * 16 + c * 4 + r;
+                    float key;
+                    if (METRIC == kCosine) {
+                        key = -acc[b][r] * inv;  // (a decoded code is odd: the norm is never 0; exactly mq_score_bf16s_kernel's key)
+                        if (!(nrm <= 3.0e38f)) key = -2.0f;
+                    } else {
+                        key = fmaf(-2.0f, acc[b][r], nrm + qnv[r]);
+                    }
+                    if (!(key == key)) key = 3.0e38f;
+                    if (key > 3.0e38f) key = 3.0e38f;
+                    keys[b][r] = key;
+                    if (COLLECT)
+                        hm |= (row_ok && q < a.n_queries && key <= thv[r]) ? (1u << (b * 4 + r)) : 0u;
+                    else if (q < a.n_queries)
+                        a.keys[(size_t)q * a.key_stride + row] = key;
+                }
+            }
+            if (COLLECT) offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row);
+        }
+        if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores (one vmcnt for loads and stores)
+#pragma unroll
+        for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        nrm = 0.f;
+    };
+
+    {
+        uint64_t issued = D, consumed = 0;
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            MQD_ISSUE(u)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();  // the query image is complete (the rows do not depend on it)
+#pragma unroll
+        for (int b = 0; b < NB; b++) qn[b] = qimg[lane + b * 64];
+        while (consumed + 2 * D <= NP) {
+#pragma unroll
+            for (int u = 0; u < D; u++) {
+                MQD_CONSUME(u)
+                MQD_ISSUE(u)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            consumed += D;
+            issued += D;
+        }
+        while (consumed < NP) {
+#pragma unroll
+            for (int u = 0; u < D; u++) {
+                if (consumed < NP) {
+                    MQD_CONSUME(u)
+                    consumed++;
+                    if (issued < NP) {
+                        MQD_ISSUE(u)
+                        issued++;
+                    }
+                }
+            }
+        }
+    }
+#undef MQD_ISSUE
+#undef MQD_CONSUME
+    if (COLLECT) hit_flush(a, hb, lane);
+}
+#endif  // SZG_MQ_PART == 116 (direct 16-bit)
 
 #if SZG_MQ_PART == 1 || SZG_MQ_PART == 2
 // ---- exact integer shared sweep, 8-bit rows (part 1) and 4-bit rows (part 2) ---------------------------------------
@@ -1666,8 +1881,9 @@ size_t mq_bf16_image_bytes(int row_bits, int r16, int nb)
 }
 size_t mq_bf16_lds_bytes(int row_bits, int r16, int nb)
 {   // + thresholds, |q|^2 table and the waves' hit buffers
-    return mq_bf16_image_bytes(row_bits, r16, nb) + 2 * kMqMaxQueries * sizeof(float) + (size_t)SZG_MQB_WAVES * kHitCap * 9 +
-           (size_t)SZG_MQB_WAVES * 1024;  // + a KiB of operand staging per wave
+    // (16-bit rows -- the direct kernel -- run 12 waves without a staging KiB; the staged kernels 8 with one each)
+    return mq_bf16_image_bytes(row_bits, r16, nb) + 2 * kMqMaxQueries * sizeof(float) +
+           std::max((size_t)SZG_MQB_WAVES * (kHitCap * 9 + 1024), (size_t)12 * kHitCap * 9);
 }
 hipError_t launch_mq_score_bf16_rows32(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
 hipError_t launch_mq_score_bf16_rows16(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
@@ -1704,9 +1920,32 @@ hipError_t launch_mq_score_bf16_t(const MqArgs &a, int grid, size_t lds, hipStre
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kMqbThreads), lds, stream, a);
     return hipGetLastError();
 }
+#if SZG_MQ_PART == 116
+template <int NB, int METRIC, bool COLLECT>
+hipError_t launch_mq_score_bf16d_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
+{
+    auto *kern = &mq_score_bf16d_kernel<NB, METRIC, COLLECT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kMqdThreads), lds, stream, a);
+    return hipGetLastError();
+}
+#endif
 template <int NB>
 hipError_t launch_mq_score_bf16_m(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
+#if SZG_MQ_PART == 116
+    static const bool staged16 = getenv("SZG_BF16_STAGED16") != nullptr;  // (A/B: the LDS-staged form for 16-bit rows)
+    if (!staged16) {
+        if (a.collect) {
+            if (a.metric == kCosine) return launch_mq_score_bf16d_t<NB, kCosine, true>(a, grid, lds, stream);
+            return launch_mq_score_bf16d_t<NB, kEuclidean, true>(a, grid, lds, stream);
+        }
+        if (a.metric == kCosine) return launch_mq_score_bf16d_t<NB, kCosine, false>(a, grid, lds, stream);
+        return launch_mq_score_bf16d_t<NB, kEuclidean, false>(a, grid, lds, stream);
+    }
+#endif
     if (a.collect) {
         if (a.metric == kCosine) return launch_mq_score_bf16_t<NB, kCosine, true>(a, grid, lds, stream);
         return launch_mq_score_bf16_t<NB, kEuclidean, true>(a, grid, lds, stream);
