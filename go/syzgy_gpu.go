@@ -316,7 +316,9 @@ func (m *gpuMirror) searchExactKeyed(c *Collection, args SearchArgs, filterKey s
 	tie := false
 	if ok && orderStale {
 		// deterministic mode with rows out of sort.Strings order: did this answer depend on the visit order?
-		// (a concurrent search's replay can only make this fire needlessly, never hide a tie)
+		// (a concurrent search's replay can only make this fire needlessly, never hide a tie.  The counter only
+		// moves with the library's tie_mode 0 -- the default, which this binding never changes; a host that sets
+		// tie_mode 1 must re-page up front instead, as syzgydb_amd/collection.py does)
 		tie = m.fullReplays() != before
 		if args.Radius > 0 {
 			seen := make(map[float64]bool, len(dist))

@@ -319,78 +319,52 @@ int szg_get_stats(szg_index *ix, szg_stats *out);
 int szg_reset_stats(szg_index *ix);
 
 /*
- * Tunables (name, default, meaning).  All are safe to change between calls.
+ * Tunables (name, default, meaning): the sixteen a deployment could want.  All are safe to change between calls.
+ * (Rounds 1-3 exposed another fifteen -- ring depths, waves per CU, stream placement, sweep kinds per row width --
+ * whose values measurement settled; they are compile-time constants now, csrc/scan_internal.h, and A/B runs go
+ * through `make variant`.)
  *
  *   answer semantics
- *     tie_mode            0   when two of the best k+1 distances are exactly equal, or one is NaN,
- *                             the reference's output depends on its whole heap history, so the
- *                             query is re-answered by an exact replay over every row; 1 = keep the
- *                             fast answer (a valid top-k whose order among equal distances may
- *                             differ from the reference's)
+ *     tie_mode            0   when two of the best k+1 distances are exactly equal, or one is NaN, the reference's
+ *                             output depends on its whole heap history, so the query is re-answered by an exact
+ *                             replay over every row; 1 = keep the fast answer (a valid top-k whose order among equal
+ *                             distances may differ from the reference's)
  *     slack               16  extra candidates kept beyond k (at least; k/2 when larger)
  *   one sweep per query
- *     queries_per_launch  16  sweeps one scan launch walks back to back (query-major): no launch
- *                             gap or chip-wide tail between the sweeps of a batch
+ *     queries_per_launch  16  sweeps one scan launch walks back to back (query-major): no launch gap or chip-wide
+ *                             tail between the sweeps of a batch
  *     query_batch         16  queries staged, merged, re-ranked and copied back together
- *     blocks_per_cu       0   0 = chosen from the row format (8-12 waves per CU); block_threads 256
- *     mask_dense          1   sweeps whose filter / tombstone masks pass at least half the rows read
- *                             every row and apply the masks at the row finish; selective masks (and
- *                             0) compact the row steps that hold a passing row first
- *     shape_kernels       1   row-shape-specialised kernels where they exist (4-bit rows)
- *     serialize_scans     1   sweeps of one shard never overlap each other; contexts 3 = batches in flight
+ *     mask_dense          1   sweeps whose filter / tombstone masks pass at least half the rows read every row and
+ *                             apply the masks at the row finish; selective masks (and 0) compact the row steps that
+ *                             hold a passing row first
+ *     serialize_scans     1   sweeps of one shard never overlap each other (every sweep has the whole HBM bandwidth)
+ *     contexts            3   batches in flight per shard
  *   sketch pre-pass (float32 rows)
- *     sketch              0   1 = keep an 8-bit sketch of every row (+25 % memory, built on the device at the
- *                             first search after a load, kept up to date across appends / overwrites /
- *                             tombstones) and answer one-query-per-sweep searches by sweeping the sketch
- *                             (a quarter of the bytes) for k + sketch_extra candidates, re-ranking those on
- *                             the float32 rows in float64 and certifying with the triangle inequality of the
- *                             reference's distance -- the angle, or the Euclidean distance with one scale for
- *                             the collection -- (k-th distance < candidates' last sketch distance - largest
- *                             row-to-sketch distance); unsettled queries take the full sweep.  Same answers.
- *                             1M x 768 cosine k=10: 2.2 k -> 8.0 k queries/s
- *     sketch_extra        30  candidates beyond k; the pre-pass serves k + sketch_extra <= 64 (longer candidate
- *                             lists make the sketch sweep slower than the sweep it replaces)
+ *     sketch              0   1 = keep an 8-bit sketch of every row (+25 % memory, built on the device at the first
+ *                             search after a load, kept up to date across appends / overwrites / tombstones) and
+ *                             answer one-query-per-sweep searches by sweeping the sketch (a quarter of the bytes) for
+ *                             k + sketch_extra candidates, re-ranking those on the float32 rows in float64 and
+ *                             certifying with the triangle inequality of the reference's distance; unsettled queries
+ *                             take the full sweep.  Same answers.  1M x 768 cosine k=10: 2.2 k -> 8.0 k queries/s
+ *     sketch_extra        30  candidates beyond k; the pre-pass serves k + sketch_extra <= 64
  *     sketch_min_rows     4096  collections below this size always take the full sweep
  *   shared sweeps
- *     multi_query         1   batches of >= mq_min (2) queries share ONE sweep of the corpus, the
- *                             dot products on the matrix cores (4/8/16/32-bit rows, either metric),
- *                             up to 16 * mq_blocks queries per sweep (mq_blocks 6: 96 for the bfloat16
- *                             sweep of 32-bit rows, 48 = 3 blocks at most for the others, fewer when
- *                             the image does not fit LDS); 0 = one sweep per query
- *     mq_i8               1   8- and 4-bit rows: exact integer sweep on the int8 matrix cores
- *                             (v_mfma_i32_16x16x64_i8); 0 = the float32 MFMA sweep
- *     mq_bf16             1   32- and 16-bit rows of any dimension
- *                             (decoded on the fly): the sweep multiplies bfloat16
- *                             roundings of rows and queries (v_mfma_f32_16x16x32_bf16, 16 x the float32
- *                             matrix rate: the sweep becomes a plain stream of the rows), its
- *                             candidates are scored again in float32 before the selection, and the
- *                             certification uses the bfloat16 bound (2^-7 |x||q|: 2^-8 per operand)
- *                             for the rows it left out; 0 = the float32 MFMA sweep
- *     mq_overlap          1   bfloat16 sweeps: a batch's threshold pass and post-processing run on the
- *                             context's stream beside the neighbouring batches' sweeps (+13 % queries/s)
- *     mq_bf16_slack       246 candidates kept beyond k where the lists hold bfloat16 keys themselves
- *                             (score-matrix form: small shards, overflow reruns)
- *     mq_i8_groups        2   int8 sweeps: one launch walks the passes of up to two groups of 48 queries
- *                             (both LDS images staged up front); 1 = one group per launch
- *     mq_fused            1   threshold-collect selection instead of a score matrix
+ *     multi_query         1   batches of >= mq_min queries share ONE sweep of the corpus, the dot products on the
+ *                             matrix cores: 64- / 32- / 16-bit rows on bfloat16 roundings (v_mfma_f32_16x16x32_bf16,
+ *                             up to 96 queries per pass; candidates scored again in float32, certified against the
+ *                             bfloat16 bound), 8- / 4-bit rows in exact integer arithmetic (v_mfma_i32_16x16x64_i8, 48
+ *                             per pass, two passes per launch); 0 = one sweep per query
+ *     mq_min              2   smallest batch worth a shared sweep
  *     mq_hits             1024 candidates per query the threshold from the prefix pass aims at
- *     mq_tail_overlap     0   1 = a batch's selection / rerank / copy-back run beside the next
- *                             batch's sweep (+3-6 % queries/s, the sweep itself 5 % slower)
- *     coalesce            1   concurrent szg_search_topk calls with ONE query each -- the
- *                             reference's Searches under RLock -- are answered together, up to 96
- *                             per shared sweep, by whichever caller finds no batch in flight;
- *                             concurrent szg_search_radius callers likewise share query-major
- *                             collect launches (16 sweeps per launch, each with its own radius)
- *     radius_mq           1   radius batches (szg_search_radius_batch, coalesced szg_search_radius
- *                             callers) of two or more queries share ONE sweep of the corpus per up to 96
- *                             queries -- the shared sweeps' collect form with the radius as threshold;
- *                             0 = one collect sweep per query
- *     radius_sort         1   a radius batch's re-ranked hits are sorted by distance on the device
- *                             (lists of up to 2 048 hits); 0 = the host sorts
- *     finish_thread       1   a call of three or more shared-sweep batches assembles its finished
- *                             batches (waits, certification, output) on a second host thread while
- *                             the caller's prepares and enqueues the next ones; 0 = one thread
- *   tests / tuning hooks: force_escalate, lanes_per_row
+ *     coalesce            1   concurrent szg_search_topk calls with ONE query each -- the reference's Searches under
+ *                             RLock -- are answered together, up to 96 per shared sweep, by whichever caller finds no
+ *                             batch in flight; concurrent szg_search_radius callers likewise
+ *     radius_mq           1   radius batches of two or more queries share ONE sweep of the corpus per up to 96
+ *                             queries (the radius is the collect threshold); 0 = one collect sweep per query
+ *     finish_thread       1   a call of three or more shared-sweep batches assembles its finished batches on a
+ *                             second host thread while the caller's prepares and enqueues the next ones
+ *   test hooks (paths that data takes by itself only rarely): force_escalate, force_matrix (the score-matrix form of
+ *   the shared sweeps: small shards, candidate-buffer overflow), force_no_refine (their tail as separate launches: kp > 256)
  */
 int szg_set_option(szg_index *ix, const char *name, int64_t value);
 

@@ -44,20 +44,25 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   one /tmp/prof_rad_$ctr "*counter_collection.csv" $out/${tag}_pmc_cfg5radius_$lc.csv
 done
 
+echo "[hl] headline only: launches of 16 sweeps under --kernel-trace --stats (AverageNs / 16 = one sweep)" | tee -a $out/progress.log
+rm -rf /tmp/prof_hl
+SZG_LAUNCHES=12 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_hl -- python3 $GRAFT_REPO_ROOT/scripts/dev_one.py 1000000 768 32 1 10 16 > /tmp/hl.log 2>&1
+one /tmp/prof_hl "*kernel_stats.csv" $out/${tag}_headline_16sweep_kernel_stats.csv
+
 echo "[mq] shared sweeps: kernel stats + counters" | tee -a $out/progress.log
-for b in 32 16 8 4; do
+for b in 64 32 16 8 4; do
   rm -rf /tmp/prof_mq$b
   SZG_BITS=$b rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mq$b -- python3 $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /tmp/mq.log 2>&1
   one /tmp/prof_mq$b "*kernel_stats.csv" $out/${tag}_mq_${b}bit_kernel_stats.csv
 done
-# the float32 MFMA form of the 32-bit sweep (mq_bf16 = 0), for comparison
-rm -rf /tmp/prof_mqf
-SZG_BITS=32 SZG_OPTS=mq_bf16=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mqf -- python3 $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /tmp/mq.log 2>&1
-one /tmp/prof_mqf "*kernel_stats.csv" $out/${tag}_mq_32bit_f32mfma_kernel_stats.csv
+# one dimension WITHOUT a shape kernel of its own (4-bit rows of 1 024 dims: the any-shape int8 sweep)
+rm -rf /tmp/prof_mq4g
+SZG_BITS=4 SZG_DIM=1024 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mq4g -- python3 $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /tmp/mq.log 2>&1
+one /tmp/prof_mq4g "*kernel_stats.csv" $out/${tag}_mq_4bit_dim1024_kernel_stats.csv
 SZG_BITS=8 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_i8s_kernel<3, 1" $out/${tag}_pmc_mq_i8_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
 SZG_BITS=4 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_i8s_kernel<3, 1" $out/${tag}_pmc_mq_i8_4bit_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
 SZG_BITS=32 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_bf16s_kernel<6, 1, true" $out/${tag}_pmc_mq_bf16_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
-SZG_BITS=16 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_bf16s_kernel<6, 1, true" $out/${tag}_pmc_mq_bf16_16bit_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
-SZG_BITS=32 SZG_OPTS=mq_bf16=0 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_kernel<3, 32, 1, true" $out/${tag}_pmc_mq_f32_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
+SZG_BITS=64 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_bf16s_kernel<6, 1, true" $out/${tag}_pmc_mq_bf16_64bit_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
+SZG_BITS=16 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_bf16d_kernel<6, 1, true" $out/${tag}_pmc_mq_bf16_16bit_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
 python3 $GRAFT_REPO_ROOT/scripts/make_traffic.py $out $tag > $out/traffic.json || true
 echo done | tee -a $out/progress.log

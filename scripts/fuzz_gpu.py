@@ -15,13 +15,11 @@ from syzgydb_amd import ScanIndex
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
-OPTS = [("queries_per_launch", [1, 3, 16]), ("multi_query", [0, 1]), ("mq_fused", [0, 1]), ("mq_i8", [0, 1]),
-        ("serialize_scans", [0, 1]), ("shape_kernels", [0, 1]), ("blocks_per_cu", [0, 1, 3]),
-        ("mq_min", [2, 8]), ("mq_blocks", [1, 2, 3]), ("slack", [0, 16, 40]), ("mq_bf16", [0, 1, 1]),
-        ("mq_overlap", [0, 1]), ("mq_bf16_slack", [0, 118, 246]), ("mq_hits", [64, 1024]), ("sketch", [0, 1, 1]),
-        ("sketch_extra", [0, 30]), ("sketch_min_rows", [1, 1, 4096]), ("mq_i8_groups", [1, 2]),
-        ("mq_refine", [0, 1, 1]), ("first_batch", [0, 1, 4]), ("mask_dense", [0, 1]), ("coalesce", [0, 1]),
-        ("finish_thread", [0, 1, 1]), ("radius_mq", [0, 1, 1]), ("radius_sort", [0, 1, 1])]
+OPTS = [("queries_per_launch", [1, 3, 16]), ("multi_query", [0, 1]), ("force_matrix", [0, 0, 1]),
+        ("serialize_scans", [0, 1]), ("mq_min", [2, 8]), ("slack", [0, 16, 40]), ("mq_hits", [64, 1024]),
+        ("sketch", [0, 1, 1]), ("sketch_extra", [0, 30]), ("sketch_min_rows", [1, 1, 4096]),
+        ("force_no_refine", [0, 0, 1]), ("mask_dense", [0, 1]), ("coalesce", [0, 1]), ("finish_thread", [0, 1, 1]),
+        ("radius_mq", [0, 1, 1]), ("query_batch", [5, 16])]
 
 
 def same(got_r, got_d, want_r, want_d):

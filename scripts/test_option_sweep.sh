@@ -17,9 +17,10 @@ run() {  # $1 = label, rest = pytest arguments
 # tests/test_gpu_parity.py::test_tie_mode_1_returns_a_valid_topk.)
 # SWEEP_SETS="a=1 b=2,c=3" restricts the first loop to those sets (re-checking a fix)
 # SWEEP_SKIP_MAIN=1 skips this loop (a box allows 20 minutes per call: the two loops can go in two calls)
-[ -n "$SWEEP_SKIP_MAIN" ] || for opts in ${SWEEP_SETS:-serialize_scans=0 queries_per_launch=1 queries_per_launch=3,blocks_per_cu=1 shape_kernels=0,block_threads=128 \
-            mq_fused=0,mq_i8=0 mq_tail_overlap=1,mq_blocks=2 multi_query=0,query_batch=5 contexts=1,blocks_per_cu=6 mask_dense=0,coalesce=0 \
-            mq_min=8,tie_mode=0 ring=8,mq_hits=256 mq_bf16=0 mq_overlap=0,mq_bf16_slack=0 sketch=1,sketch_min_rows=1 sketch=1,multi_query=0,sketch_extra=0,sketch_min_rows=1 mq_refine=0 first_batch=0,queries_per_launch=5 first_batch=1 finish_thread=0,mq_hits=256 radius_mq=0,radius_sort=0}; do
+[ -n "$SWEEP_SKIP_MAIN" ] || for opts in ${SWEEP_SETS:-serialize_scans=0 queries_per_launch=1 queries_per_launch=3,query_batch=5 \
+            force_matrix=1 multi_query=0 contexts=1,mask_dense=0,coalesce=0 mq_min=8,mq_hits=256 \
+            sketch=1,sketch_min_rows=1 sketch=1,multi_query=0,sketch_extra=0,sketch_min_rows=1 force_no_refine=1 \
+            finish_thread=0,radius_mq=0}; do
   run "$opts" tests -m gpu -q -x --ignore=tests/test_gpu_fullsize.py --ignore=tests/test_gpu_bench_launch.py \
       --deselect tests/test_gpu_multiquery.py::test_shared_sweep_matches_oracle \
       --deselect tests/test_gpu_multiquery.py::test_shared_sweep_quantized_rows \
@@ -34,7 +35,7 @@ run() {  # $1 = label, rest = pytest arguments
       --ignore=tests/test_gpu_comm.py
 done
 # shared-sweep variants on the shared-sweep tests (their statistics do not depend on these)
-for opts in ${SWEEP_MQ_SETS-mq_fused=0 mq_i8=0 mq_tail_overlap=1 mq_fused=0,mq_tail_overlap=1,serialize_scans=0 mq_bf16=0 mq_overlap=0 mq_fused=0,mq_bf16_slack=0 mq_i8_groups=1 mq_refine=0 mq_refine=0,mq_overlap=0 finish_thread=0}; do
+for opts in ${SWEEP_MQ_SETS-force_matrix=1,serialize_scans=0 force_no_refine=1 finish_thread=0,mq_hits=256}; do
   run "multiquery tests, $opts" tests/test_gpu_multiquery.py -q -x \
       --deselect tests/test_gpu_multiquery.py::test_fused_selection_overflow_falls_back
 done

@@ -298,6 +298,10 @@ class Collection:
                     return self._index.search_radius(q, args.Radius, allow=allow)
                 r, d, c = self._index.search_topk(q, args.K, allow=allow)
                 return r[0, : c[0]], d[0, : c[0]]
+            if self._order_stale and self._index.options.get("tie_mode", 0) != 0:
+                # tie_mode 1 keeps the fast answer for ties and counts no replay: the test below would never see one,
+                # so the deterministic mode re-pages up front
+                self._resort()
             if self._order_stale:
                 # rows out of sort.Strings order: did the answer depend on the visit order?  (the library re-answers
                 # ties among the best k+1 by an exact replay in ROW order and counts it; a radius result depends on

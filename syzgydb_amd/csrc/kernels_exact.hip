@@ -662,7 +662,9 @@ __global__ __launch_bounds__(256) void sort_hits_kernel(RerankOut *out, const ui
     for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) {
         if (i < n) {
             ent[i] = o[i];
-            key[i] = ordered_f64(ent[i].dist);
+            // (strictly below the padding key: a NaN with an all-ones payload orders as ~0 too, and a padding index
+            // sorted in front of it would copy an entry that was never staged)
+            key[i] = min(ordered_f64(ent[i].dist), ~0ull - 1ull);
         } else {
             key[i] = ~0ull;
         }

@@ -1713,36 +1713,90 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
             qf[i] = i < dim ? (float)(q64[(size_t)q * dim + i] * sc) : 0.0f;  // (padding: zeros, as in the rows)
     }
     if (tid == 0) n_band = 0;
-    WaveList wl;
-    wl.init(wl_lds + (size_t)wave * kp, kp, lane);
-    __syncthreads();
-    for (uint32_t i = tid; i < ((n + kRefineThreads - 1) / kRefineThreads) * kRefineThreads; i += kRefineThreads) {
-        const bool ok = i < n;
-        wl.offer(ok, ok ? cand[i] : kInvalidCand, lane);
-    }
-    wl.flush(lane);
-    __syncthreads();
-    block_merge_lists(wl_lds, NW, kp, MODE > 0 ? top : out, tid, kRefineThreads);
-    for (int i = tid; i < n_sent; i += kRefineThreads) out[kp + i] = sent[(size_t)q * n_sent + i];
-    if (MODE == 0) return;
-    __syncthreads();
-
-    // the band: sweep key <= t_kp + W
-    const uint64_t kth = top[kp - 1];
     float edge = 3.0e38f;  // fewer than kp candidates: everything collected is in the band
-    if (kth != kInvalidCand) {
-        const float t = key_from_ordered((uint32_t)(kth >> 32));
-        const float c = 1.01f * 0x1p-7f, nu = ((float)dim + (row_bits == 64 ? 20.0f : 16.0f)) * 0x1p-24f;  // key_eps (scan_query.cpp), bfloat16 branch
-        float eps;
-        if (MODE == 1) {
-            eps = c + 4.0f * nu + 1e-6f;
-        } else {  // key_eps (scan_query.cpp), bfloat16 euclid branch
-            const float qn = sqrtf((float)qnorm2[q]), rt = sqrtf(fmaxf(t, 0.0f));
-            const float s2 = 2.0f * qn + rt;
-            eps = 2.0f * c * qn * (1.1f * qn + rt) + c * c * qn * qn + 3.0f * nu * s2 * s2;
+    if (MODE == 0) {
+        WaveList wl;
+        wl.init(wl_lds + (size_t)wave * kp, kp, lane);
+        __syncthreads();
+        for (uint32_t i = tid; i < ((n + kRefineThreads - 1) / kRefineThreads) * kRefineThreads; i += kRefineThreads) {
+            const bool ok = i < n;
+            wl.offer(ok, ok ? cand[i] : kInvalidCand, lane);
         }
-        edge = t + 2.02f * eps;
-        if (!(edge < 3.0e38f)) edge = 3.0e38f;
+        wl.flush(lane);
+        __syncthreads();
+        block_merge_lists(wl_lds, NW, kp, out, tid, kRefineThreads);
+        for (int i = tid; i < n_sent; i += kRefineThreads) out[kp + i] = sent[(size_t)q * n_sent + i];
+        return;
+    }
+    for (int i = tid; i < n_sent; i += kRefineThreads) out[kp + i] = sent[(size_t)q * n_sent + i];
+    // The band needs ONE number of the sweep's keys: the kp-th smallest, t_kp (any value at or above it serves: the band
+    // only grows).  Two histogram rounds over the ordered key's top 12 + 12 bits (as mq_thr_radix_kernel) instead of
+    // round 3's sixteen sorted per-wave lists and their rank merge, which nothing else read: 60 -> ~30 us per batch.
+    {
+        uint32_t *hist = reinterpret_cast<uint32_t *>(qf + ((dim + 7) & ~7));  // [4096]
+        __shared__ uint32_t wsum[NW];
+        __shared__ uint32_t sel_bin, sel_below;
+        uint32_t prefix_bits = 0, below = 0;
+        bool found = n >= (uint32_t)kp;
+        for (int round = 0; round < 2 && found; round++) {
+            for (int i = tid; i < 4096; i += kRefineThreads) hist[i] = 0;
+            __syncthreads();
+            const int shift = round == 0 ? 20 : 8;
+            for (uint32_t i = tid; i < n; i += kRefineThreads) {
+                const uint32_t u = (uint32_t)(cand[i] >> 32);
+                if (round == 0 || (u >> 20) == prefix_bits) atomicAdd(&hist[(u >> shift) & 0xFFFu], 1u);
+            }
+            __syncthreads();
+            const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const uint32_t mine = h0 + h1 + h2 + h3;
+            uint32_t incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            if (tid == 0) sel_bin = 0xFFFFFFFFu;
+            __syncthreads();
+            uint32_t before = below;
+            for (int w = 0; w < wave; w++) before += wsum[w];
+            const uint32_t excl = before + incl - mine;
+            if (excl < (uint32_t)kp && excl + mine >= (uint32_t)kp) {  // exactly one thread
+                uint32_t acc = excl;
+                const uint32_t hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    if (acc < (uint32_t)kp && acc + hh[b] >= (uint32_t)kp) {
+                        sel_bin = 4 * tid + b;
+                        sel_below = acc;
+                    }
+                    acc += hh[b];
+                }
+            }
+            __syncthreads();
+            if (sel_bin == 0xFFFFFFFFu) {
+                found = false;  // (cannot happen with n >= kp; uniform over the block)
+            } else {
+                prefix_bits = round == 0 ? sel_bin : ((prefix_bits << 12) | sel_bin);
+                below = sel_below;
+            }
+            __syncthreads();
+        }
+        if (found) {
+            float t = key_from_ordered((prefix_bits << 8) | 0xFFu);  // the top of the kp-th key's 24-bit bin
+            if (!(t <= 3.0e38f)) t = 3.0e38f;
+            const float c = 1.01f * 0x1p-7f, nu = ((float)dim + (row_bits == 64 ? 20.0f : 16.0f)) * 0x1p-24f;  // key_eps (scan_query.cpp), bfloat16 branch
+            float eps;
+            if (MODE == 1) {
+                eps = c + 4.0f * nu + 1e-6f;
+            } else {  // key_eps (scan_query.cpp), bfloat16 euclid branch
+                const float qn = sqrtf((float)qnorm2[q]), rt = sqrtf(fmaxf(t, 0.0f));
+                const float s2 = 2.0f * qn + rt;
+                eps = 2.0f * c * qn * (1.1f * qn + rt) + c * c * qn * qn + 3.0f * nu * s2 * s2;
+            }
+            edge = t + 2.02f * eps;
+            if (!(edge < 3.0e38f)) edge = 3.0e38f;
+        }
     }
     const uint32_t uedge = ordered_key(edge);
     for (uint32_t i = tid; i < n; i += kRefineThreads) {
@@ -1848,7 +1902,7 @@ hipError_t launch_cand_refine(int mode, const uint8_t *rows, uint32_t pitch, int
     if (!cand_refine_applies(kp, cand_cap, dim, mode > 0)) return hipErrorInvalidValue;
     if (mode > 0 && row_bits != 32 && row_bits != 16 && row_bits != 64) return hipErrorInvalidValue;
     const size_t lds = ((size_t)kRefineMaxCands + (size_t)(kRefineThreads / 64) * kp + kp + kRefineMaxBand) * sizeof(uint64_t) +
-                       (mode > 0 ? (size_t)((dim + 7) & ~7) * sizeof(float) : 0);
+                       (mode > 0 ? (size_t)((dim + 7) & ~7) * sizeof(float) + 4096 * sizeof(uint32_t) : 0);
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -694,18 +694,6 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
     if (n == "slack") {
         if (value < 0 || value > 4096) return fail(SZG_E_INVALID, "slack out of range");
         ix->slack_min = (int)value;
-    } else if (n == "blocks_per_cu") {
-        if (value < 0 || value > 16) return fail(SZG_E_INVALID, "blocks_per_cu out of range");
-        ix->blocks_per_cu = (int)value;
-    } else if (n == "block_threads") {
-        if (value != 64 && value != 128 && value != 256)
-            return fail(SZG_E_INVALID, "block_threads must be 64/128/256");
-        ix->block_threads = (int)value;
-    } else if (n == "shape_kernels") {
-        ix->shape_kernels = value != 0;
-    } else if (n == "ring") {
-        if (value != 0 && value != 8) return fail(SZG_E_INVALID, "ring must be 0 (auto) or 8 (deep)");
-        ix->ring = (int)value;
     } else if (n == "queries_per_launch") {
         if (value < 1 || value > szg::kMaxSweepsPerLaunch)
             return fail(SZG_E_INVALID, "queries_per_launch out of range");
@@ -713,21 +701,12 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
     } else if (n == "query_batch") {
         if (value < 1 || value > kMaxBatch) return fail(SZG_E_INVALID, "query_batch out of range");
         ix->query_batch = (int)value;
-    } else if (n == "radius_sort") {
-        if (value < 0 || value > 1) return fail(SZG_E_INVALID, "radius_sort is 0 or 1");
-        ix->radius_sort = (int)value;
     } else if (n == "radius_mq") {
         if (value < 0 || value > 1) return fail(SZG_E_INVALID, "radius_mq is 0 or 1");
         ix->radius_mq = (int)value;
     } else if (n == "finish_thread") {
         if (value < 0 || value > 1) return fail(SZG_E_INVALID, "finish_thread is 0 or 1");
         ix->finish_thread = (int)value;
-    } else if (n == "short_call") {
-        if (value < 0 || value > kMaxBatch) return fail(SZG_E_INVALID, "short_call out of range");
-        ix->short_call = (int)value;
-    } else if (n == "first_batch") {
-        if (value < 0 || value > kMaxBatch) return fail(SZG_E_INVALID, "first_batch out of range");
-        ix->first_batch = (int)value;
     } else if (n == "contexts") {
         if (value < 1 || value > ix->n_ctx) return fail(SZG_E_INVALID, "contexts out of range");
         for (Shard *sh : ix->shards) {   // call while no search is in flight
@@ -741,40 +720,16 @@ int szg_set_option(szg_index *ix, const char *name, int64_t value)
                 sh->free_ctx.pop_back();
             }
         }
-    } else if (n == "lanes_per_row") {
-        // tuning hook: force the lane-group width L (power of two, L*P >= r16)
-        if (ix->layout.tiled) return fail(SZG_E_UNSUPPORTED, "lanes_per_row: tiled rows walk 4 lanes per row");
-        const int L = (int)value, r16 = ix->map.r16;
-        if (L < 1 || L > 64 || (L & (L - 1))) return fail(SZG_E_INVALID, "lanes_per_row must be a power of two <= 64");
-        const int P = (r16 + L - 1) / L;
-        ix->map = szg::RowMap{r16, L, P, 64 / L, 1, (L * P == r16) ? 1 : 0};
     } else if (n == "multi_query") {
         ix->multi_query = value != 0;
-    } else if (n == "mq_blocks") {
-        if (value < 1 || value > 6) return fail(SZG_E_INVALID, "mq_blocks must be 1..6");
-        ix->mq_blocks_max = (int)value;
     } else if (n == "mask_dense") {
         ix->mask_dense = value != 0;
     } else if (n == "coalesce") {
         ix->coalesce = value != 0;
-    } else if (n == "mq_fused") {
-        ix->mq_fused = value != 0;
-    } else if (n == "mq_i8") {
-        ix->mq_i8 = value != 0;
-    } else if (n == "mq_i8_groups") {
-        if (value < 1 || value > 2) return fail(SZG_E_INVALID, "mq_i8_groups must be 1 or 2");
-        ix->mq_i8_groups = (int)value;
-    } else if (n == "mq_refine") {
-        ix->mq_refine = value != 0;
-    } else if (n == "mq_bf16") {
-        ix->mq_bf16 = value != 0;
-    } else if (n == "mq_overlap") {
-        ix->mq_overlap = value != 0;
-    } else if (n == "mq_bf16_slack") {
-        if (value < 0 || value > 4000) return fail(SZG_E_INVALID, "mq_bf16_slack out of range");
-        ix->mq_bf16_slack = (int)value;
-    } else if (n == "mq_tail_overlap") {
-        ix->mq_tail_overlap = value != 0;
+    } else if (n == "force_matrix") {
+        ix->force_matrix = value != 0;
+    } else if (n == "force_no_refine") {
+        ix->force_no_refine = value != 0;
     } else if (n == "mq_hits") {
         if (value < 64 || value > 65536) return fail(SZG_E_INVALID, "mq_hits out of range");
         ix->mq_hits = (int)value;

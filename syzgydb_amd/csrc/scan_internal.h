@@ -315,43 +315,44 @@ struct szg_index {
     std::vector<uint64_t> sk_exc;        // rows without a usable sketch (zero rows, non-finite elements): always re-ranked
     bool sk_disabled = false;            // too many such rows
     std::vector<std::pair<std::string, int64_t>> opt_log;  // tunables set so far (replayed on the sketch index)
-    // tunables
+    // tunables (szg_set_option; include/syzgy_scan.h lists them)
     int slack_min = 16;
     int n_ctx = 3;            // contexts (and streams) per shard
     int n_ctx_active = 3;
-    int blocks_per_cu = 0;    // 0 = choose from the row format (scan_geometry)
-    int block_threads = 256;
     int query_batch = 16;     // queries per scan launch
-    int first_batch = 4;      // ... of a call's first launch (0 = query_batch): the card starts sooner
-    int short_call = 32;      // calls of up to this many one-sweep queries are ONE batch on the scan stream (0 = off)
-    int radius_sort = 1;      // a radius batch's re-ranked hits are sorted by distance on the device (lists of up to 2 048)
     int radius_mq = 1;        // radius batches of 2+ queries share one sweep of the corpus (the shared sweeps' collect form)
     int finish_thread = 1;    // shared-sweep calls of 3+ batches: a second host thread assembles the finished batches
                               // while the caller's prepares and enqueues the next ones (0 = one thread does both)
-    int shape_kernels = 1;    // use the row-shape-specialised scan kernels where they exist
-    int ring = 0;             // tuning hook: 8 = always the deep piece ring
     int queries_per_launch = 16;  // sweeps one scan launch walks back to back (query-major)
-    int force_escalate = 0;   // test hook: treat every first pass as uncertified
     int tie_mode = 0;         // 0: exact full replay on ties/NaN, 1: keep the fast answer
     int serialize_scans = 1;  // scan launches of a shard never overlap each other
     int multi_query = 1;      // share one sweep between the queries of a batch (MFMA path)
     int mask_dense = 1;       // masked sweeps whose masks pass most rows use the dense phase
     int coalesce = 1;         // concurrent single-query calls share sweeps (see Combiner)
-    int mq_fused = 1;         // shared sweep: threshold-collect selection instead of a score matrix
-    int mq_i8 = 1;            // 8-bit rows: exact integer shared sweep (v_mfma_i32_16x16x64_i8)
-    int mq_i8_groups = 2;     // int8 sweeps: query groups of 48 one launch walks (1 or 2)
-    int mq_refine = 1;        // shared sweeps: the batch's tail is one cand_refine launch + one rerank
-    int mq_bf16 = 1;          // 32-bit rows: shared sweep on bfloat16 roundings (v_mfma_f32_16x16x32_bf16), certified
-                              // against its own bound and re-ranked in float64 like every other path
-    int mq_overlap = 1;       // bfloat16 sweeps: a batch's threshold pass and its post-processing run on the context's
-                              // stream beside the neighbouring batches' sweeps (the sweep is a bare stream of the rows)
-    int mq_bf16_slack = 246;  // candidates kept beyond k by a bfloat16 sweep in the score-matrix form (its band holds more rows)
-    int mq_tail_overlap = 0;  // shared sweep: post-processing of a batch beside the next batch's sweep
     int mq_min = 2;           // smallest batch worth a shared sweep (measured: 2 queries already break even)
-    int mq_blocks_max = 6;    // query blocks of 16 per shared sweep (LDS image permitting; 3 at most for the
-                              // float32 and int8 sweeps, 6 for the bfloat16 sweep)
     int mq_hits = 1024;       // fused selection: candidates per query the full sweep is expected to collect
                               // (sets the prefix: n_rows * kp / mq_hits rows)
+    // test hooks: paths that occur by themselves only on particular data
+    int force_escalate = 0;   // treat every first pass as uncertified
+    int force_matrix = 0;     // shared sweeps: the score-matrix form (what an overflowing candidate buffer falls back to)
+    int force_no_refine = 0;  // shared sweeps: the batch's tail as separate re-score / select / rerank launches (kp > 256)
+    // settled by measurement (rounds 1-3): compile-time facts since round 4, A/B through -D and `make variant`
+    static constexpr int blocks_per_cu = 0;     // 0 = waves per CU chosen from the row format (scan_geometry)
+    static constexpr int block_threads = 256;
+    static constexpr int first_batch = 4;       // queries of a call's first launch: the card starts sweeping sooner
+    static constexpr int short_call = 32;       // calls of up to this many one-sweep queries are ONE batch on the scan stream
+    static constexpr int radius_sort = 1;       // a radius batch's re-ranked hits are sorted by distance on the device
+    static constexpr int shape_kernels = 1;     // row-shape-specialised kernels where they exist
+    static constexpr int ring = 0;              // 8 = always the deep piece ring
+    static constexpr int mq_i8 = 1;             // 8- / 4-bit rows: exact integer shared sweep (v_mfma_i32_16x16x64_i8)
+    static constexpr int mq_i8_groups = 2;      // ... one launch walks the passes of up to two groups of 48 queries
+    static constexpr int mq_bf16 = 1;           // 64- / 32- / 16-bit rows: shared sweep on bfloat16 roundings, certified
+                                                // against its own bound and re-ranked in float64 like every other path
+    static constexpr int mq_overlap = 1;        // a batch's threshold pass and tail on the context's stream beside the
+                                                // neighbouring batches' sweeps
+    static constexpr int mq_bf16_slack = 246;   // candidates kept beyond k where the lists hold bfloat16 keys themselves
+    static constexpr int mq_tail_overlap = 0;
+    static constexpr int mq_blocks_max = 6;     // query blocks of 16 per shared sweep (LDS image permitting)
     int timing = 0;           // 0 off, 1 HIP events around the scan launches, 2 + around the whole per-batch pipeline
     std::mutex stats_mu;
     // coalescing of concurrent single-query searches (szg_search_topk, n_queries == 1)

@@ -115,12 +115,12 @@ MqPlan mq_plan(const szg_index *ix, const Shard *sh, int kp, int kp_wide, int nq
     const uint64_t hits = std::max<uint64_t>((uint64_t)ix->mq_hits, 16ull * kp);
     p.prefix = ((sh->n_rows * (uint64_t)kp + hits - 1) / hits + 15) & ~15ull;
     p.prefix = std::max<uint64_t>(p.prefix, 16ull * kp);
-    p.fused = ix->mq_fused && !force_matrix && p.prefix * 4 <= sh->n_rows;
+    p.fused = !ix->force_matrix && !force_matrix && p.prefix * 4 <= sh->n_rows;
     p.stage2 = p.bf16 && p.fused;
     p.kp = p.bf16 && !p.fused ? std::max(kp, kp_wide) : kp;
     p.cand_cap = (uint32_t)(4 * hits);
     p.key_stride = p.fused ? (size_t)p.prefix : (((size_t)sh->n_rows + 3) & ~(size_t)3);
-    p.refine = p.fused && ix->mq_refine && szg::cand_refine_applies(p.kp, p.cand_cap, ix->dim, p.stage2);
+    p.refine = p.fused && !ix->force_no_refine && szg::cand_refine_applies(p.kp, p.cand_cap, ix->dim, p.stage2);
     return p;
 }
 

@@ -63,6 +63,7 @@ class ScanIndex:
             self._L.szg_index_destroy(self._h)
             self._h = ctypes.c_void_p()
         self._comm = None
+        self.options = {}
 
     def __del__(self):
         try:
@@ -290,6 +291,7 @@ class ScanIndex:
 
     def set_option(self, name, value):
         check(self._L.szg_set_option(self._h, name.encode(), int(value)), "szg_set_option")
+        self.options[name] = int(value)   # (what the host mirrors consult: e.g. tie_mode, collection.py)
 
 
 def f64_probe(op, a, b=None):

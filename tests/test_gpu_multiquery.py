@@ -158,8 +158,8 @@ def test_shared_sweep_euclidean_far_from_origin():
 @pytest.mark.parametrize("dim,n", [(768, 3000), (1536, 1500), (100, 4000), (37, 900), (64, 2000), (128, 2500), (3, 500)])
 def test_shared_sweep_int8_mfma(bits, metric, dim, n):
     """8- and 4-bit rows take the exact integer sweep (v_mfma_i32_16x16x64_i8 on the queries'
-    int8 digit planes; 4-bit rows as two nibble operands per piece); same bar, and with the sweep switched off
-    (mq_i8=0: one sweep per query) the answers are the same."""
+    int8 digit planes; 4-bit rows as two nibble operands per piece); same bar, and with the shared sweeps switched
+    off (multi_query=0: one sweep per query) the answers are the same."""
     rows = orc.synth_rows(331 + dim, 0, n, dim, bits)
     Q = orc.synth_vectors(332 + dim, 0, 48, dim)
     Q[7] *= 25.0
@@ -168,7 +168,7 @@ def test_shared_sweep_int8_mfma(bits, metric, dim, n):
     with ScanIndex(dim, bits, metric) as ix:
         ix.load(rows)
         for i8 in (1, 0):
-            ix.set_option("mq_i8", i8)
+            ix.set_option("multi_query", i8)
             ix.reset_stats()
             check(ix, rows, dim, Q, 10, bits=bits, metric=metric)
             assert ix.stats()["mq_queries"] == (48 if i8 else 0)
@@ -180,7 +180,7 @@ def test_fused_selection_overflow_falls_back(bits):
     """The shared sweep collects (query, row) pairs under a threshold taken from a prefix of the
     rows.  When the prefix is unrepresentative -- rows sorted worst-first, or one vector repeated
     thousands of times -- the candidate buffers overflow and the batch is redone through the
-    score matrix; answers stay the oracle's either way (and equal with mq_fused=0)."""
+    score matrix; answers stay the oracle's either way (and equal with force_matrix=1)."""
     dim, n = 32, 60000
     rng = np.random.default_rng(3)
     q0 = rng.standard_normal(dim)
@@ -196,7 +196,7 @@ def test_fused_selection_overflow_falls_back(bits):
         ix.set_option("tie_mode", 1)          # ties here are by construction; order among them is not the point
         r1, d1, c1 = ix.search_topk(Q, 10)
         assert ix.stats()["mq_fallbacks"] == 1
-        ix.set_option("mq_fused", 0)
+        ix.set_option("force_matrix", 1)
         r0, d0, c0 = ix.search_topk(Q, 10)
         assert ix.stats()["mq_queries"] == 32
         for qi in range(Q.shape[0]):
@@ -227,12 +227,11 @@ def test_bf16_sweep_matches_oracle(metric, dim, n):
             blocks = min(6, (160 * 1024 - 13600) // (((dim + 31) // 32) * 1024))
             assert st["mq_bf16_sweeps"] == st["mq_launches"] == (50 + 16 * blocks - 1) // (16 * blocks)
             assert st["mq_fallbacks"] == 0
-            ix.set_option("mq_blocks", 2)
             ix.reset_stats()
-            check(ix, rows, dim, Q, 10, metric=metric)
+            check(ix, rows, dim, Q[:30], 10, metric=metric)     # two query blocks: the NB = 2 kernels
+            check(ix, rows, dim, Q[:9], 10, metric=metric)      # one
             assert ix.stats()["mq_bf16_sweeps"] == 2
-            ix.set_option("mq_blocks", 6)
-        ix.set_option("mq_bf16", 0)
+        ix.set_option("multi_query", 0)
         ix.reset_stats()
         check(ix, rows, dim, Q[:20], 10, metric=metric)
         assert ix.stats()["mq_bf16_sweeps"] == 0
@@ -256,7 +255,7 @@ def test_bf16_sweep_16bit_rows(metric, dim, n):
             assert st["mq_bf16_sweeps"] == st["mq_launches"] >= 1 and st["mq_queries"] == 50
             assert st["mq_fallbacks"] == 0
         check(ix, rows, dim, Q[:20], 7, allow=allow, bits=16, metric=metric)
-        ix.set_option("mq_bf16", 0)
+        ix.set_option("multi_query", 0)
         ix.reset_stats()
         check(ix, rows, dim, Q[:20], 10, bits=16, metric=metric)
         assert ix.stats()["mq_bf16_sweeps"] == 0
@@ -276,7 +275,7 @@ def test_bf16_sweep_few_dims_far_from_origin(dim, fused):
         rows = orc.encode_rows(vec, 32)
         with ScanIndex(dim, 32, SZG_COSINE) as ix:
             ix.load(rows)
-            ix.set_option("mq_fused", fused)
+            ix.set_option("force_matrix", 1 - fused)
             ix.set_option("mq_min", 8)
             check(ix, rows, dim, Q, 1)
             check(ix, rows, dim, Q, 10, allow=rng.random(n) < 0.5)
@@ -345,10 +344,9 @@ def test_int8_sweep_two_query_groups_per_launch(bits, metric):
         st = ix.stats()
         if DEFAULT_TUNABLES:
             assert st["mq_queries"] == 140 and st["mq_launches"] == 4   # 2 calls x (48 + 22)
-        ix.set_option("mq_fused", 0)                                    # the score-matrix form
+        ix.set_option("force_matrix", 1)                                # the score-matrix form
         check(ix, rows, dim, Q, 10, bits=bits, metric=metric)
-        ix.set_option("mq_i8_groups", 1)
-        ix.set_option("mq_fused", 1)
+        ix.set_option("force_matrix", 0)
         check(ix, rows, dim, Q[:60], 10, bits=bits, metric=metric)
 
 
@@ -408,9 +406,9 @@ def test_bf16_sweep_64bit_rows(metric, dim, n):
         if DEFAULT_TUNABLES:
             assert st["mq_queries"] == 50 and st["mq_bf16_sweeps"] == st["mq_launches"] >= 1
         check(ix, rows, dim, Q[:20], 7, allow=allow, bits=64, metric=metric)
-        ix.set_option("mq_fused", 0)          # the score-matrix form (lists of bfloat16 keys, wide slack)
+        ix.set_option("force_matrix", 1)      # the score-matrix form (lists of bfloat16 keys, wide slack)
         check(ix, rows, dim, Q[:20], 10, bits=64, metric=metric)
-        ix.set_option("mq_fused", 1)
+        ix.set_option("force_matrix", 0)
         ix.set_option("multi_query", 0)
         ix.reset_stats()
         check(ix, rows, dim, Q[:9], 10, bits=64, metric=metric)
