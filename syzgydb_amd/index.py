@@ -51,6 +51,8 @@ class ScanIndex:
         check(self._L.szg_index_create(ctypes.byref(self._h), self.dim, self.quant_bits,
                                        self.metric, dev_arr, n_dev), "szg_index_create")
         self.row_bytes = int(self._L.szg_row_bytes(self.quant_bits, self.dim))
+        self.options = {}   # tunables set through this object (the host mirrors consult tie_mode)
+        self._comm = None
         # SZG_OPTIONS="name=value,...": tunables applied to every new handle (test sweeps)
         for item in os.environ.get("SZG_OPTIONS", "").split(","):
             if "=" in item:
@@ -63,7 +65,6 @@ class ScanIndex:
             self._L.szg_index_destroy(self._h)
             self._h = ctypes.c_void_p()
         self._comm = None
-        self.options = {}
 
     def __del__(self):
         try:
