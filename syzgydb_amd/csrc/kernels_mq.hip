@@ -1812,33 +1812,49 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
         for (int i = tid; i < kp; i += kRefineThreads) out[i] = kInvalidCand;
         return;
     }
-    // float32 keys for the band: one wave per candidate
+    // float32 keys for the band: one wave per candidate, four candidates' row gathers in flight per wave (the rows were
+    // streamed past the caches by the sweep: every gather is a full HBM round trip, and a wave that walked its ~7
+    // candidates one after the other paid seven of them in a row)
     const int epp = row_bits == 16 ? 8 : (row_bits == 64 ? 2 : 4), pieces = (dim + epp - 1) / epp;
-    for (uint32_t ci = wave; ci < nb; ci += NW) {
-        const uint32_t row = (uint32_t)band[ci];
-        const uint8_t *rp = rows + (size_t)row * pitch;
-        float dot = 0.f, nrm = 0.f;
-        uint32_t nz = 0;
-        for (int i = lane; i < pieces; i += 64) rescore_piece<MODE == 1>(rp, qf, i, row_bits, dim, dot, nrm, nz);
+    constexpr int U = 4;
+    for (uint32_t c0 = (uint32_t)wave * U; c0 < nb; c0 += NW * U) {
+        const uint8_t *rp[U];
+        uint32_t rowv[U];
+        float dot[U], nrm[U];
+        uint32_t nz[U];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            dot += __shfl_xor(dot, o);
-            if (MODE == 1) {
-                nrm += __shfl_xor(nrm, o);
-                nz |= __shfl_xor(nz, o);
+        for (int u = 0; u < U; u++) {
+            rowv[u] = (uint32_t)band[min(c0 + u, nb - 1)];  // (past the band's end: the last candidate again, not written)
+            rp[u] = rows + (size_t)rowv[u] * pitch;
+            dot[u] = nrm[u] = 0.f;
+            nz[u] = 0;
+        }
+        for (int i = lane; i < pieces; i += 64) {
+#pragma unroll
+            for (int u = 0; u < U; u++) rescore_piece<MODE == 1>(rp[u], qf, i, row_bits, dim, dot[u], nrm[u], nz[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                dot[u] += __shfl_xor(dot[u], o);
+                if (MODE == 1) {
+                    nrm[u] += __shfl_xor(nrm[u], o);
+                    nz[u] |= __shfl_xor(nz[u], o);
+                }
             }
+            float key;
+            if (MODE == 1) {  // exactly cand_rescore_kernel's key (the certification bound is the float32 sweeps')
+                key = -dot[u] * __frsqrt_rn(nrm[u]);
+                if (nrm[u] == 0.f) key = nz[u] ? -2.0f : 1.0f;
+                if (!(nrm[u] <= 3.0e38f)) key = -2.0f;  // norm overflow: forced in (see RowAcc::finish)
+            } else {
+                key = dot[u];
+            }
+            if (!(key == key)) key = 3.0e38f;
+            if (key > 3.0e38f) key = 3.0e38f;
+            if (lane == 0 && c0 + u < nb) band[c0 + u] = ((uint64_t)ordered_key(key) << 32) | rowv[u];
         }
-        float key;
-        if (MODE == 1) {  // exactly cand_rescore_kernel's key (the certification bound is the float32 sweeps')
-            key = -dot * __frsqrt_rn(nrm);
-            if (nrm == 0.f) key = nz ? -2.0f : 1.0f;
-            if (!(nrm <= 3.0e38f)) key = -2.0f;  // norm overflow: forced in (see RowAcc::finish)
-        } else {
-            key = dot;
-        }
-        if (!(key == key)) key = 3.0e38f;
-        if (key > 3.0e38f) key = 3.0e38f;
-        if (lane == 0) band[ci] = ((uint64_t)ordered_key(key) << 32) | row;
     }
     __syncthreads();
     // the kp best of the band by float32 key: rank by counting (entries are unique: the row is part of the word)
