@@ -733,7 +733,8 @@ func (m *gpuMirror) attachComm(cm *gpuComm, rowBase uint64) bool {
 // single-collection answer as GLOBAL rows (position in the unsharded visit order) with the reference's float64
 // distances; the rank that owns a row resolves it to its document.  historyDependent[i] reports equal distances
 // (or NaN) among the best K+1 of query i: the one case where the reference's order depends on its whole heap
-// history, which no single rank holds.
+// history, which no single rank holds -- the library then lets the heap travel rank 0 -> 1 -> ... in visit order,
+// each rank replaying consider() over its own rows, so the answer is the unsharded collection's, order included.
 func (m *gpuMirror) searchExactSharded(queries []float64, nq, k int) (rows []uint64, dist []float64, count []int32, historyDependent []bool, ok bool) {
 	m.mu.RLock()
 	defer m.mu.RUnlock()
@@ -755,4 +756,38 @@ func (m *gpuMirror) searchExactSharded(queries []float64, nq, k int) (rows []uin
 		historyDependent[i] = hist[i] != 0
 	}
 	return rows, dist, count, historyDependent, true
+}
+
+// SearchBatch is the multi-query entry point SURVEY.md 8f-4 asks for beside the single-query Search
+// (collection.go:569-711): the answers Search would give, query by query.  A list of exact searches of one kind --
+// top-k with one K, or radius searches -- is ONE library call whose queries share sweeps of the corpus on the matrix
+// cores (searchExactBatch); anything else is answered by Search itself, one by one.  INTEGRATION.md 1b shows the REST
+// handler that exposes it beside handleSearch (rest.go:371-487).
+func (c *Collection) SearchBatch(args []SearchArgs) []SearchResults {
+	out := make([]SearchResults, len(args))
+	batch := c.gpu != nil && len(args) > 1
+	for i := range args {
+		a := args[i]
+		batch = batch && a.Precision == "exact" && (a.K > 0 || a.Radius > 0) &&
+			(a.Radius > 0) == (args[0].Radius > 0) && (a.Radius > 0 || a.K == args[0].K)
+	}
+	if batch {
+		c.mutex.RLock()
+		res, ok := c.gpu.searchExactBatch(c, args, nil)
+		_, numRecords := c.spanfile.GetStats()
+		c.mutex.RUnlock()
+		if ok {
+			for i := range res {
+				out[i] = SearchResults{Results: res[i], PercentSearched: 100}
+				if numRecords == 0 { // collection.go:706-709
+					out[i].PercentSearched = 0
+				}
+			}
+			return out
+		}
+	}
+	for i := range args {
+		out[i] = c.Search(args[i])
+	}
+	return out
 }

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SZG_ABI_VERSION 3
+#define SZG_ABI_VERSION 4
 
 /* DistanceMethod, collection.go:186-189 */
 #define SZG_EUCLIDEAN 0

@@ -60,7 +60,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libsyzgy_scan.so does not export %s" % name
     assert sorted(_lib.EXPORTS) == declared
-    assert L.szg_abi_version() == 3
+    assert L.szg_abi_version() == 4
     pager = _declared_symbols("syzgy_pager.h")
     assert sorted(_lib.PAGER_EXPORTS) == pager
     for name in pager:
