@@ -664,7 +664,8 @@ __global__ __launch_bounds__(256) void sort_hits_kernel(RerankOut *out, const ui
             ent[i] = o[i];
             // (strictly below the padding key: a NaN with an all-ones payload orders as ~0 too, and a padding index
             // sorted in front of it would copy an entry that was never staged)
-            key[i] = min(ordered_f64(ent[i].dist), ~0ull - 1ull);
+            const uint64_t ok_ = ordered_f64(ent[i].dist);
+            key[i] = ok_ == ~0ull ? ~0ull - 1ull : ok_;  // (no min(): its overloads take uint64_t through double)
         } else {
             key[i] = ~0ull;
         }
