@@ -234,3 +234,27 @@ def test_radius_batch_16bit_rows_with_padding_codes_and_small_queries(dim, metri
         for j in range(12):
             er, ed, _ = orc.search_exact(rows, dim, 16, metric, Q[j], k=5)
             assert [int(x) for x in r[j, : c[j]]] == [int(x) for x in er] and (d[j, : c[j]] == np.asarray(ed)).all(), j
+
+
+@pytest.mark.parametrize("bits,metric,dim,n,nth", [(4, SZG_EUCLIDEAN, 768, 5000, 60), (4, SZG_EUCLIDEAN, 384, 1000, 61),
+                                                   (8, SZG_COSINE, 2, 3000, 60), (4, SZG_EUCLIDEAN, 100, 65, 56)])
+def test_hits_whose_distances_differ_in_their_last_bits_keep_the_references_order(bits, metric, dim, n, nth):
+    """Coarse rows (4-bit Euclidean, 2-dimensional 8-bit cosine): a result holds exactly equal distances AND distances
+    that differ only in their last bits.  The device-side sort of a batch's hits compares 64-bit ordered keys; round 4
+    briefly clamped them through min(), whose overload took uint64 through double -- 11 bits gone, near-equal
+    distances out of order, nothing downstream looks at a list it believes sorted (scripts/fuzz_gpu.py seed 401: ten
+    of 6 443 cases).  One sweep per query and shared sweeps alike."""
+    rows = orc.synth_rows(SEED + 700 + dim, 0, n, dim, bits)
+    Q = orc.synth_vectors(SEED + 701 + dim, 0, 17, dim)
+    with ScanIndex(dim, bits, metric) as ix:
+        ix.load(rows)
+        radii = []
+        for i in range(len(Q)):
+            _, od, _ = orc.search_exact(rows, dim, bits, metric, Q[i], k=min(nth, n))
+            fin = [x for x in od if x == x and x > 0]
+            radii.append(float(fin[-1]) if fin else 0.5)
+        for shared in (1, 0):
+            ix.set_option("radius_mq", shared)
+            check(ix.search_radius_batch(Q, radii), rows, dim, bits, metric, Q, radii)
+            r1, d1 = ix.search_radius(Q[3], radii[3])
+            check([(r1, d1)], rows, dim, bits, metric, Q[3:4], radii[3:4])
