@@ -475,10 +475,17 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
         }
         const uint64_t row = tile * 16 + trow;
         const float inv = __frsqrt_rn(nrm);
+        // What depends on the ROW alone is settled once per lane, not once per (row, query) pair: a zero row (distance
+        // 1.0, collection.go:828-830) or a norm beyond float32 (forced in: see RowAcc::finish) has one fixed key for
+        // every query.  The two clamps (NaN and +inf -> the worst finite key) are ONE v_min_f32 -- minnum returns the
+        // other operand for a NaN -- and the hit bits are combined without short-circuits: round 3's form compiled to
+        // three exec-masked branches and ~12 vector instructions per pair, 40 % of the sweep's vector instructions on
+        // 16-bit rows (PMC: 57 per K-step against the 30 of its step loop), on kernels whose SIMDs issue all the time.
+        const bool use_fixed = METRIC == kCosine && (nrm == 0.f || !(nrm <= 3.0e38f));
+        const float fixed = (nrm == 0.f && !nz) ? 1.0f : -2.0f;
         if (COLLECT || row < a.n_rows) {
             float keys[NB][4];
             uint32_t hm = 0;
-            const bool row_ok = row < a.n_rows;
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 const float4 th = COLLECT ? *reinterpret_cast<const float4 *>(thr_lds + b * 16 + c * 4)
@@ -489,25 +496,25 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
                 const float qnv[4] = {qn4.x, qn4.y, qn4.z, qn4.w};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int q = b * 16 + c * 4 + r;
                     float key;
                     if (METRIC == kCosine) {
                         key = -acc[b][r] * inv;
-                        if (nrm == 0.f) key = nz ? -2.0f : 1.0f;  // zero row: distance 1.0 (collection.go:828-830)
-                        if (!(nrm <= 3.0e38f)) key = -2.0f;  // norm overflow: forced in (see RowAcc::finish)
+                        key = use_fixed ? fixed : key;
                     } else {
                         key = fmaf(-2.0f, acc[b][r], nrm + qnv[r]);
                     }
-                    if (!(key == key)) key = 3.0e38f;
-                    if (key > 3.0e38f) key = 3.0e38f;
+                    key = fminf(key, 3.0e38f);  // NaN, +inf -> 3e38
                     keys[b][r] = key;
-                    if (COLLECT)
-                        hm |= (row_ok && q < a.n_queries && key <= thv[r]) ? (1u << (b * 4 + r)) : 0u;
-                    else if (q < a.n_queries)
-                        a.keys[(size_t)q * a.key_stride + row] = key;
+                    if (COLLECT)  // (unused query slots carry a threshold of -3e38: never a hit)
+                        hm |= (uint32_t)(key <= thv[r]) << (b * 4 + r);
+                    else if (b * 16 + c * 4 + r < a.n_queries)
+                        a.keys[(size_t)(b * 16 + c * 4 + r) * a.key_stride + row] = key;
                 }
             }
-            if (COLLECT) offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row);
+            if (COLLECT) {
+                hm = row < a.n_rows ? hm : 0u;
+                offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row);
+            }
         }
         if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores: gfx9 counts loads and stores in ONE vmcnt, a pending store would turn every ring wait into vmcnt(0)
 #pragma unroll
@@ -691,10 +698,11 @@ __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArg
         nrm += __shfl_xor(nrm, 32);
         const uint64_t row = tile * 16 + trow;
         const float inv = __frsqrt_rn(nrm);
+        // (a decoded code is odd: the norm of a 16-bit row is neither 0 nor beyond float32 -- no fixed keys here; the
+        // clamps are one v_min_f32 and the hit bits have no short-circuits: see mq_score_bf16s_kernel's finish)
         if (COLLECT || row < a.n_rows) {
             float keys[NB][4];
             uint32_t hm = 0;
-            const bool row_ok = row < a.n_rows;
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 const float4 th = COLLECT ? *reinterpret_cast<const float4 *>(thr_lds + b * 16 + c * 4)
@@ -705,24 +713,19 @@ __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArg
                 const float qnv[4] = {qn4.x, qn4.y, qn4.z, qn4.w};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int q = b * 16 + c * 4 + r;
-                    float key;
-                    if (METRIC == kCosine) {
-                        key = -acc[b][r] * inv;  // (a decoded code is odd: the norm is never 0; exactly mq_score_bf16s_kernel's key)
-                        if (!(nrm <= 3.0e38f)) key = -2.0f;
-                    } else {
-                        key = fmaf(-2.0f, acc[b][r], nrm + qnv[r]);
-                    }
-                    if (!(key == key)) key = 3.0e38f;
-                    if (key > 3.0e38f) key = 3.0e38f;
+                    float key = METRIC == kCosine ? -acc[b][r] * inv : fmaf(-2.0f, acc[b][r], nrm + qnv[r]);
+                    key = fminf(key, 3.0e38f);  // NaN, +inf -> 3e38
                     keys[b][r] = key;
-                    if (COLLECT)
-                        hm |= (row_ok && q < a.n_queries && key <= thv[r]) ? (1u << (b * 4 + r)) : 0u;
-                    else if (q < a.n_queries)
-                        a.keys[(size_t)q * a.key_stride + row] = key;
+                    if (COLLECT)  // (unused query slots carry a threshold of -3e38: never a hit)
+                        hm |= (uint32_t)(key <= thv[r]) << (b * 4 + r);
+                    else if (b * 16 + c * 4 + r < a.n_queries)
+                        a.keys[(size_t)(b * 16 + c * 4 + r) * a.key_stride + row] = key;
                 }
             }
-            if (COLLECT) offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row);
+            if (COLLECT) {
+                hm = row < a.n_rows ? hm : 0u;
+                offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row);
+            }
         }
         if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores (one vmcnt for loads and stores)
 #pragma unroll
@@ -991,7 +994,7 @@ __global__ __launch_bounds__(kMq8Threads) void mq_score_i8_kernel(const MqArgs a
                     // (finite by construction: integer sums, norm >= dim > 0 -- no NaN / inf clamps)
                     keys[b][r] = key;
                     if (COLLECT)
-                        hm |= (row_ok && key <= thv[r]) ? (1u << (b * 4 + r)) : 0u;  // unused queries: thr = -3e38
+                        hm |= (uint32_t)(row_ok & (key <= thv[r])) << (b * 4 + r);  // unused queries: thr = -3e38
                     else if (qoff + q < a.n_queries)
                         a.keys[(size_t)(qoff + q) * a.key_stride + row] = key;
                 }
