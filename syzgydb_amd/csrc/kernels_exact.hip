@@ -695,6 +695,46 @@ __global__ __launch_bounds__(256) void sort_hits_kernel(RerankOut *out, const ui
 }
 }  // namespace
 
+// ---- resident row norms (16-bit rows) ---------------------------------------------------------------------------
+// 16 lanes per row, 16 rows per block of 256 threads; every lane sums the squares of its 16-byte pieces' real
+// elements (the padding codes of the last piece stay out, as in the sweeps), the 16 partial sums are added with DPP.
+namespace {
+__global__ __launch_bounds__(256) void row_norms16_kernel(const uint8_t *rows, uint32_t pitch, int dim, uint64_t first_row,
+                                                          uint64_t n_rows, float *out)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    float s = 0.f;
+    if (r < n_rows) {
+        const uint8_t *rp = rows + (first_row + r) * (uint64_t)pitch;
+        const int pieces = (dim + 7) / 8;
+        for (int i = l; i < pieces; i += 16) {
+            const uint4 w = reinterpret_cast<const uint4 *>(rp)[i];
+            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+            const int nk = min(8, dim - i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t v = (ww[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                const float x = fmaf((float)v, 2.0f, -65535.0f);
+                s = e < nk ? fmaf(x, x, s) : s;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (r < n_rows && l == 0) out[first_row + r] = s;
+}
+}  // namespace
+
+hipError_t launch_row_norms16(const uint8_t *rows, uint32_t pitch, int dim, uint64_t first_row, uint64_t n_rows,
+                              float *out, hipStream_t stream)
+{
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(row_norms16_kernel, dim3((unsigned)((n_rows + 15) / 16)), dim3(256), 0, stream, rows, pitch, dim,
+                       first_row, n_rows, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_sort_hits(RerankOut *out, const uint32_t *count, uint32_t count_stride, uint32_t cap, int n_queries,
                             hipStream_t stream)
 {

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
 #define SZG_MQD_WAVES 12  // waves per block (one block per CU): no staging KiB per wave, <= 168 registers: three per SIMD
 #endif
 constexpr int kMqdThreads = 64 * SZG_MQD_WAVES;
-template <int NB, int METRIC, bool COLLECT>
+template <int NB, int METRIC, bool COLLECT, bool RN>
 __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArgs a)
 {
     constexpr int D = COLLECT ? SZG_MQD_RING : 8;  // (the threshold pass: a few tiles per wave, latency-bound)
@@ -668,7 +668,9 @@ __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArg
             bop_[i] = (int)__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x_[2 * i], x_[2 * i + 1]}, bf16x2)); \
         }                                                                                \
         float s_ = 0.f;                                                                  \
-        if ((partial || pad16) && cs == KT - 1) { /* (wave-uniform) the row's last K-step: zero-block lanes and the */ \
+        if (RN) { /* resident norms: this tile's 16 arrive while its K-steps run */       \
+            if (cs == 0) nrm = a.row_norm[min(ctile * 16 + trow, (uint64_t)a.n_rows - 1)]; \
+        } else if ((partial || pad16) && cs == KT - 1) { /* (wave-uniform) the row's last K-step: zero-block lanes and the */ \
             /* padding codes of the last piece decode to -65535 -- zeros stand against them in the image, and they */ \
             /* stay out of the norm */                                                   \
             const int nk_ = past ? 0 : (c == last_valid - 1 ? 8 - pad16 : 8);            \
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArg
         } else {                                                                         \
             _Pragma("unroll") for (int i = 0; i < 8; i++) s_ = fmaf(x_[i], x_[i], s_);   \
         }                                                                                \
-        nrm += s_;                                                                       \
+        if (!RN) nrm += s_;                                                              \
         const int qnext_ = lane + (cs + 1 == KT ? 0 : cs + 1) * (NB * 64);               \
         _Pragma("unroll") for (int b = 0; b < NB; b++)                                   \
         {                                                                                \
@@ -694,8 +696,10 @@ __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArg
 
     auto finish_tile = [&](uint64_t tile) {
         // row norms: over the row's 4 k-group lanes (the MFMA result's column = the row, as the operand's)
-        nrm += __shfl_xor(nrm, 16);
-        nrm += __shfl_xor(nrm, 32);
+        if (!RN) {
+            nrm += __shfl_xor(nrm, 16);
+            nrm += __shfl_xor(nrm, 32);
+        }
         const uint64_t row = tile * 16 + trow;
         const float inv = __frsqrt_rn(nrm);
         // (a decoded code is odd: the norm of a 16-bit row is neither 0 nor beyond float32 -- no fixed keys here; the
@@ -1997,7 +2001,7 @@ hipError_t launch_mq_score_bf16_t(const MqArgs &a, int grid, size_t lds, hipStre
 template <int NB, int METRIC, bool COLLECT>
 hipError_t launch_mq_score_bf16d_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
-    auto *kern = &mq_score_bf16d_kernel<NB, METRIC, COLLECT>;
+    auto *kern = a.row_norm ? &mq_score_bf16d_kernel<NB, METRIC, COLLECT, true> : &mq_score_bf16d_kernel<NB, METRIC, COLLECT, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -234,6 +234,7 @@ int reset_shards(szg_index *ix, const std::vector<uint64_t> &counts)
         HIPCHK(hipDeviceSynchronize());
         sh->first = first;
         sh->n_rows = 0;
+        sh->norm_valid = 0;
         sh->n_live = 0;
         sh->has_dead = false;
         int rc = shard_reserve(ix, sh, counts[s]);
@@ -404,6 +405,7 @@ void szg_index_destroy(szg_index *ix)
         (void)hipFree(sh->sk_buf);
         (void)hipFree(sh->rows);
         (void)hipFree(sh->live_bits);
+        (void)hipFree(sh->row_norm);
         delete sh;
     }
     delete ix;
@@ -542,6 +544,8 @@ int szg_index_overwrite_f64(szg_index *ix, uint64_t row, const double *vector)
     hipError_t e = hipMemcpy(stage, vector, (size_t)ix->dim * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = szg::launch_synth(ix->bits, sh->rows, ix->layout, local, ix->dim, 1, 0, 0, stage, nullptr);
+    if (e == hipSuccess && sh->row_norm && local < sh->norm_valid)
+        e = szg::launch_row_norms16(sh->rows, ix->pitch, ix->dim, local, 1, sh->row_norm, nullptr);
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) return fail(SZG_E_DEVICE, "overwrite_f64", e);
     return SZG_OK;
@@ -558,7 +562,12 @@ int szg_index_overwrite(szg_index *ix, uint64_t row, const uint8_t *row_bytes)
     note_overwritten(ix, row);
     HIPCHK(hipSetDevice(sh->device));
     HIPCHK(hipDeviceSynchronize());
-    return upload_rows(ix, sh, local, row_bytes, 1);
+    const int rc = upload_rows(ix, sh, local, row_bytes, 1);
+    if (rc == SZG_OK && sh->row_norm && local < sh->norm_valid) {
+        HIPCHK(szg::launch_row_norms16(sh->rows, ix->pitch, ix->dim, local, 1, sh->row_norm, nullptr));
+        HIPCHK(hipStreamSynchronize(nullptr));
+    }
+    return rc;
     SZG_CATCH
 }
 

@@ -260,6 +260,11 @@ struct Shard {
     std::mutex chain_mu;
     hipStream_t scan_stream = nullptr;
     uint8_t *zero16 = nullptr;   // 16 zero bytes idle lanes of the multi-query sweep read
+    // resident float32 row norms (16-bit rows, shared bfloat16 sweep): rows [0, norm_valid) are up to date; load /
+    // synth reset it, appended rows are caught up before the next shared sweep, an overwritten row at once
+    float *row_norm = nullptr;
+    uint64_t norm_cap = 0, norm_valid = 0;
+    std::mutex norm_mu;
     // device staging of the mutation entry points (load / append / overwrite / read-back): kept
     // between calls, so AddDocument in a loop pays no hipMalloc / hipFree per row
     uint8_t *stage = nullptr;
@@ -437,6 +442,8 @@ int search_radius_impl(szg_index *ix, const double *queries, int n_queries, cons
                        const uint64_t *const *masks, std::vector<std::vector<HeapItem>> *results);
 
 // ---- scan_mq.cpp
+// the shard's resident row norms are complete (16-bit rows; no-op otherwise): called before a shared sweep is enqueued
+int ensure_row_norms(szg_index *ix, Shard *sh);
 int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int nq, int nb, bool has_allow,
                     bool force_matrix = false);
 
