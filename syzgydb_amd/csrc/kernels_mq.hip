@@ -569,16 +569,25 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
 // ---- 16-bit rows without the LDS stage: the codes arrive in the MFMA operand layout ---------------------------------
 //
 // A 16-byte chunk of a 16-bit row is eight codes -- exactly one lane's share (eight bfloat16) of the B operand of
-// v_mfma_f32_16x16x32_bf16.  So lane (row = lane & 15, k-group = lane >> 4) loads ITS chunk of K-step k (64 bytes of the
-// row) straight from HBM, decodes (n = 2v - 65535), rounds to bfloat16 in registers and multiplies: no ds_write /
-// ds_read / wait between the load and the matrix instruction.  The staged kernel above reads 128-byte segments of 8
-// rows per instruction, which streams better (scripts/readbw: 6.95 against 6.2 TB/s for 64-byte segments of 16 rows),
-// but on 16-bit rows its chain -- 56 VALU of decode, then write -> read -> wait TWICE per step, then the MFMAs --
-// held the sweep at 4.2-5.0 TB/s with two waves per SIMD to hide it and no register-allocation-proof way to
-// software-pipeline it (round 4: the allocator answered every staged-operand pipeline with copies of the load ring at
-// the loop's end, i.e. vmcnt(0)).  Here the chain is load -> 28 VALU -> 6 MFMAs.
+// v_mfma_f32_16x16x32_bf16 (lane = k-group * 16 + row).  So the lanes load the chunks themselves, decode
+// (n = 2v - 65535), round to bfloat16 in registers and multiply: no ds_write / ds_read / wait between the load and the
+// matrix instruction, where the staged kernel above -- 56 VALU of decode, then write -> read -> wait TWICE per step --
+// held 16-bit rows at 4.2-5.0 TB/s.
+//
+// WHICH chunk a lane loads is the round-4 lesson.  Loading the operand layout directly (lane = row & 15, chunk =
+// lane >> 4: 64 bytes of each of 16 rows per instruction, the line's other half one instruction later) streams at
+// 5.1-5.6 TB/s with NOTHING but the loads in the kernel (scripts/readbw/rowpat, mode 0), and the sweep sat at 5.3-5.5
+// whatever was removed from its arithmetic (resident norms: 8 of 30 VALU per step gone, same time).  128 bytes of each
+// of 8 rows per instruction (lane = row & 7, chunk = lane >> 3) streams at 7.0-7.2 (mode 2).  So a DOUBLE step loads X
+// = rows 0-7 and Y = rows 8-15 of the tile, 128 bytes of each, and one DPP exchange per dword (row_ror:8 -- lane L
+// takes from lane L ^ 8 -- under a bank mask) turns the pair into two operands in MFMA layout:
+//     E[L] = L & 8 ? Y[L ^ 8] : X[L]      row L & 15, chunk 2 * (L >> 4)        (the even chunks of the 128 bytes)
+//     O[L] = L & 8 ? Y[L] : X[L ^ 8]      row L & 15, chunk 2 * (L >> 4) + 1    (the odd chunks)
+// The k order inside a matrix instruction is free as long as both operands agree, so the A operands are the SAME image
+// read at permuted addresses: k-group g of E pairs with chunk 2g = K-step 2t + (g >> 1), k-group 2 (g & 1) of the
+// image; O with the k-group after it.
 #ifndef SZG_MQD_RING
-#define SZG_MQD_RING 3  // 16-byte loads per lane in flight (3 x 1 KiB per wave; 3..6 measure within 2 %)
+#define SZG_MQD_RING 2  // PAIRS of 16-byte loads per lane in flight (2 x 2 KiB per wave)
 #endif
 #ifndef SZG_MQD_WAVES
 #define SZG_MQD_WAVES 12  // waves per block (one block per CU): no staging KiB per wave, <= 168 registers: three per SIMD
@@ -587,17 +596,15 @@ constexpr int kMqdThreads = 64 * SZG_MQD_WAVES;
 template <int NB, int METRIC, bool COLLECT, bool RN>
 __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArgs a)
 {
-    constexpr int D = COLLECT ? SZG_MQD_RING : 8;  // (the threshold pass: a few tiles per wave, latency-bound)
+    constexpr int D = COLLECT ? SZG_MQD_RING : 4;  // (the threshold pass: a few tiles per wave, latency-bound)
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int nwaves = blockDim.x >> 6;
-    const int KT = (a.r16 + 3) / 4;               // K-steps (32 elements, 64 bytes of a row) per row, the last possibly short
-    const int last_valid = a.r16 - 4 * (KT - 1);  // 16-byte chunks of the last K-step that belong to the row (1..4)
-    const bool partial = last_valid < 4;
-    const int n16 = KT * NB * 64;
-    const int pad16 = a.r16 * 8 - a.dim;          // padding codes in the row's last 16-byte piece
+    const int DT = (a.r16 + 7) / 8;        // double steps (64 elements, 128 bytes of a row) per row, the last possibly short
+    const bool partial = (a.r16 & 7) != 0;
+    const int n16 = 2 * DT * NB * 64;      // the image holds an even number of K-steps (mq_bf16_image_bytes), zero-filled
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
@@ -617,48 +624,53 @@ __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArg
         hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
         hb.n = 0;
     }
-    const int trow = lane & 15, c = lane >> 4;
+    const int row8 = lane & 7, chunk = lane >> 3;  // as loaded: 128 bytes of each of 8 rows
+    const int trow = lane & 15, c = lane >> 4;     // as multiplied (after the exchange), and the result's layout
     const uint64_t n_tiles = ((uint64_t)a.n_rows + 15) / 16;
     const uint64_t tile_stride = (uint64_t)gridDim.x * nwaves;
     const uint64_t tile_first = (uint64_t)blockIdx.x * nwaves + wave;
     const uint64_t n_it = tile_first < n_tiles ? (n_tiles - tile_first + tile_stride - 1) / tile_stride : 0;
-    const uint64_t NP = n_it * (uint64_t)KT;
-    const bool past = c >= last_valid;  // this lane's chunk of a short last K-step lies beyond the row: the zero block
+    const uint64_t NP = n_it * (uint64_t)DT;
+    const bool past = (DT - 1) * 8 + chunk >= a.r16;  // this lane's chunk of a short last double step lies beyond the row
+    // the A operand of (double step t, half h, block b): qimg[t * 2 * NB * 64 + h * 16 + b * 64 + lane_e]
+    const int lane_e = trow + 32 * (c & 1) + (c >> 1) * (NB * 64);
 
     uint64_t itile = tile_first, ctile = tile_first;
     int is = 0, cs = 0;
-    u32x4 ring[D];
+    u32x4 ring[2 * D];
     f32x4 acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     float nrm = 0.f;
     v4i32b qn[NB];
-    auto row_ptr = [&](uint64_t tile) -> const uint8_t * {
-        const uint64_t r = min(tile * 16 + trow, (uint64_t)a.n_rows - 1);  // past the end: a valid row, discarded
-        return a.rows + (size_t)r * a.pitch + (size_t)c * 16;
+    auto row_ptr = [&](uint64_t tile, int half) -> const uint8_t * {
+        const uint64_t r = min(tile * 16 + half * 8 + row8, (uint64_t)a.n_rows - 1);  // past the end: a valid row, discarded
+        return a.rows + (size_t)r * a.pitch + (size_t)chunk * 16;
     };
-    const uint8_t *iptr = row_ptr(tile_first);
+    const uint8_t *ipx = row_ptr(tile_first, 0), *ipy = row_ptr(tile_first, 1);
 
 #define MQD_ISSUE(u)                                                                     \
     {                                                                                    \
-        const bool z_ = partial && is == KT - 1 && past;                                 \
-        ring[u] = load_nt(z_ ? a.zero16 : iptr); /* (plain: the line's other half is the next K-step's) */ \
-        if (++is == KT) {                                                                \
+        const bool z_ = partial && is == DT - 1 && past;                                 \
+        ring[2 * (u)] = load_stream<true>(z_ ? a.zero16 : ipx); /* (whole lines, used once: past the caches) */ \
+        ring[2 * (u) + 1] = load_stream<true>(z_ ? a.zero16 : ipy);                      \
+        if (++is == DT) {                                                                \
             is = 0;                                                                      \
             itile += tile_stride;                                                        \
-            iptr = row_ptr(itile);                                                       \
+            ipx = row_ptr(itile, 0);                                                     \
+            ipy = row_ptr(itile, 1);                                                     \
         } else {                                                                         \
-            iptr += 64;                                                                  \
+            ipx += 128;                                                                  \
+            ipy += 128;                                                                  \
         }                                                                                \
     }
 
-    // (Tried: the decode in packed float32 pairs -- v_pk_fma_f32 for n = 2v - 65535 and for the norm, 20 instead of 28
-    // vector instructions per K-step -- measured 3-5 % SLOWER on the same box; 8 instead of 12 waves, rings of 3..6:
-    // all within 2 % of each other.  profiles/r04_bf16_16bit_experiments.txt.)
-#define MQD_CONSUME(u)                                                                   \
+    // one operand (half h_ of the double step): decode, norm, NB matrix instructions, the next operands' reads
+    // (Tried on the 64-byte form: the decode in packed float32 pairs -- v_pk_fma_f32, 20 instead of 28 vector
+    // instructions per K-step -- 3-5 % SLOWER on the same box.  profiles/r04_bf16_16bit_experiments.txt.)
+#define MQD_HALF(raw_, h_)                                                               \
     {                                                                                    \
-        const u32x4 v_ = ring[u];                                                        \
-        const uint32_t w_[4] = {v_.x, v_.y, v_.z, v_.w};                                 \
+        const uint32_t w_[4] = {raw_.x, raw_.y, raw_.z, raw_.w};                         \
         float x_[8];                                                                     \
         v4i32b bop_;                                                                     \
         _Pragma("unroll") for (int i = 0; i < 4; i++)                                    \
@@ -667,19 +679,21 @@ __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArg
             x_[2 * i + 1] = fmaf((float)(w_[i] >> 16), 2.0f, -65535.0f);                 \
             bop_[i] = (int)__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x_[2 * i], x_[2 * i + 1]}, bf16x2)); \
         }                                                                                \
-        float s_ = 0.f;                                                                  \
-        if (RN) { /* resident norms: this tile's 16 arrive while its K-steps run */       \
-            if (cs == 0) nrm = a.row_norm[min(ctile * 16 + trow, (uint64_t)a.n_rows - 1)]; \
-        } else if ((partial || pad16) && cs == KT - 1) { /* (wave-uniform) the row's last K-step: zero-block lanes and the */ \
-            /* padding codes of the last piece decode to -65535 -- zeros stand against them in the image, and they */ \
-            /* stay out of the norm */                                                   \
-            const int nk_ = past ? 0 : (c == last_valid - 1 ? 8 - pad16 : 8);            \
-            _Pragma("unroll") for (int i = 0; i < 8; i++) s_ = i < nk_ ? fmaf(x_[i], x_[i], s_) : s_; \
+        if (RN) { /* resident norms: this tile's 16 arrive while its steps run */         \
+            if ((h_) == 0 && cs == 0) nrm = a.row_norm[min(ctile * 16 + trow, (uint64_t)a.n_rows - 1)]; \
         } else {                                                                         \
-            _Pragma("unroll") for (int i = 0; i < 8; i++) s_ = fmaf(x_[i], x_[i], s_);   \
+            float s_ = 0.f;                                                              \
+            if (cs == DT - 1) { /* (wave-uniform) the row's last double step: zero-block lanes and the padding codes */ \
+                /* of the last chunk decode to -65535 -- zeros stand against them in the image, and they stay out of */ \
+                /* the norm */                                                           \
+                const int nk_ = a.dim - (cs * 8 + 2 * c + (h_)) * 8;                     \
+                _Pragma("unroll") for (int i = 0; i < 8; i++) s_ = i < nk_ ? fmaf(x_[i], x_[i], s_) : s_; \
+            } else {                                                                     \
+                _Pragma("unroll") for (int i = 0; i < 8; i++) s_ = fmaf(x_[i], x_[i], s_); \
+            }                                                                            \
+            nrm += s_;                                                                   \
         }                                                                                \
-        if (!RN) nrm += s_;                                                              \
-        const int qnext_ = lane + (cs + 1 == KT ? 0 : cs + 1) * (NB * 64);               \
+        const int qnext_ = lane_e + ((h_) == 0 ? cs * (2 * NB * 64) + 16 : (cs + 1 == DT ? 0 : cs + 1) * (2 * NB * 64)); \
         _Pragma("unroll") for (int b = 0; b < NB; b++)                                   \
         {                                                                                \
             const v4i32b qc_ = qn[b];                                                    \
@@ -687,7 +701,20 @@ __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArg
             acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qc_),              \
                                                              __builtin_bit_cast(bf16x8, bop_), acc[b], 0, 0, 0); \
         }                                                                                \
-        if (++cs == KT) {                                                                \
+    }
+
+#define MQD_CONSUME(u)                                                                   \
+    {                                                                                    \
+        const u32x4 vx_ = ring[2 * (u)], vy_ = ring[2 * (u) + 1];                         \
+        u32x4 ve_, vo_;                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; i++)                                    \
+        {   /* row_ror:8 = 0x128; bank mask 0x3: lanes 0-7 of every 16 are written, 0xC: lanes 8-15 */ \
+            vo_[i] = (uint32_t)__builtin_amdgcn_update_dpp((int)vy_[i], (int)vx_[i], 0x128, 0xF, 0x3, false); \
+            ve_[i] = (uint32_t)__builtin_amdgcn_update_dpp((int)vx_[i], (int)vy_[i], 0x128, 0xF, 0xC, false); \
+        }                                                                                \
+        MQD_HALF(ve_, 0)                                                                 \
+        MQD_HALF(vo_, 1)                                                                 \
+        if (++cs == DT) {                                                                \
             finish_tile(ctile);                                                          \
             cs = 0;                                                                      \
             ctile += tile_stride;                                                        \
@@ -746,7 +773,7 @@ __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArg
         }
         __syncthreads();  // the query image is complete (the rows do not depend on it)
 #pragma unroll
-        for (int b = 0; b < NB; b++) qn[b] = qimg[lane + b * 64];
+        for (int b = 0; b < NB; b++) qn[b] = qimg[lane_e + b * 64];
         while (consumed + 2 * D <= NP) {
 #pragma unroll
             for (int u = 0; u < D; u++) {
@@ -772,6 +799,7 @@ __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArg
         }
     }
 #undef MQD_ISSUE
+#undef MQD_HALF
 #undef MQD_CONSUME
     if (COLLECT) hit_flush(a, hb, lane);
 }
