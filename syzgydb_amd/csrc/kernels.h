@@ -185,8 +185,9 @@ struct MqArgs {
     const uint64_t *live_bits;   // nullable
     const uint64_t *allow_bits;  // nullable, per query
     uint32_t allow_stride;
-    const float *row_norm;       // nullable: resident float32 sum n^2 per row (16-bit rows: the direct bfloat16 sweep
-                                 // then spends no vector instructions on the norm -- 8 of the 30 of its K-step)
+    const float *row_norm;       // resident row norms (launch_row_norms): 16-bit rows (nullable: the direct bfloat16
+                                 // sweep then sums its own) and 8-/4-bit rows (the shape kernels REQUIRE them; without,
+                                 // the any-shape kernel runs)
 };
 // thr[q] = key of the kp-th entry of query q's sorted list (3.0e38 if the list is shorter)
 hipError_t launch_mq_thr(const uint64_t *lists, int kp, int n_queries, float *thr, hipStream_t stream);
@@ -284,10 +285,11 @@ hipError_t launch_synth(int qbits, uint8_t *rows, RowLayout layout, uint64_t dst
                         uint64_t n_rows, uint64_t seed, uint64_t seed_first_row, const double *src,
                         hipStream_t stream);
 
-// Resident row norms of 16-bit rows (shared bfloat16 sweep): out[first_row + i] = sum over the row's real elements of
-// n^2, n = 2v - 65535, in float32, for rows [first_row, first_row + n_rows) of the (linear) mirror.
-hipError_t launch_row_norms16(const uint8_t *rows, uint32_t pitch, int dim, uint64_t first_row, uint64_t n_rows,
-                              float *out, hipStream_t stream);
+// Resident row norms (shared sweeps), out[first_row + i] for rows [first_row, first_row + n_rows) of the mirror:
+// 16-bit rows (linear): the float32 sum of n^2, n = 2v - 65535, over the row's real elements, as the direct bfloat16
+// sweep summed it; 8- and 4-bit rows (either layout): (float)(4 * sum (x'^2 + x')) + norm_bias, the int8 sweeps' norm.
+hipError_t launch_row_norms(int bits, const uint8_t *rows, const RowLayout &lay, int dim, float norm_bias, uint64_t first_row,
+                            uint64_t n_rows, float *out, hipStream_t stream);
 
 // device float64 primitive probe (tests)
 hipError_t launch_f64_probe(int op, const double *a, const double *b, double *out, uint64_t n,

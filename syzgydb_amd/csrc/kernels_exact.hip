@@ -726,12 +726,59 @@ __global__ __launch_bounds__(256) void row_norms16_kernel(const uint8_t *rows, u
 }
 }  // namespace
 
-hipError_t launch_row_norms16(const uint8_t *rows, uint32_t pitch, int dim, uint64_t first_row, uint64_t n_rows,
-                              float *out, hipStream_t stream)
+// 8- and 4-bit rows (either layout): the int8 sweeps' norm, formed exactly as they form it -- the integer
+// 4 * sum (x'^2 + x') over every code of the pitched row (x' = v - 128, resp. nibble - 8), converted once, plus the
+// handle's bias for the padding codes.  4 lanes per row (16 rows per wave: a tiled KiB is read in order).
+namespace {
+template <int RB>
+__global__ __launch_bounds__(256) void row_norms_i8_kernel(const uint8_t *rows, RowLayout lay, int r16, float norm_bias,
+                                                           uint64_t first_row, uint64_t n_rows, float *out)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int c = threadIdx.x & 3;
+    int SQ = 0, SV = 0;
+    if (r < n_rows) {
+        for (int j = c; j < r16; j += 4) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(rows + piece_offset(lay, first_row + r, (uint32_t)j));
+            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                if (RB == 8) {
+                    const int wn = (int)(ww[d] ^ 0x80808080u);
+                    SQ = __builtin_amdgcn_sdot4(wn, wn, SQ, false);
+                    SV = __builtin_amdgcn_sdot4(wn, 0x01010101, SV, false);
+                } else {
+                    const int wn = (int)(ww[d] ^ 0x88888888u);
+                    SQ = __builtin_amdgcn_sdot8(wn, wn, SQ, false);
+                    SV = __builtin_amdgcn_sdot8(wn, 0x11111111, SV, false);
+                }
+            }
+        }
+    }
+    int nrm = 4 * (SQ + SV);
+    nrm += __shfl_xor(nrm, 1);
+    nrm += __shfl_xor(nrm, 2);
+    if (r < n_rows && c == 0) out[first_row + r] = (float)nrm + norm_bias;
+}
+}  // namespace
+
+hipError_t launch_row_norms(int bits, const uint8_t *rows, const RowLayout &lay, int dim, float norm_bias, uint64_t first_row,
+                            uint64_t n_rows, float *out, hipStream_t stream)
 {
     if (n_rows == 0) return hipSuccess;
-    hipLaunchKernelGGL(row_norms16_kernel, dim3((unsigned)((n_rows + 15) / 16)), dim3(256), 0, stream, rows, pitch, dim,
-                       first_row, n_rows, out);
+    if (bits == 16 && !lay.tiled) {
+        hipLaunchKernelGGL(row_norms16_kernel, dim3((unsigned)((n_rows + 15) / 16)), dim3(256), 0, stream, rows, lay.pitch, dim,
+                           first_row, n_rows, out);
+    } else if (bits == 8 || bits == 4) {
+        const int r16 = (int)(lay.pitch / 16);
+        const dim3 grid((unsigned)((n_rows + 63) / 64));
+        if (bits == 8)
+            hipLaunchKernelGGL(row_norms_i8_kernel<8>, grid, dim3(256), 0, stream, rows, lay, r16, norm_bias, first_row, n_rows, out);
+        else
+            hipLaunchKernelGGL(row_norms_i8_kernel<4>, grid, dim3(256), 0, stream, rows, lay, r16, norm_bias, first_row, n_rows, out);
+    } else {
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

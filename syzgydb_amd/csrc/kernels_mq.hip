@@ -1151,6 +1151,9 @@ __device__ __forceinline__ void pretest_consts(float thr, float qs, float qn, fl
 #ifndef SZG_S6_RING
 #define SZG_S6_RING 3
 #endif
+#ifndef SZG_I8S_RN
+#define SZG_I8S_RN 1  // the shape kernels take the rows' norms from the resident array (MqArgs::row_norm) instead of summing them
+#endif
 template <int RB, int STEPS>
 constexpr int i8s_waves()
 {   // (4-bit rows of 12 steps -- 1 536 dims -- at 12 waves per CU spilled 2-4 of their 168 registers: 8 waves, 256)
@@ -1161,6 +1164,9 @@ constexpr int i8s_ring()
 {
     if (RB == 8 && STEPS == 12) return SZG_S12_RING;
     if (RB == 8 && STEPS == 6) return SZG_S6_RING;
+#ifdef SZG_S6R4_RING
+    if (RB == 4 && STEPS == 6) return SZG_S6R4_RING;
+#endif
     return STEPS % 4 == 0 ? 4 : (STEPS % 3 == 0 ? 3 : (STEPS % 2 == 0 ? 2 : 1));
 }
 template <int NB, int METRIC, int RB, int STEPS>
@@ -1172,6 +1178,7 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
     static_assert(NPL == 2, "the integer plane combine in the tile finish assumes two digit planes");
     constexpr int QSTEP = NPL * T * NB * 64;  // 16-byte words of the image per 64-byte step
     constexpr int N16 = STEPS * QSTEP;
+    constexpr bool RN = SZG_I8S_RN != 0;
     extern __shared__ __align__(16) uint8_t smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1262,6 +1269,10 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
         for (uint64_t it = 0; it < n_it; it++, tile += tile_stride) {
             // (past the wave's last tile: its own tile again -- D loads nobody consumes)
             const uint8_t *nxt = it + 1 < n_it ? row_ptr(tile + tile_stride) : cur;
+            // resident norms: the tile's 16 arrive while its steps run (the decode below then spends nothing on them:
+            // 12 of its 24 vector instructions per 64-byte step of 4-bit rows, 8 of 12 for 8-bit rows)
+            float norm_res = 0.f;
+            if constexpr (RN) norm_res = a.row_norm[min(tile * 16 + trow, (uint64_t)a.n_rows - 1)];
 #pragma unroll
             for (int st = 0; st < STEPS; st++) {
                 const u32x4 v_ = ring[st % D];
@@ -1279,15 +1290,18 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
                     read_phase((st * T + 1) % PHASES, qbuf[(st * T + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
                     // region 1: G MFMAs of phase st * T, with the rest of the decode in their shadows
+                    // (the tile's first matrix instructions start from a literal zero: no accumulator clearing per tile)
 #pragma unroll
                     for (int g = 0; g < G; g++)
-                        acc[g / NB][g % NB] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qbuf[(st * T) & 1][g], bop_[0],
-                                                                                  acc[g / NB][g % NB], 0, 0, 0);
+                        acc[g / NB][g % NB] = __builtin_amdgcn_mfma_i32_16x16x64_i8(
+                            qbuf[(st * T) & 1][g], bop_[0], st == 0 ? v4i32{0, 0, 0, 0} : acc[g / NB][g % NB], 0, 0, 0);
                     if constexpr (RB == 8) {
+                        if constexpr (!RN) {
 #pragma unroll
-                        for (int d = 0; d < 4; d++) {
-                            SQ = __builtin_amdgcn_sdot4(bop_[0][d], bop_[0][d], SQ, false);
-                            SV = __builtin_amdgcn_sdot4(bop_[0][d], 0x01010101, SV, false);
+                            for (int d = 0; d < 4; d++) {
+                                SQ = __builtin_amdgcn_sdot4(bop_[0][d], bop_[0][d], SQ, false);
+                                SV = __builtin_amdgcn_sdot4(bop_[0][d], 0x01010101, SV, false);
+                            }
                         }
                     } else {
 #pragma unroll
@@ -1300,11 +1314,13 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
                         for (int g = 0; g < G; g++)
                             acc[g / NB][g % NB] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qbuf[(st * T + 1) & 1][g], bop_[T - 1],
                                                                                       acc[g / NB][g % NB], 0, 0, 0);
+                        if constexpr (!RN) {
 #pragma unroll
-                        for (int d = 0; d < 4; d++) {
-                            const int wn_ = (int)(raw_[d] ^ 0x88888888u);
-                            SQ = __builtin_amdgcn_sdot8(wn_, wn_, SQ, false);
-                            SV = __builtin_amdgcn_sdot8(wn_, 0x11111111, SV, false);
+                            for (int d = 0; d < 4; d++) {
+                                const int wn_ = (int)(raw_[d] ^ 0x88888888u);
+                                SQ = __builtin_amdgcn_sdot8(wn_, wn_, SQ, false);
+                                SV = __builtin_amdgcn_sdot8(wn_, 0x11111111, SV, false);
+                            }
                         }
                     }
                 } else {
@@ -1313,14 +1329,18 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
                         if (RB == 8) {
                             const int wn_ = (int)(raw_[d] ^ 0x80808080u);
                             bop_[0][d] = wn_;
-                            SQ = __builtin_amdgcn_sdot4(wn_, wn_, SQ, false);
-                            SV = __builtin_amdgcn_sdot4(wn_, 0x01010101, SV, false);
+                            if constexpr (!RN) {
+                                SQ = __builtin_amdgcn_sdot4(wn_, wn_, SQ, false);
+                                SV = __builtin_amdgcn_sdot4(wn_, 0x01010101, SV, false);
+                            }
                         } else {
                             const int wn_ = (int)(raw_[d] ^ 0x88888888u);
                             bop_[0][d] = (int)((raw_[d] >> 4) & 0x0F0F0F0Fu);
                             bop_[T - 1][d] = (int)(raw_[d] & 0x0F0F0F0Fu);
-                            SQ = __builtin_amdgcn_sdot8(wn_, wn_, SQ, false);
-                            SV = __builtin_amdgcn_sdot8(wn_, 0x11111111, SV, false);
+                            if constexpr (!RN) {
+                                SQ = __builtin_amdgcn_sdot8(wn_, wn_, SQ, false);
+                                SV = __builtin_amdgcn_sdot8(wn_, 0x11111111, SV, false);
+                            }
                         }
                     }
 #pragma unroll
@@ -1330,7 +1350,8 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
 #pragma unroll
                             for (int b = 0; b < NB; b++) {
                                 const v4i32 qc_ = qimg[st * QSTEP + ((p * T + t) * NB + b) * 64];
-                                acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(qc_, bop_[t], acc[p][b], 0, 0, 0);
+                                acc[p][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(
+                                    qc_, bop_[t], st == 0 && t == 0 ? v4i32{0, 0, 0, 0} : acc[p][b], 0, 0, 0);
                             }
                 }
             }
@@ -1344,10 +1365,15 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
             // exactly the one-stage test's.  (1M rows with the default 1 024 expected hits per query: more than half
             // the tiles hold a hit and the two-stage form measures the same as the one-stage form; 12.5M rows: see
             // profiles/r03_i8_sweep_experiments.txt, section 11.)
-            int nrm = 4 * (SQ + SV);
-            nrm += __shfl_xor(nrm, 16);
-            nrm += __shfl_xor(nrm, 32);
-            const float norm = (float)nrm + a.norm_bias;
+            float norm;
+            if constexpr (RN) {
+                norm = norm_res;
+            } else {
+                int nrm = 4 * (SQ + SV);
+                nrm += __shfl_xor(nrm, 16);
+                nrm += __shfl_xor(nrm, 32);
+                norm = (float)nrm + a.norm_bias;
+            }
             const float inv = __frsqrt_rn(norm);
             const uint64_t row = tile * 16 + trow;
             const bool row_ok = row < a.n_rows;
@@ -1406,10 +1432,6 @@ __global__ __launch_bounds__((64 * i8s_waves<RB, STEPS>())) void mq_score_i8s_ke
                 }
                 offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row, qoff);
             }
-#pragma unroll
-            for (int p = 0; p < NPL; p++)
-#pragma unroll
-                for (int b = 0; b < NB; b++) acc[p][b] = v4i32{0, 0, 0, 0};
             SQ = 0;
             SV = 0;
             cur = nxt;
@@ -2119,7 +2141,7 @@ hipError_t launch_mq_score_i8_m(const MqArgs &a, int grid, size_t lds, hipStream
 {
     if (a.collect) {
         if constexpr (NB == 3) {  // full query groups: the row shapes with a kernel of their own
-            if (a.shape_kernels && a.tiled && a.r16 % 4 == 0 && a.n_rows > 0) {
+            if (a.shape_kernels && a.tiled && a.r16 % 4 == 0 && a.n_rows > 0 && (!SZG_I8S_RN || a.row_norm)) {
                 hipError_t e = hipSuccess;
                 if (a.metric == kCosine ? launch_mq_score_i8s<NB, kCosine>(a, grid, lds, stream, &e)
                                         : launch_mq_score_i8s<NB, kEuclidean>(a, grid, lds, stream, &e))

@@ -545,7 +545,7 @@ int szg_index_overwrite_f64(szg_index *ix, uint64_t row, const double *vector)
     if (e == hipSuccess)
         e = szg::launch_synth(ix->bits, sh->rows, ix->layout, local, ix->dim, 1, 0, 0, stage, nullptr);
     if (e == hipSuccess && sh->row_norm && local < sh->norm_valid)
-        e = szg::launch_row_norms16(sh->rows, ix->pitch, ix->dim, local, 1, sh->row_norm, nullptr);
+        e = szg::launch_row_norms(ix->bits, sh->rows, ix->layout, ix->dim, (float)ix->norm_bias, local, 1, sh->row_norm, nullptr);
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) return fail(SZG_E_DEVICE, "overwrite_f64", e);
     return SZG_OK;
@@ -564,7 +564,7 @@ int szg_index_overwrite(szg_index *ix, uint64_t row, const uint8_t *row_bytes)
     HIPCHK(hipDeviceSynchronize());
     const int rc = upload_rows(ix, sh, local, row_bytes, 1);
     if (rc == SZG_OK && sh->row_norm && local < sh->norm_valid) {
-        HIPCHK(szg::launch_row_norms16(sh->rows, ix->pitch, ix->dim, local, 1, sh->row_norm, nullptr));
+        HIPCHK(szg::launch_row_norms(ix->bits, sh->rows, ix->layout, ix->dim, (float)ix->norm_bias, local, 1, sh->row_norm, nullptr));
         HIPCHK(hipStreamSynchronize(nullptr));
     }
     return rc;

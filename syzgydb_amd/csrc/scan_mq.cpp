@@ -81,15 +81,21 @@ void build_image_i8(const szg_index *ix, Ctx *c, int nq, int nb, size_t group_st
     }
 }
 
-// Resident row norms (16-bit rows): the direct bfloat16 sweep is bound by its vector-instruction issue, and 8 of the
-// 30 vector instructions of its K-step summed the row's squares -- a number that only changes when the row does.  It
-// lives beside the rows (4 bytes per 2 x dim: 0.26 % more to read at 768 dims), computed on the device for the rows
-// added since the last shared sweep.
+// Resident row norms.  The 16-bit and the int8 shared sweeps are bound by their vector-instruction issue, and a good
+// part of it summed the row's squares -- 8 of the 30 vector instructions of a 16-bit K-step, 12 of the 24 that decode
+// a 64-byte step of 4-bit rows -- a number that only changes when the row does.  It lives beside the rows (4 bytes per
+// row: 0.26 % more to read for 16-bit rows of 768 dims, 1 % for 4-bit), computed on the device for the rows added since
+// the last shared sweep; an overwritten row's is refreshed at once (scan_handle.cpp).
+static bool row_norms_apply(const szg_index *ix)
+{
+    static const bool off = getenv("SZG_NO_ROW_NORMS") != nullptr;  // (A/B hook)
+    if (off) return false;
+    return (ix->bits == 16 && !ix->layout.tiled) || ix->bits == 8 || ix->bits == 4;
+}
+
 int ensure_row_norms(szg_index *ix, Shard *sh)
 {
-    if (ix->bits != 16 || ix->layout.tiled || sh->n_rows == 0) return SZG_OK;
-    static const bool off = getenv("SZG_NO_ROW_NORMS") != nullptr;  // (A/B hook)
-    if (off) return SZG_OK;
+    if (!row_norms_apply(ix) || sh->n_rows == 0) return SZG_OK;
     std::lock_guard<std::mutex> lk(sh->norm_mu);
     if (sh->norm_valid >= sh->n_rows && sh->row_norm) return SZG_OK;
     HIPCHK(hipSetDevice(sh->device));
@@ -105,8 +111,8 @@ int ensure_row_norms(szg_index *ix, Shard *sh)
         sh->row_norm = nn;
         sh->norm_cap = cap;
     }
-    HIPCHK(szg::launch_row_norms16(sh->rows, ix->pitch, ix->dim, sh->norm_valid, sh->n_rows - sh->norm_valid, sh->row_norm,
-                                   sh->scan_stream));
+    HIPCHK(szg::launch_row_norms(ix->bits, sh->rows, ix->layout, ix->dim, (float)ix->norm_bias, sh->norm_valid,
+                                 sh->n_rows - sh->norm_valid, sh->row_norm, sh->scan_stream));
     HIPCHK(hipStreamSynchronize(sh->scan_stream));  // (the batch's prefix pass may run on another stream)
     sh->norm_valid = sh->n_rows;
     return SZG_OK;
@@ -241,7 +247,7 @@ static szg::MqArgs mq_args_base(const szg_index *ix, const Shard *sh, const Ctx 
     for (int q = 0; q < nq && q < szg::kMqMaxQueries; q++) a.qnorm2[q] = (float)c->meta[q].qnorm2;
     a.zero16 = sh->zero16;
     a.norm_bias = (float)ix->norm_bias;
-    a.row_norm = ix->bits == 16 && sh->row_norm && sh->norm_valid >= sh->n_rows ? sh->row_norm : nullptr;
+    a.row_norm = row_norms_apply(ix) && sh->row_norm && sh->norm_valid >= sh->n_rows ? sh->row_norm : nullptr;
     return a;
 }
 

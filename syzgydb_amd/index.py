@@ -128,6 +128,13 @@ class ScanIndex:
             raise ValueError("overwrite takes exactly one row")
         check(self._L.szg_index_overwrite(self._h, int(row), _u8(a)), "szg_index_overwrite")
 
+    def overwrite_vector(self, row, vector):
+        """UpdateDocument from a float64 vector: quantized and packed on the device."""
+        v = np.ascontiguousarray(vector, dtype=np.float64).reshape(-1)
+        if v.size != self.dim:
+            raise ValueError("vector length %d != dimension %d" % (v.size, self.dim))
+        check(self._L.szg_index_overwrite_f64(self._h, int(row), _f64(v)), "szg_index_overwrite_f64")
+
     def tombstone(self, row):
         check(self._L.szg_index_tombstone(self._h, int(row)), "szg_index_tombstone")
 

@@ -438,3 +438,44 @@ def test_bf16_sweep_64bit_rows_beyond_float32(metric):
         check(ix, rows, dim, Q, 12, bits=64, metric=metric)
         if DEFAULT_TUNABLES:
             assert ix.stats()["mq_queries"] == len(Q)
+
+
+@pytest.mark.parametrize("bits", [4, 8, 16])
+@pytest.mark.parametrize("dim", [768, 384, 100])
+def test_resident_row_norms_follow_mutations(bits, dim):
+    """The shared sweeps of 4-, 8- and 16-bit rows take the rows' norms from a resident array (built on the device
+    before the first batch, caught up after appends, refreshed at once when a row is overwritten -- through either
+    entry point): batches after every kind of mutation answer as the reference's loop over the mutated corpus."""
+    n = 2500
+    rows = orc.synth_rows(7100 + dim + bits, 0, n, dim, bits).reshape(n, -1).copy()
+    Q = orc.synth_vectors(7101 + dim, 0, 48, dim)
+    with ScanIndex(dim, bits, SZG_COSINE) as ix:
+        ix.load(rows[:2000])
+        check(ix, rows[:2000].reshape(-1), dim, Q, 10, bits=bits)           # norms built for 2 000 rows
+        ix.append(rows[2000:2300])                                           # appended rows: caught up
+        check(ix, rows[:2300].reshape(-1), dim, Q, 10, bits=bits)
+        # overwrite stored bytes: the rows the queries like best get the bytes of other rows
+        r, _, _ = ix.search_topk(Q[:1], 3)
+        for j, victim in enumerate(int(x) for x in r[0, :3]):
+            rows[victim] = rows[2400 + j]
+            ix.overwrite(victim, rows[victim])
+        check(ix, rows[:2300].reshape(-1), dim, Q, 10, bits=bits)
+        # overwrite from a float64 vector (quantized on the device): the mirror's bytes are the oracle's quantization
+        v = orc.synth_vectors(7102 + dim, 0, 1, dim)[0] * 0.25
+        victim = int(ix.search_topk(Q[1:2], 1)[0][0, 0])
+        ix.overwrite_vector(victim, v)
+        rows[victim] = ix.read_rows(victim, 1)[0]
+        check(ix, rows[:2300].reshape(-1), dim, Q, 10, bits=bits)
+        ix.tombstone(int(r[0, 0]))
+        ix.append(rows[2300:2500])
+        allow = np.ones(2500, dtype=bool)
+        allow[int(r[0, 0])] = False
+        got_r, got_d, got_c = ix.search_topk(Q, 10)
+        for qi in range(Q.shape[0]):
+            o_rows, o_dist, _ = orc.search_exact(rows.reshape(-1), dim, bits, SZG_COSINE, Q[qi], k=10, allow=allow.astype(np.uint8))
+            assert [int(x) for x in got_r[qi, : got_c[qi]]] == [int(x) for x in o_rows], qi
+            assert (got_d[qi, : got_c[qi]] == o_dist).all(), qi
+        if DEFAULT_TUNABLES:
+            assert ix.stats()["mq_queries"] > 0
+        ix.load(rows[:1000])                                                 # a reload starts the norms over
+        check(ix, rows[:1000].reshape(-1), dim, Q, 10, bits=bits)
