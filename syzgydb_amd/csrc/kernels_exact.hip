@@ -270,6 +270,103 @@ __global__ __launch_bounds__(64) void rerank_kernel(const uint8_t *rows, RowLayo
     }
 }
 
+// One LANE per candidate: the form for many candidates per query (a radius batch's hits, a full exact replay).  The
+// kernel above gives a candidate a whole wave and spends most of it on three lanes walking the ordered sums -- right
+// for the handful of candidates of a top-k query, 118 us for the 46 000 hits of a cfg5-shard radius batch.  Here every
+// lane walks its own row piece by piece and keeps the three sums in registers, the same operations in the same order
+// (each product rounded once, added in index order), so 64 candidates share a wave's issue slots and a batch's hits
+// finish within about one chain's latency.  The query sits in LDS (all lanes read the same element: a broadcast);
+// 4- and 8-bit codes decode through a table of the 16 / 256 values the formula of quantization.go:35 gives.
+template <int QBITS, int METRIC>
+__global__ __launch_bounds__(64) void rerank_lanes_kernel(const uint8_t *rows, RowLayout lay, int dim, const double *query,
+                                                          const uint64_t *cands, const uint32_t *n_dev, uint32_t n_dev_stride,
+                                                          uint32_t n_max, RerankOut *out)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    double *qs = reinterpret_cast<double *>(smem);  // the query
+    double *tab = qs + ((dim + 1) & ~1);            // decode table (4- and 8-bit rows)
+    constexpr int E = 128 / QBITS;                  // elements per 16-byte piece
+    const int lane = threadIdx.x;
+    uint32_t n = n_max;
+    if (n_dev) n = min(n_dev[(size_t)blockIdx.y * n_dev_stride], n_max);
+    if (blockIdx.x * 64u >= n) return;
+    query += (size_t)blockIdx.y * dim;
+    if (cands) cands += (size_t)blockIdx.y * n_max;
+    out += (size_t)blockIdx.y * n_max;
+    for (int i = lane; i < dim; i += 64) qs[i] = query[i];
+    if (QBITS <= 8) {
+        const double maxInt = (double)((1u << QBITS) - 1u);
+        for (int v = lane; v < (1 << QBITS); v += 64) tab[v] = __dsub_rn(__dmul_rn(__ddiv_rn((double)v, maxInt), 2.0), 1.0);
+    }
+    __syncthreads();
+    const int pieces = (dim + E - 1) / E;
+    for (uint32_t c0 = blockIdx.x * 64u; c0 < n; c0 += gridDim.x * 64u) {
+        const uint32_t ci = c0 + lane;
+        if (ci >= n) continue;
+        const uint64_t c = cands ? cands[ci] : (uint64_t)ci;
+        RerankOut r;
+        if (c == kInvalidCand) {
+            r.dist = 0.0;
+            r.row = 0xFFFFFFFFu;
+            r.ukey = 0xFFFFFFFFu;
+            out[ci] = r;
+            continue;
+        }
+        const uint32_t row = (uint32_t)c;
+        double s = 0.0, m1 = 0.0, m2 = 0.0;
+        uint4 w = *reinterpret_cast<const uint4 *>(rows + piece_offset(lay, row, 0));
+        for (int j = 0; j < pieces; j++) {
+            const uint4 cur = w;
+            if (j + 1 < pieces) w = *reinterpret_cast<const uint4 *>(rows + piece_offset(lay, row, (uint32_t)(j + 1)));
+            const uint32_t ww[4] = {cur.x, cur.y, cur.z, cur.w};
+            const int nk = min(E, dim - j * E);
+#pragma unroll
+            for (int i = 0; i < E; i++) {
+                if (i >= nk) break;
+                double y;
+                if (QBITS == 64) {
+                    y = __hiloint2double((int)ww[2 * (i & 1) + 1], (int)ww[2 * (i & 1)]);
+                } else if (QBITS == 32) {
+                    y = (double)__uint_as_float(ww[i & 3]);
+                } else if (QBITS == 16) {
+                    const uint32_t v = (ww[(i >> 1) & 3] >> (16 * (i & 1))) & 0xFFFFu;
+                    y = __dsub_rn(__dmul_rn(__ddiv_rn((double)v, 65535.0), 2.0), 1.0);
+                } else if (QBITS == 8) {
+                    y = tab[(ww[(i >> 2) & 3] >> (8 * (i & 3))) & 0xFFu];
+                } else {  // byte b holds element 2b in its high nibble, 2b + 1 in the low one (collection.go:774-779)
+                    const uint32_t b = (ww[(i >> 3) & 3] >> (8 * ((i >> 1) & 3))) & 0xFFu;
+                    y = tab[(i & 1) ? (b & 0x0Fu) : (b >> 4)];
+                }
+                const double x = qs[j * E + i];
+                if (METRIC == kEuclidean) {
+                    const double diff = __dsub_rn(x, y);
+                    s = __dadd_rn(s, __dmul_rn(diff, diff));
+                } else {
+                    s = __dadd_rn(s, __dmul_rn(x, y));
+                    m1 = __dadd_rn(m1, __dmul_rn(x, x));
+                    m2 = __dadd_rn(m2, __dmul_rn(y, y));
+                }
+            }
+        }
+        double dist;
+        if (METRIC == kEuclidean) {  // collection.go:812-819
+            dist = __dsqrt_rn(s);
+        } else {  // collection.go:821-832
+            if (m1 == 0 || m2 == 0) {
+                dist = 1.0;
+            } else {
+                const double Pi = 3.14159265358979323846264338327950288;
+                const double cosv = __ddiv_rn(s, __dmul_rn(__dsqrt_rn(m1), __dsqrt_rn(m2)));
+                dist = __ddiv_rn(go_acos(cosv), Pi);
+            }
+        }
+        r.dist = dist;
+        r.row = row;
+        r.ukey = cands ? (uint32_t)(c >> 32) : 0u;
+        out[ci] = r;
+    }
+}
+
 // ---- synthetic corpus ---------------------------------------------------------
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
@@ -525,6 +622,17 @@ hipError_t launch_rerank_q(int metric, const uint8_t *rows, RowLayout lay, int d
                            const uint32_t *left_rows = nullptr, uint32_t n_dev_stride = 0)
 {
     if (n_max == 0 || n_queries == 0) return hipSuccess;
+    if (!left_rows && n_max >= 512u) {  // many candidates per query: one lane each
+        const dim3 grid(std::min((n_max + 63u) / 64u, 4096u), n_queries);
+        const size_t lds = ((size_t)((dim + 1) & ~1) + (QBITS <= 8 ? (size_t)1 << QBITS : 0)) * sizeof(double);
+        if (metric == kCosine)
+            hipLaunchKernelGGL((rerank_lanes_kernel<QBITS, kCosine>), grid, dim3(64), lds, stream, rows, lay, dim, q, cands, n_dev,
+                               n_dev_stride, n_max, out);
+        else
+            hipLaunchKernelGGL((rerank_lanes_kernel<QBITS, kEuclidean>), grid, dim3(64), lds, stream, rows, lay, dim, q, cands,
+                               n_dev, n_dev_stride, n_max, out);
+        return hipGetLastError();
+    }
     const dim3 grid(n_max < 4096u ? n_max : 4096u, n_queries);
     const size_t lds = (size_t)rerank_chunk(dim) * (metric == kCosine ? 3 : 1) * sizeof(double);
     if (metric == kCosine)

@@ -213,10 +213,16 @@ int RadiusCall::stage(RadiusTicket &t)
         if (!c0) {
             c0 = c;
             for (int j = 0; j < t.nq; j++) {
-                // (the single-query form is built too: a query whose hits overflow the batch's buffers is swept again
-                // on its own)
-                prep_query(ix, q + (size_t)j * ix->dim, c->h_qsw + (size_t)j * ix->qsw_bytes, &c->meta[j]);
-                t.thr_single[j] = t.thr[j] = radius_key_threshold(ix, radii[t.first + j], c->meta[j]);
+                // (a shared sweep stages its own image: the single-query form -- digit planes / swizzled floats, its
+                // quantization step and the threshold that goes with it -- is built in finish() for a query whose
+                // hits overflow the batch's buffers and which is then swept again on its own.  Building it here for
+                // every query was 1.4 us of the 2.5 us of host preparation per query of a cfg5 batch.)
+                if (t.nb > 0) {
+                    prep_query_meta(ix, q + (size_t)j * ix->dim, &c->meta[j]);
+                } else {
+                    prep_query(ix, q + (size_t)j * ix->dim, c->h_qsw + (size_t)j * ix->qsw_bytes, &c->meta[j]);
+                    t.thr_single[j] = t.thr[j] = radius_key_threshold(ix, radii[t.first + j], c->meta[j]);
+                }
                 if (t.nb > 0) {  // the shared sweep's arithmetic has its own error bound
                     if (int_planes) prep_mq_int(ix, q + (size_t)j * ix->dim, &c->meta[j], c->h_mqQ + (size_t)j * ix->dim);
                     QMeta m2 = c->meta[j];
@@ -226,7 +232,7 @@ int RadiusCall::stage(RadiusTicket &t)
                 }
             }
         } else {
-            memcpy(c->h_qsw, c0->h_qsw, ix->qsw_bytes * (size_t)t.nq);
+            if (t.nb == 0) memcpy(c->h_qsw, c0->h_qsw, ix->qsw_bytes * (size_t)t.nq);
             if (int_planes) memcpy(c->h_mqQ, c0->h_mqQ, sizeof(int32_t) * (size_t)t.nq * ix->dim);
             for (int j = 0; j < t.nq; j++) c->meta[j] = c0->meta[j];
         }
@@ -234,7 +240,7 @@ int RadiusCall::stage(RadiusTicket &t)
     const double t1 = now_us();
     for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
         if (!t.ctx[s]) continue;
-        rc = enqueue_queries(ix, ix->shards[s], t.ctx[s], q, t.nq, t.any_mask ? m.data() : nullptr);
+        rc = enqueue_queries(ix, ix->shards[s], t.ctx[s], q, t.nq, t.any_mask ? m.data() : nullptr, t.nb == 0);
         if (rc == SZG_OK) rc = enqueue_shard(t, s);
     }
     std::lock_guard<std::mutex> lk(ix->stats_mu);
@@ -314,6 +320,22 @@ int RadiusCall::finish(RadiusTicket &t)
             cands[j].clear();
             std::vector<Cand> all;
             const double tw = now_us();
+            if (t.nb > 0) {  // the single-query form of this query, now that it is needed (see stage())
+                const double *qj = queries + (size_t)(t.first + j) * ix->dim;
+                for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
+                    Ctx *c = t.ctx[s];
+                    if (!c) continue;
+                    QMeta m;
+                    prep_query(ix, qj, c->h_qsw + (size_t)j * ix->qsw_bytes, &m);
+                    c->meta[j] = m;
+                    t.thr_single[j] = radius_key_threshold(ix, radii[t.first + j], m);
+                    hipError_t e = hipSetDevice(ix->shards[s]->device);
+                    if (e == hipSuccess)
+                        e = hipMemcpyAsync(c->d_qsw + (size_t)j * ix->qsw_bytes, c->h_qsw + (size_t)j * ix->qsw_bytes,
+                                           ix->qsw_bytes, hipMemcpyHostToDevice, c->work);
+                    if (e != hipSuccess) rc = fail(SZG_E_DEVICE, "hipMemcpyAsync(single-query form)", e);
+                }
+            }
             for (size_t s = 0; s < n_sh && rc == SZG_OK; s++)
                 if (t.ctx[s]) rc = run_collect(ix, ix->shards[s], t.ctx[s], j, t.thr_single[j], t.any_mask, &all);
             t_wait += now_us() - tw;
