@@ -338,7 +338,7 @@ int szg_reset_stats(szg_index *ix);
  *                             apply the masks at the row finish; selective masks (and 0) compact the row steps that
  *                             hold a passing row first
  *     serialize_scans     1   sweeps of one shard never overlap each other (every sweep has the whole HBM bandwidth)
- *     contexts            3   batches in flight per shard
+ *     contexts            4   batches in flight per shard
  *   sketch pre-pass (float32 rows)
  *     sketch              0   1 = keep an 8-bit sketch of every row (+25 % memory, built on the device at the first
  *                             search after a load, kept up to date across appends / overwrites / tombstones) and

@@ -322,8 +322,8 @@ struct szg_index {
     std::vector<std::pair<std::string, int64_t>> opt_log;  // tunables set so far (replayed on the sketch index)
     // tunables (szg_set_option; include/syzgy_scan.h lists them)
     int slack_min = 16;
-    int n_ctx = 3;            // contexts (and streams) per shard
-    int n_ctx_active = 3;
+    int n_ctx = 4;            // contexts (and streams) per shard (bfloat16 batches of 1M x 768: 3 -> 4 = 155 -> 162 k queries/s; 6: no more)
+    int n_ctx_active = 4;
     int query_batch = 16;     // queries per scan launch
     int radius_mq = 1;        // radius batches of 2+ queries share one sweep of the corpus (the shared sweeps' collect form)
     int finish_thread = 1;    // shared-sweep calls of 3+ batches: a second host thread assembles the finished batches

@@ -562,7 +562,7 @@ def test_search_batch_equals_search_by_search():
 @pytest.mark.parametrize("bits,devices", [(8, [0]), (32, [0, 0])])
 def test_concurrent_long_calls_with_finisher_threads(bits, devices):
     """Four threads on one handle, each issuing calls of 200-400 queries (3+ shared-sweep batches: producer + finisher
-    thread per call, all of them competing for the shards' three contexts) mixed with radius batches: no deadlock,
+    thread per call, all of them competing for the shards' four contexts) mixed with radius batches: no deadlock,
     every answer the oracle's."""
     import threading
     dim, n, metric = 48, 6000, 1
