@@ -593,7 +593,7 @@ __global__ __launch_bounds__(kMqbThreads) void mq_score_bf16s_kernel(const MqArg
 #define SZG_MQD_WAVES 12  // waves per block (one block per CU): no staging KiB per wave, <= 168 registers: three per SIMD
 #endif
 constexpr int kMqdThreads = 64 * SZG_MQD_WAVES;
-template <int NB, int METRIC, bool COLLECT, bool RN>
+template <int NB, int METRIC, bool COLLECT>
 __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArgs a)
 {
     constexpr int D = COLLECT ? SZG_MQD_RING : 4;  // (the threshold pass: a few tiles per wave, latency-bound)
@@ -679,20 +679,10 @@ __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArg
             x_[2 * i + 1] = fmaf((float)(w_[i] >> 16), 2.0f, -65535.0f);                 \
             bop_[i] = (int)__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x_[2 * i], x_[2 * i + 1]}, bf16x2)); \
         }                                                                                \
-        if (RN) { /* resident norms: this tile's 16 arrive while its steps run */         \
-            if ((h_) == 0 && cs == 0) nrm = a.row_norm[min(ctile * 16 + trow, (uint64_t)a.n_rows - 1)]; \
-        } else {                                                                         \
-            float s_ = 0.f;                                                              \
-            if (cs == DT - 1) { /* (wave-uniform) the row's last double step: zero-block lanes and the padding codes */ \
-                /* of the last chunk decode to -65535 -- zeros stand against them in the image, and they stay out of */ \
-                /* the norm */                                                           \
-                const int nk_ = a.dim - (cs * 8 + 2 * c + (h_)) * 8;                     \
-                _Pragma("unroll") for (int i = 0; i < 8; i++) s_ = i < nk_ ? fmaf(x_[i], x_[i], s_) : s_; \
-            } else {                                                                     \
-                _Pragma("unroll") for (int i = 0; i < 8; i++) s_ = fmaf(x_[i], x_[i], s_); \
-            }                                                                            \
-            nrm += s_;                                                                   \
-        }                                                                                \
+        /* resident norms (MqArgs::row_norm): this tile's 16 arrive while its steps run.  (Summing them here -- eight */ \
+        /* more vector instructions per operand -- measured 3.5 % slower, and the threshold pass then spilled: */        \
+        /* without the array the staged kernel runs, which sums its own.) */                                              \
+        if ((h_) == 0 && cs == 0) nrm = a.row_norm[min(ctile * 16 + trow, (uint64_t)a.n_rows - 1)]; \
         const int qnext_ = lane_e + ((h_) == 0 ? cs * (2 * NB * 64) + 16 : (cs + 1 == DT ? 0 : cs + 1) * (2 * NB * 64)); \
         _Pragma("unroll") for (int b = 0; b < NB; b++)                                   \
         {                                                                                \
@@ -722,12 +712,7 @@ __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArg
     }
 
     auto finish_tile = [&](uint64_t tile) {
-        // row norms: over the row's 4 k-group lanes (the MFMA result's column = the row, as the operand's)
-        if (!RN) {
-            nrm += __shfl_xor(nrm, 16);
-            nrm += __shfl_xor(nrm, 32);
-        }
-        const uint64_t row = tile * 16 + trow;
+        const uint64_t row = tile * 16 + trow;  // (the MFMA result's column = the row, as the operand's)
         const float inv = __frsqrt_rn(nrm);
         // (a decoded code is odd: the norm of a 16-bit row is neither 0 nor beyond float32 -- no fixed keys here; the
         // clamps are one v_min_f32 and the hit bits have no short-circuits: see mq_score_bf16s_kernel's finish)
@@ -2051,7 +2036,7 @@ hipError_t launch_mq_score_bf16_t(const MqArgs &a, int grid, size_t lds, hipStre
 template <int NB, int METRIC, bool COLLECT>
 hipError_t launch_mq_score_bf16d_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
 {
-    auto *kern = a.row_norm ? &mq_score_bf16d_kernel<NB, METRIC, COLLECT, true> : &mq_score_bf16d_kernel<NB, METRIC, COLLECT, false>;
+    auto *kern = &mq_score_bf16d_kernel<NB, METRIC, COLLECT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -2064,7 +2049,7 @@ hipError_t launch_mq_score_bf16_m(const MqArgs &a, int grid, size_t lds, hipStre
 {
 #if SZG_MQ_PART == 116
     static const bool staged16 = getenv("SZG_BF16_STAGED16") != nullptr;  // (A/B: the LDS-staged form for 16-bit rows)
-    if (!staged16) {
+    if (!staged16 && a.row_norm) {  // (no resident norms -- an allocation failed, SZG_NO_ROW_NORMS: the staged form sums its own)
         if (a.collect) {
             if (a.metric == kCosine) return launch_mq_score_bf16d_t<NB, kCosine, true>(a, grid, lds, stream);
             return launch_mq_score_bf16d_t<NB, kEuclidean, true>(a, grid, lds, stream);
