@@ -39,6 +39,11 @@ for opts in ${SWEEP_MQ_SETS-force_matrix=1,serialize_scans=0 force_no_refine=1 f
   run "multiquery tests, $opts" tests/test_gpu_multiquery.py -q -x \
       --deselect tests/test_gpu_multiquery.py::test_fused_selection_overflow_falls_back
 done
+# the shared sweeps without the resident row norms (a test hook of its own: an environment variable read once per process)
+opts=""
+export SZG_NO_ROW_NORMS=1
+run "SZG_NO_ROW_NORMS=1 (int8 any-shape kernels, staged 16-bit sweep)" tests/test_gpu_multiquery.py tests/test_gpu_radius_batch.py -m gpu -q -x
+unset SZG_NO_ROW_NORMS
 cat $out
 echo "option sets failed: $failed"
 exit $failed
