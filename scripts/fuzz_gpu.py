@@ -166,6 +166,46 @@ while time.time() < t_end:
                 if total != len(w_rows) or not same(tr, td, w_rows[:cap], w_dist[:cap]):
                     fails += 1
                     print("MISMATCH truncated radius", desc, cap, total, len(w_rows), flush=True)
+            # a second act: mutations AFTER searches (whatever the handle keeps beside the rows -- resident row norms,
+            # sketches, liveness words -- has to follow them), then the same questions again
+            if n > 3 and allow is None and rng.random() < 0.4:
+                for r0 in rng.choice(n, size=min(4, n), replace=False):
+                    if r0 in dead:
+                        continue
+                    nv = rng.uniform(-1, 1, dim) * float(rng.choice([1.0, 0.3, 0.0]))
+                    if rng.random() < 0.5:
+                        rows[r0] = orc.encode_rows(nv.reshape(1, -1), bits)[0]
+                        ix.overwrite(int(r0), rows[r0])
+                    else:
+                        ix.overwrite_vector(int(r0), nv)
+                        rows[r0] = ix.read_rows(int(r0), 1)[0]
+                        assert (rows[r0] == orc.encode_rows(nv.reshape(1, -1), bits)[0]).all(), "device quantization differs"
+                extra = int(rng.integers(1, 40))
+                ev = rng.uniform(-1, 1, (extra, dim))
+                erows = orc.encode_rows(ev, bits)
+                ix.append(erows)
+                rows2 = np.concatenate([rows, erows])
+                live2 = np.concatenate([live, np.ones(extra, dtype=bool)])
+                r, d, c = ix.search_topk(Q, k)
+                for qi in range(nq):
+                    o_rows, o_dist, _ = orc.search_exact(rows2, dim, bits, metric, Q[qi], k=k, allow=live2.astype(np.uint8))
+                    if not same(r[qi, : c[qi]], d[qi, : c[qi]], o_rows, o_dist):
+                        fails += 1
+                        print("MISMATCH topk after mutation", desc, "query", qi, flush=True)
+                        break
+                nb_ = min(nq, 9)
+                radii = []
+                for qj in range(nb_):
+                    od = orc.search_exact(rows2, dim, bits, metric, Q[qj], k=5, allow=live2.astype(np.uint8))[1]
+                    fin = [x for x in od if x == x and x > 0]
+                    radii.append(float(fin[-1]) if fin else 0.5)
+                hits = ix.search_radius_batch(Q[:nb_], radii)
+                for qj in range(nb_):
+                    w_r, w_d, _ = orc.search_exact(rows2, dim, bits, metric, Q[qj], radius=radii[qj], allow=live2.astype(np.uint8))
+                    if not same(hits[qj][0], hits[qj][1], w_r, w_d):
+                        fails += 1
+                        print("MISMATCH radius batch after mutation", desc, "query", qj, flush=True)
+                        break
     except Exception as e:  # noqa: BLE001
         fails += 1
         print("EXCEPTION", desc, repr(e), flush=True)
