@@ -16,7 +16,8 @@ run() {  # $1 = label, rest = pytest arguments
 # (tie_mode=1 changes the contract -- any valid top-k among equal distances -- and has its own test,
 # tests/test_gpu_parity.py::test_tie_mode_1_returns_a_valid_topk.)
 # SWEEP_SETS="a=1 b=2,c=3" restricts the first loop to those sets (re-checking a fix)
-# SWEEP_SKIP_MAIN=1 skips this loop (a box allows 20 minutes per call: the two loops can go in two calls)
+# SWEEP_SKIP_MAIN=1 skips this loop (a box allows 20 minutes per call and this loop takes 19 of them: first call
+# `SWEEP_MQ_SETS="" SWEEP_SKIP_NORMS=1`, second call `SWEEP_SKIP_MAIN=1`)
 [ -n "$SWEEP_SKIP_MAIN" ] || for opts in ${SWEEP_SETS:-serialize_scans=0 queries_per_launch=1 queries_per_launch=3,query_batch=5 \
             force_matrix=1 multi_query=0 contexts=1,mask_dense=0,coalesce=0 mq_min=8,mq_hits=256 \
             sketch=1,sketch_min_rows=1 sketch=1,multi_query=0,sketch_extra=0,sketch_min_rows=1 force_no_refine=1 \
@@ -40,10 +41,12 @@ for opts in ${SWEEP_MQ_SETS-force_matrix=1,serialize_scans=0 force_no_refine=1 f
       --deselect tests/test_gpu_multiquery.py::test_fused_selection_overflow_falls_back
 done
 # the shared sweeps without the resident row norms (a test hook of its own: an environment variable read once per process)
-opts=""
-export SZG_NO_ROW_NORMS=1
-run "SZG_NO_ROW_NORMS=1 (int8 any-shape kernels, staged 16-bit sweep)" tests/test_gpu_multiquery.py tests/test_gpu_radius_batch.py -m gpu -q -x
-unset SZG_NO_ROW_NORMS
+if [ -z "$SWEEP_SKIP_NORMS" ]; then
+  opts=""
+  export SZG_NO_ROW_NORMS=1
+  run "SZG_NO_ROW_NORMS=1 (int8 any-shape kernels, staged 16-bit sweep)" tests/test_gpu_multiquery.py tests/test_gpu_radius_batch.py -m gpu -q -x
+  unset SZG_NO_ROW_NORMS
+fi
 cat $out
 echo "option sets failed: $failed"
 exit $failed
