@@ -356,8 +356,8 @@ def side_workload(name, n_queries, devices):
 
 
 def batched_leg(bits, n_rows, dim, metric, k, devices, seed):
-    """The shared sweep on a quantized copy of the headline shape: 960 queries in one call (the int8 sweeps for 8- and
-    4-bit rows, the bfloat16 sweep for 16-bit rows)."""
+    """The shared sweep on a quantized copy of the headline shape: 960 queries in one call (the exact int8 sweep for
+    4-bit rows; the bfloat16 sweep for 64-, 16- and -- their codes being exact in bfloat16 -- tiled 8-bit rows)."""
     from syzgydb_amd import ScanIndex
     from syzgydb_amd.synth import synth_vectors
     with ScanIndex(dim, bits, metric, devices=devices) as ix:
@@ -377,9 +377,11 @@ def batched_leg(bits, n_rows, dim, metric, k, devices, seed):
         s_rows, s_dist, _ = ix.search_topk(qb[:32], k)
         pass_ms = st["scan_ms"] / max(st["timed_launches"], 1)
         gbps = n_rows * ix.row_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms else 0.0
-        kern = {16: "szg::mq_score_bf16s_kernel<6,cosine,collect,16> (v_mfma_f32_16x16x32_bf16, 16-bit codes decoded on the fly)",
+        kern = {16: "szg::mq_score_bf16d_kernel<6,cosine,collect> (v_mfma_f32_16x16x32_bf16, 16-bit codes decoded on the fly)",
                 64: "szg::mq_score_bf16s_kernel<6,cosine,collect,64> (v_mfma_f32_16x16x32_bf16, float64 narrowed on the fly)"}.get(
                     bits, "szg::mq_score_i8s_kernel (v_mfma_i32_16x16x64_i8, exact integer)")
+        if bits == 8 and st["mq_bf16_sweeps"]:
+            kern = "szg::mq_score_bf16d8_kernel<6,cosine,collect> (v_mfma_f32_16x16x32_bf16, 8-bit codes exact in bfloat16: 96 queries per pass)"
         return {"workload": "%d x %d, %d-bit, cosine, k=%d, 960 queries in one call" % (n_rows, dim, bits, k),
                 "value": round(960 / elapsed, 1), "unit": "queries/s",
                 "queries_per_pass": round(st["mq_queries"] / max(st["mq_launches"], 1), 2),

@@ -55,11 +55,16 @@ for b in 64 32 16 8 4; do
   SZG_BITS=$b rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mq$b -- python3 $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /tmp/mq.log 2>&1
   one /tmp/prof_mq$b "*kernel_stats.csv" $out/${tag}_mq_${b}bit_kernel_stats.csv
 done
+# 8-bit rows on the exact int8 sweep (what radius batches take; SZG_BF16_8BIT=0)
+rm -rf /tmp/prof_mq8i
+SZG_BF16_8BIT=0 SZG_BITS=8 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mq8i -- python3 $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /tmp/mq.log 2>&1
+one /tmp/prof_mq8i "*kernel_stats.csv" $out/${tag}_mq_8bit_int8_kernel_stats.csv
 # one dimension WITHOUT a shape kernel of its own (4-bit rows of 1 024 dims: the any-shape int8 sweep)
 rm -rf /tmp/prof_mq4g
 SZG_BITS=4 SZG_DIM=1024 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_mq4g -- python3 $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /tmp/mq.log 2>&1
 one /tmp/prof_mq4g "*kernel_stats.csv" $out/${tag}_mq_4bit_dim1024_kernel_stats.csv
-SZG_BITS=8 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_i8s_kernel<3, 1" $out/${tag}_pmc_mq_i8_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
+SZG_BITS=8 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_bf16d8_kernel<6, 1, true" $out/${tag}_pmc_mq_bf16_8bit_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
+SZG_BF16_8BIT=0 SZG_BITS=8 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_i8s_kernel<3, 1" $out/${tag}_pmc_mq_i8_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
 SZG_BITS=4 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_i8s_kernel<3, 1" $out/${tag}_pmc_mq_i8_4bit_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
 SZG_BITS=32 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_bf16s_kernel<6, 1, true" $out/${tag}_pmc_mq_bf16_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true
 SZG_BITS=64 bash $GRAFT_REPO_ROOT/scripts/pmc.sh "mq_score_bf16s_kernel<6, 1, true" $out/${tag}_pmc_mq_bf16_64bit_sweep_summary.txt $GRAFT_REPO_ROOT/scripts/dev_mq_one.py > /dev/null 2>&1 || true

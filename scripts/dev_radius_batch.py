@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from syzgydb_amd import ScanIndex
 from syzgydb_amd.synth import synth_vectors
-dim, bits, metric = 384, 4, 1
+dim, bits, metric = int(os.environ.get("SZG_DIM", "384")), int(os.environ.get("SZG_BITS", "4")), 1
 n = int(os.environ.get("SZG_ROWS", "12500000"))
 nq = int(os.environ.get("SZG_NQ", "24"))
 q = synth_vectors(7, 0, max(nq, 16), dim)

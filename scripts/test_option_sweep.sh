@@ -46,6 +46,9 @@ if [ -z "$SWEEP_SKIP_NORMS" ]; then
   export SZG_NO_ROW_NORMS=1
   run "SZG_NO_ROW_NORMS=1 (int8 any-shape kernels, staged 16-bit sweep)" tests/test_gpu_multiquery.py tests/test_gpu_radius_batch.py -m gpu -q -x
   unset SZG_NO_ROW_NORMS
+  export SZG_BF16_8BIT=0
+  run "SZG_BF16_8BIT=0 (top-k batches on tiled 8-bit rows through the exact int8 sweep)" tests/test_gpu_multiquery.py -m gpu -q -x -k "8 or quantized or int8 or long_calls"
+  unset SZG_BF16_8BIT
 fi
 cat $out
 echo "option sets failed: $failed"

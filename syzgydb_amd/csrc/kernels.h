@@ -167,6 +167,7 @@ struct MqArgs {
     int metric;               // kCosine: image = q/|q|, key = -cos.  kEuclidean: image = the scan's
                               // prepared query (maxInt*q for quantized rows), key = |n - image|^2
     float qnorm2[kMqMaxQueries];  // euclid: |image_q|^2 per query
+    float qsum[kMqMaxQueries];    // 8-bit rows through the bfloat16 sweep: -255 x the sum of the query's (rounded) image values
     float norm_bias;          // integer sweep: turns 4*(sum v'^2 + sum v') into sum n^2 of the real elements
     float *keys;              // out: [n_queries][key_stride] ranking keys
     size_t key_stride;        // floats, multiple of 4, >= n_rows
@@ -200,14 +201,14 @@ hipError_t launch_cand_select(const uint64_t *cand_buf, const uint32_t *cand_cou
 // where the band ended -- followed by the query's n_sent sentinel rows: lists [n_queries][kp + n_sent].  A band that
 // does not fit sets cand_count[q] to 0xFFFFFFFF (the batch is redone through the score matrix).
 bool cand_refine_applies(int kp, uint32_t cand_cap, int dim, bool rescore);
-hipError_t launch_cand_refine(int mode, const uint8_t *rows, uint32_t pitch, int dim, const double *q64,
+hipError_t launch_cand_refine(int mode, const uint8_t *rows, RowLayout layout, int dim, const double *q64,
                               const double *qscale, const double *qnorm2, const uint64_t *cand_buf, uint32_t *cand_count,
                               uint32_t cand_cap, int kp, int n_queries, const uint64_t *sent, int n_sent,
                               uint64_t *lists, float *band_edge, int row_bits, hipStream_t stream);
 // float32 re-score of the collected candidates of a bfloat16 sweep (32-bit rows, or 16-bit rows of whole 16-byte
 // pieces, decoded to n = 2v - 65535): replaces the key in every candidate word; qscale[q] = 1/|q| (cosine) or the
 // prepared query's scale (euclid: 1, or 65535 for 16-bit rows), the float32 query is (float)(q64 * qscale)
-hipError_t launch_cand_rescore(int metric, const uint8_t *rows, uint32_t pitch, int dim, const double *q64,
+hipError_t launch_cand_rescore(int metric, const uint8_t *rows, RowLayout layout, int dim, const double *q64,
                                const double *qscale, uint64_t *cand_buf, const uint32_t *cand_count,
                                uint32_t cand_cap, int n_queries, int row_bits, hipStream_t stream);
 

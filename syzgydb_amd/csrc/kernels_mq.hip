@@ -790,6 +790,222 @@ __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArg
 }
 #endif  // SZG_MQ_PART == 116 (direct 16-bit)
 
+#if SZG_MQ_PART == 108
+// ---- 8-bit rows through the bfloat16 matrix instruction: 96 queries per pass -----------------------------------------
+//
+// An 8-bit code is EXACT in bfloat16: v = 0..255 has eight significant bits.  So the rows need no digit planes and no
+// integer arithmetic to be multiplied exactly -- only the QUERY is rounded (to bfloat16, as for float rows), which the
+// bfloat16 path's second stage (float32 re-score of the band, §4.2a) and bounds already cover.  What that buys: the
+// image of 96 queries is 6 KiB per 32 elements instead of the int8 sweep's 2 planes x 3 KiB per 48 queries, i.e. ONE
+// pass of the rows per 96 queries where the int8 sweep makes two, for the same number of matrix instructions.
+// The row operand: lane (row = lane & 15, c = lane >> 4) loads its 16 bytes of the 64-byte step of a TILED row (one
+// contiguous KiB per wave instruction) = 16 codes = its share of TWO B operands (codes 0-7 and 8-15); the A operands
+// are the natural image at the permuted addresses of mq_score_bf16d_kernel.  With n = 2v - 255:
+// sum g n = 2 sum g v - 255 sum g; -255 sum g (over the ROUNDED image) is a per-query constant staged beside the
+// thresholds (MqArgs::qsum).
+// Norms: the resident array (launch_row_norms, the int8 formula = sum n^2 of the real elements).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef SZG_MQD8_WAVES
+#define SZG_MQD8_WAVES 12
+#endif
+#ifndef SZG_MQD8_RING
+#define SZG_MQD8_RING 4
+#endif
+constexpr int kMqd8Threads = 64 * SZG_MQD8_WAVES;
+template <int NB, int METRIC, bool COLLECT>
+__global__ __launch_bounds__(kMqd8Threads) void mq_score_bf16d8_kernel(const MqArgs a)
+{
+    constexpr int D = COLLECT ? SZG_MQD8_RING : 6;
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int DT = (int)a.steps;        // 64-byte steps per (tiled) row = double K-steps
+    const int n16 = 2 * DT * NB * 64;   // a KiB per 32-element K-step and query block
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        stage_image(dst, src, n16, tid, blockDim.x);
+        // table: [0, 96) thresholds, [96, 192) |g|^2, [192, 288) -255 sum g
+        float *tab = reinterpret_cast<float *>(smem + (size_t)n16 * 16);
+        if (COLLECT && tid < kMqMaxQueries) tab[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
+        if (tid >= 128 && tid < 128 + kMqMaxQueries) tab[tid - 32] = a.qnorm2[tid - 128];
+        if (tid >= 256 && tid < 256 + kMqMaxQueries) tab[tid - 64] = a.qsum[tid - 256];
+    }
+    const v4i32b *qimg = reinterpret_cast<const v4i32b *>(smem);
+    const float *thr_lds = reinterpret_cast<const float *>(smem + (size_t)n16 * 16);
+    HitBuf hb;
+    {
+        uint8_t *base = smem + (size_t)n16 * 16 + 3 * kMqMaxQueries * sizeof(float);
+        hb.cand = reinterpret_cast<uint64_t *>(base) + (size_t)wave * kHitCap;
+        hb.query = base + (size_t)nwaves * kHitCap * 8 + (size_t)wave * kHitCap;
+        hb.n = 0;
+    }
+    const int trow = lane & 15, c = lane >> 4;
+    const uint64_t n_tiles = ((uint64_t)a.n_rows + 15) / 16;
+    const uint64_t tile_stride = (uint64_t)gridDim.x * nwaves;
+    const uint64_t tile_first = (uint64_t)blockIdx.x * nwaves + wave;
+    const uint64_t n_it = tile_first < n_tiles ? (n_tiles - tile_first + tile_stride - 1) / tile_stride : 0;
+    const uint64_t NP = n_it * (uint64_t)DT;
+    const int lane_e = trow + 32 * (c & 1) + (c >> 1) * (NB * 64);  // (see mq_score_bf16d_kernel)
+    const size_t tile_bytes = (size_t)DT * 1024;
+    const size_t lane_off = (size_t)trow * 64 + (size_t)c * 16;
+
+    uint64_t itile = tile_first, ctile = tile_first;
+    int is = 0, cs = 0;
+    u32x4 ring[D];
+    f32x4 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float nrm = 0.f;
+    v4i32b qn[NB];
+    const uint8_t *iptr = a.rows + (size_t)min(tile_first, n_tiles - 1) * tile_bytes + lane_off;
+
+#define MQ8_ISSUE(u)                                                                     \
+    {                                                                                    \
+        ring[u] = load_stream<true>(iptr);                                               \
+        if (++is == DT) {                                                                \
+            is = 0;                                                                      \
+            itile += tile_stride;                                                        \
+            iptr = a.rows + (size_t)min(itile, n_tiles - 1) * tile_bytes + lane_off; /* (past the end: the last tile, discarded) */ \
+        } else {                                                                         \
+            iptr += 1024;                                                                \
+        }                                                                                \
+    }
+
+    // one operand: two dwords = eight codes v (0..255: exact in bfloat16) -> float (v_cvt_f32_ubyteN) -> bfloat16 pairs,
+    // NB matrix instructions.  (The signed form v - 128 cost a sign extension per code: 44 instead of 24 vector
+    // instructions per KiB.)
+#ifdef SZG_MQD8_SIGNED
+#define MQ8_PK(a_, b_) (int)__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{(float)(a_), (float)(b_)}, bf16x2))
+#define MQ8_DECODE(w0_, w1_)                                                             \
+        {                                                                                \
+            const int s0_ = (int)((w0_) ^ 0x80808080u), s1_ = (int)((w1_) ^ 0x80808080u); \
+            bop_[0] = MQ8_PK((s0_ << 24) >> 24, (s0_ << 16) >> 24);                      \
+            bop_[1] = MQ8_PK((s0_ << 8) >> 24, s0_ >> 24);                               \
+            bop_[2] = MQ8_PK((s1_ << 24) >> 24, (s1_ << 16) >> 24);                      \
+            bop_[3] = MQ8_PK((s1_ << 8) >> 24, s1_ >> 24);                               \
+        }
+#else
+#define MQ8_PK(a_, b_) (int)__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{(float)(a_), (float)(b_)}, bf16x2))
+#define MQ8_DECODE(w0_, w1_)                                                             \
+        {                                                                                \
+            bop_[0] = MQ8_PK((w0_) & 0xFFu, ((w0_) >> 8) & 0xFFu);                       \
+            bop_[1] = MQ8_PK(((w0_) >> 16) & 0xFFu, (w0_) >> 24);                        \
+            bop_[2] = MQ8_PK((w1_) & 0xFFu, ((w1_) >> 8) & 0xFFu);                       \
+            bop_[3] = MQ8_PK(((w1_) >> 16) & 0xFFu, (w1_) >> 24);                        \
+        }
+#endif
+#define MQ8_HALF(w0_, w1_, h_)                                                           \
+    {                                                                                    \
+        v4i32b bop_;                                                                     \
+        MQ8_DECODE(w0_, w1_)                                                             \
+        if ((h_) == 0 && cs == 0) nrm = a.row_norm[min(ctile * 16 + trow, (uint64_t)a.n_rows - 1)]; \
+        const int qnext_ = lane_e + ((h_) == 0 ? cs * (2 * NB * 64) + 16 : (cs + 1 == DT ? 0 : cs + 1) * (2 * NB * 64)); \
+        _Pragma("unroll") for (int b = 0; b < NB; b++)                                   \
+        {                                                                                \
+            const v4i32b qc_ = qn[b];                                                    \
+            qn[b] = qimg[qnext_ + b * 64];                                               \
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qc_),              \
+                                                             __builtin_bit_cast(bf16x8, bop_), acc[b], 0, 0, 0); \
+        }                                                                                \
+    }
+
+#define MQ8_CONSUME(u)                                                                   \
+    {                                                                                    \
+        const u32x4 v_ = ring[u];                                                        \
+        MQ8_HALF(v_.x, v_.y, 0)                                                          \
+        MQ8_HALF(v_.z, v_.w, 1)                                                          \
+        if (++cs == DT) {                                                                \
+            finish_tile(ctile);                                                          \
+            cs = 0;                                                                      \
+            ctile += tile_stride;                                                        \
+        }                                                                                \
+    }
+
+    auto finish_tile = [&](uint64_t tile) {
+        const uint64_t row = tile * 16 + trow;
+        const float inv = __frsqrt_rn(nrm);  // (every n is odd: the norm of an 8-bit row is at least its dimension)
+        if (COLLECT || row < a.n_rows) {
+            float keys[NB][4];
+            uint32_t hm = 0;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const float4 th = COLLECT ? *reinterpret_cast<const float4 *>(thr_lds + b * 16 + c * 4)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float thv[4] = {th.x, th.y, th.z, th.w};
+                const float4 qn4 = METRIC == kCosine ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                                     : *reinterpret_cast<const float4 *>(thr_lds + kMqMaxQueries + b * 16 + c * 4);
+                const float qnv[4] = {qn4.x, qn4.y, qn4.z, qn4.w};
+                const float4 qs4 = *reinterpret_cast<const float4 *>(thr_lds + 2 * kMqMaxQueries + b * 16 + c * 4);
+                const float qsv[4] = {qs4.x, qs4.y, qs4.z, qs4.w};
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float dotn = fmaf(2.0f, acc[b][r], qsv[r]);  // sum g n = 2 sum g v - 255 sum g
+                    float key = METRIC == kCosine ? -dotn * inv : fmaf(-2.0f, dotn, nrm + qnv[r]);
+                    key = fminf(key, 3.0e38f);  // NaN, +inf -> 3e38
+                    keys[b][r] = key;
+                    if (COLLECT)  // (unused query slots carry a threshold of -3e38: never a hit)
+                        hm |= (uint32_t)(key <= thv[r]) << (b * 4 + r);
+                    else if (b * 16 + c * 4 + r < a.n_queries)
+                        a.keys[(size_t)(b * 16 + c * 4 + r) * a.key_stride + row] = key;
+                }
+            }
+            if (COLLECT) {
+                hm = row < a.n_rows ? hm : 0u;
+                offer_tile_hits<NB>(a, hb, lane, c, hm, keys, row);
+            }
+        }
+        if (!COLLECT) __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the key stores (one vmcnt for loads and stores)
+#pragma unroll
+        for (int b = 0; b < NB; b++) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        nrm = 0.f;
+    };
+
+    {
+        uint64_t issued = D, consumed = 0;
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            MQ8_ISSUE(u)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();  // the query image is complete (the rows do not depend on it)
+#pragma unroll
+        for (int b = 0; b < NB; b++) qn[b] = qimg[lane_e + b * 64];
+        while (consumed + 2 * D <= NP) {
+#pragma unroll
+            for (int u = 0; u < D; u++) {
+                MQ8_CONSUME(u)
+                MQ8_ISSUE(u)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            consumed += D;
+            issued += D;
+        }
+        while (consumed < NP) {
+#pragma unroll
+            for (int u = 0; u < D; u++) {
+                if (consumed < NP) {
+                    MQ8_CONSUME(u)
+                    consumed++;
+                    if (issued < NP) {
+                        MQ8_ISSUE(u)
+                        issued++;
+                    }
+                }
+            }
+        }
+    }
+#undef MQ8_ISSUE
+#undef MQ8_HALF
+#undef MQ8_CONSUME
+    if (COLLECT) hit_flush(a, hb, lane);
+}
+#endif  // SZG_MQ_PART == 108
+
 #if SZG_MQ_PART == 1 || SZG_MQ_PART == 2
 // ---- exact integer shared sweep, 8-bit rows (part 1) and 4-bit rows (part 2) ---------------------------------------
 //
@@ -1534,6 +1750,26 @@ template <bool COS>
 __device__ __forceinline__ void rescore_use(const uint4 w, const float *qf, int piece, int row_bits, int dim,
                                             float &dot, float &nrm, uint32_t &nz)
 {
+    if (row_bits == 8) {  // sixteen codes, n = 2v - 255 (exact); the last piece's padding codes are not part of the row
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+        const int n8 = min(16, dim - piece * 16);
+        const float *y8 = qf + (size_t)piece * 16;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (i < n8) {
+                const float xv = fmaf((float)((ww[i >> 2] >> (8 * (i & 3))) & 0xFFu), 2.0f, -255.0f);
+                if (COS) {
+                    dot = fmaf(xv, y8[i], dot);
+                    nrm = fmaf(xv, xv, nrm);
+                } else {
+                    const float d = xv - y8[i];
+                    dot = fmaf(d, d, dot);
+                }
+            }
+        }
+        nz |= 1u;
+        return;
+    }
     float x[8];
     int n;
     if (row_bits == 16) {
@@ -1571,15 +1807,20 @@ __device__ __forceinline__ void rescore_use(const uint4 w, const float *qf, int 
         }
     }
 }
-template <bool COS>
-__device__ __forceinline__ void rescore_piece(const uint8_t *row, const float *qf, int piece, int row_bits, int dim,
-                                              float &dot, float &nrm, uint32_t &nz)
+__device__ __forceinline__ int rescore_epp(int row_bits)  // elements per 16-byte piece
 {
-    rescore_use<COS>(reinterpret_cast<const uint4 *>(row)[piece], qf, piece, row_bits, dim, dot, nrm, nz);
+    return row_bits == 8 ? 16 : (row_bits == 16 ? 8 : (row_bits == 64 ? 2 : 4));
+}
+template <bool COS>
+__device__ __forceinline__ void rescore_piece(const uint8_t *rows, const RowLayout &lay, uint32_t row, const float *qf, int piece,
+                                              int row_bits, int dim, float &dot, float &nrm, uint32_t &nz)
+{
+    rescore_use<COS>(*reinterpret_cast<const uint4 *>(rows + piece_offset(lay, row, (uint32_t)piece)), qf, piece, row_bits, dim,
+                     dot, nrm, nz);
 }
 
 template <int METRIC>
-__global__ __launch_bounds__(256) void cand_rescore_kernel(const uint8_t *rows, uint32_t pitch, int dim,
+__global__ __launch_bounds__(256) void cand_rescore_kernel(const uint8_t *rows, RowLayout lay, int dim,
                                                            const double *q64, const double *qscale,
                                                            uint64_t *cand_buf, const uint32_t *cand_count,
                                                            uint32_t cand_cap, int row_bits)
@@ -1592,16 +1833,15 @@ __global__ __launch_bounds__(256) void cand_rescore_kernel(const uint8_t *rows, 
     const double sc = qscale[q];
     // whole 16-byte pieces: a 32-bit row's padding is stored as zeros, the query's staged as zeros (16-bit rows come
     // here with whole pieces only)
-    const int epp = row_bits == 16 ? 8 : (row_bits == 64 ? 2 : 4), pieces = (dim + epp - 1) / epp;
+    const int epp = rescore_epp(row_bits), pieces = (dim + epp - 1) / epp;
     for (int i = tid; i < epp * pieces; i += blockDim.x) qf[i] = i < dim ? (float)(q64[(size_t)q * dim + i] * sc) : 0.0f;
     __syncthreads();
     uint64_t *cb = cand_buf + (size_t)q * cand_cap;
     for (uint32_t ci = blockIdx.x * 4 + wave; ci < n; ci += gridDim.x * 4) {
         const uint32_t row = (uint32_t)cb[ci];
-        const uint8_t *rp = rows + (size_t)row * pitch;
         float dot = 0.f, nrm = 0.f;
         uint32_t nz = 0;
-        for (int i = lane; i < pieces; i += 64) rescore_piece<METRIC == kCosine>(rp, qf, i, row_bits, dim, dot, nrm, nz);
+        for (int i = lane; i < pieces; i += 64) rescore_piece<METRIC == kCosine>(rows, lay, row, qf, i, row_bits, dim, dot, nrm, nz);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             dot += __shfl_xor(dot, o);
@@ -1731,7 +1971,7 @@ constexpr int kRefineMaxBand = 1024;
 constexpr int kRefineMaxKp = 256;
 
 template <int MODE>
-__global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8_t *rows, uint32_t pitch, int dim,
+__global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8_t *rows, RowLayout lay, int dim,
                                                                      const double *q64, const double *qscale,
                                                                      const double *qnorm2, const uint64_t *cand_buf,
                                                                      uint32_t *cand_count, uint32_t cand_cap, int kp,
@@ -1755,7 +1995,7 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
     for (uint32_t i = tid; i < n; i += kRefineThreads) cand[i] = src[i];
     if (MODE > 0) {
         const double sc = qscale[q];
-        const int epp0 = row_bits == 16 ? 8 : (row_bits == 64 ? 2 : 4);
+        const int epp0 = rescore_epp(row_bits);
         for (int i = tid; i < epp0 * ((dim + epp0 - 1) / epp0); i += kRefineThreads)
             qf[i] = i < dim ? (float)(q64[(size_t)q * dim + i] * sc) : 0.0f;  // (padding: zeros, as in the rows)
     }
@@ -1780,7 +2020,7 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
     // only grows).  Two histogram rounds over the ordered key's top 12 + 12 bits (as mq_thr_radix_kernel) instead of
     // round 3's sixteen sorted per-wave lists and their rank merge, which nothing else read: 60 -> ~30 us per batch.
     {
-        uint32_t *hist = reinterpret_cast<uint32_t *>(qf + ((dim + 7) & ~7));  // [4096]
+        uint32_t *hist = reinterpret_cast<uint32_t *>(qf + ((dim + 15) & ~15));  // [4096]
         __shared__ uint32_t wsum[NW];
         __shared__ uint32_t sel_bin, sel_below;
         uint32_t prefix_bits = 0, below = 0;
@@ -1862,17 +2102,15 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
     // float32 keys for the band: one wave per candidate, four candidates' row gathers in flight per wave (the rows were
     // streamed past the caches by the sweep: every gather is a full HBM round trip, and a wave that walked its ~7
     // candidates one after the other paid seven of them in a row)
-    const int epp = row_bits == 16 ? 8 : (row_bits == 64 ? 2 : 4), pieces = (dim + epp - 1) / epp;
+    const int epp = rescore_epp(row_bits), pieces = (dim + epp - 1) / epp;
     constexpr int U = 4;
     for (uint32_t c0 = (uint32_t)wave * U; c0 < nb; c0 += NW * U) {
-        const uint8_t *rp[U];
         uint32_t rowv[U];
         float dot[U], nrm[U];
         uint32_t nz[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             rowv[u] = (uint32_t)band[min(c0 + u, nb - 1)];  // (past the band's end: the last candidate again, not written)
-            rp[u] = rows + (size_t)rowv[u] * pitch;
             dot[u] = nrm[u] = 0.f;
             nz[u] = 0;
         }
@@ -1886,7 +2124,7 @@ __global__ __launch_bounds__(kRefineThreads) void cand_refine_kernel(const uint8
             for (int u = 0; u < U; u++)
 #pragma unroll
                 for (int pi = 0; pi < PI; pi++)
-                    w[u][pi] = reinterpret_cast<const uint4 *>(rp[u])[min(i0 + 64 * pi, pieces - 1)];
+                    w[u][pi] = *reinterpret_cast<const uint4 *>(rows + piece_offset(lay, rowv[u], (uint32_t)min(i0 + 64 * pi, pieces - 1)));
 #pragma unroll
             for (int u = 0; u < U; u++)
 #pragma unroll
@@ -1950,18 +2188,18 @@ hipError_t launch_cand_select(const uint64_t *cand_buf, const uint32_t *cand_cou
     return hipGetLastError();
 }
 
-hipError_t launch_cand_rescore(int metric, const uint8_t *rows, uint32_t pitch, int dim, const double *q64,
+hipError_t launch_cand_rescore(int metric, const uint8_t *rows, RowLayout lay, int dim, const double *q64,
                                const double *qscale, uint64_t *cand_buf, const uint32_t *cand_count,
                                uint32_t cand_cap, int n_queries, int row_bits, hipStream_t stream)
 {
-    if (row_bits != 32 && row_bits != 16 && row_bits != 64) return hipErrorInvalidValue;
+    if (row_bits != 32 && row_bits != 16 && row_bits != 64 && row_bits != 8) return hipErrorInvalidValue;
     const dim3 grid(SZG_RESCORE_BLOCKS, n_queries);  // x 4 waves: one candidate per wave and trip
-    const size_t lds = (size_t)((dim + 7) & ~7) * sizeof(float);
+    const size_t lds = (size_t)((dim + 15) & ~15) * sizeof(float);
     if (metric == kCosine)
-        hipLaunchKernelGGL(cand_rescore_kernel<kCosine>, grid, dim3(256), lds, stream, rows, pitch, dim, q64, qscale,
+        hipLaunchKernelGGL(cand_rescore_kernel<kCosine>, grid, dim3(256), lds, stream, rows, lay, dim, q64, qscale,
                            cand_buf, cand_count, cand_cap, row_bits);
     else
-        hipLaunchKernelGGL(cand_rescore_kernel<kEuclidean>, grid, dim3(256), lds, stream, rows, pitch, dim, q64,
+        hipLaunchKernelGGL(cand_rescore_kernel<kEuclidean>, grid, dim3(256), lds, stream, rows, lay, dim, q64,
                            qscale, cand_buf, cand_count, cand_cap, row_bits);
     return hipGetLastError();
 }
@@ -1971,19 +2209,19 @@ bool cand_refine_applies(int kp, uint32_t cand_cap, int dim, bool rescore)
     return kp <= kRefineMaxKp && cand_cap <= (uint32_t)kRefineMaxCands && (!rescore || dim <= 4096);
 }
 
-hipError_t launch_cand_refine(int mode, const uint8_t *rows, uint32_t pitch, int dim, const double *q64,
+hipError_t launch_cand_refine(int mode, const uint8_t *rows, RowLayout lay, int dim, const double *q64,
                               const double *qscale, const double *qnorm2, const uint64_t *cand_buf, uint32_t *cand_count,
                               uint32_t cand_cap, int kp, int n_queries, const uint64_t *sent, int n_sent,
                               uint64_t *lists, float *band_edge, int row_bits, hipStream_t stream)
 {
     if (!cand_refine_applies(kp, cand_cap, dim, mode > 0)) return hipErrorInvalidValue;
-    if (mode > 0 && row_bits != 32 && row_bits != 16 && row_bits != 64) return hipErrorInvalidValue;
+    if (mode > 0 && row_bits != 32 && row_bits != 16 && row_bits != 64 && row_bits != 8) return hipErrorInvalidValue;
     const size_t lds = ((size_t)kRefineMaxCands + (size_t)(kRefineThreads / 64) * kp + kp + kRefineMaxBand) * sizeof(uint64_t) +
-                       (mode > 0 ? (size_t)((dim + 7) & ~7) * sizeof(float) + 4096 * sizeof(uint32_t) : 0);
+                       (mode > 0 ? (size_t)((dim + 15) & ~15) * sizeof(float) + 4096 * sizeof(uint32_t) : 0);
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(n_queries), dim3(kRefineThreads), lds, stream, rows, pitch, dim, q64, qscale, qnorm2,
+        hipLaunchKernelGGL(kern, dim3(n_queries), dim3(kRefineThreads), lds, stream, rows, lay, dim, q64, qscale, qnorm2,
                            cand_buf, cand_count, cand_cap, kp, sent, n_sent, lists, band_edge, row_bits);
         return hipGetLastError();
     };
@@ -2007,24 +2245,27 @@ size_t mq_i8_lds_bytes(int row_bits, int r16, int nb, int groups)
 size_t mq_bf16_image_bytes(int row_bits, int r16, int nb)
 {   // a KiB per 32-element K-step and query block; a 128-byte step of a row holds one (32-bit rows), two (16-bit) or
     // half a one (64-bit)
+    if (row_bits == 8) return (size_t)((r16 + 3) / 4) * 2 * nb * 1024;  // (tiled rows: two K-steps per 64-byte step)
     const size_t steps = (size_t)((r16 + 7) / 8);
     return (row_bits == 64 ? (steps + 1) / 2 : steps * (row_bits == 16 ? 2 : 1)) * nb * 1024;
 }
 size_t mq_bf16_lds_bytes(int row_bits, int r16, int nb)
 {   // + thresholds, |q|^2 table and the waves' hit buffers
     // (16-bit rows -- the direct kernel -- run 12 waves without a staging KiB; the staged kernels 8 with one each)
-    return mq_bf16_image_bytes(row_bits, r16, nb) + 2 * kMqMaxQueries * sizeof(float) +
+    return mq_bf16_image_bytes(row_bits, r16, nb) + 3 * kMqMaxQueries * sizeof(float) +  // (the third table: 8-bit rows' sum g)
            std::max((size_t)SZG_MQB_WAVES * (kHitCap * 9 + 1024), (size_t)12 * kHitCap * 9);
 }
 hipError_t launch_mq_score_bf16_rows32(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
 hipError_t launch_mq_score_bf16_rows16(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
 hipError_t launch_mq_score_bf16_rows64(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
+hipError_t launch_mq_score_bf16_rows8(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
 hipError_t launch_mq_score_bf16(int row_bits, const MqArgs &a, int nb, int grid, hipStream_t stream)
 {
     const size_t lds = mq_bf16_lds_bytes(row_bits, a.r16, nb);
     if (row_bits == 32) return launch_mq_score_bf16_rows32(a, nb, grid, lds, stream);
     if (row_bits == 16) return launch_mq_score_bf16_rows16(a, nb, grid, lds, stream);
     if (row_bits == 64) return launch_mq_score_bf16_rows64(a, nb, grid, lds, stream);
+    if (row_bits == 8) return launch_mq_score_bf16_rows8(a, nb, grid, lds, stream);
     return hipErrorInvalidValue;
 }
 hipError_t launch_mq_score_i8_rows8(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream);
@@ -2106,6 +2347,44 @@ hipError_t launch_mq_score_bf16_rows64(const MqArgs &a, int nb, int grid, size_t
     }
 }
 #endif  // SZG_MQ_PART == 3 || 116 || 164
+
+#if SZG_MQ_PART == 108
+namespace {
+template <int NB, int METRIC, bool COLLECT>
+hipError_t launch_mq_score_bf16d8_t(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
+{
+    auto *kern = &mq_score_bf16d8_kernel<NB, METRIC, COLLECT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kMqd8Threads), lds, stream, a);
+    return hipGetLastError();
+}
+template <int NB>
+hipError_t launch_mq_score_bf16d8_m(const MqArgs &a, int grid, size_t lds, hipStream_t stream)
+{
+    if (a.collect) {
+        if (a.metric == kCosine) return launch_mq_score_bf16d8_t<NB, kCosine, true>(a, grid, lds, stream);
+        return launch_mq_score_bf16d8_t<NB, kEuclidean, true>(a, grid, lds, stream);
+    }
+    if (a.metric == kCosine) return launch_mq_score_bf16d8_t<NB, kCosine, false>(a, grid, lds, stream);
+    return launch_mq_score_bf16d8_t<NB, kEuclidean, false>(a, grid, lds, stream);
+}
+}  // namespace
+
+hipError_t launch_mq_score_bf16_rows8(const MqArgs &a, int nb, int grid, size_t lds, hipStream_t stream)
+{
+    if (!a.tiled || a.steps == 0 || a.n_rows == 0 || !a.row_norm) return hipErrorInvalidValue;
+    switch (nb) {
+    case 1: return launch_mq_score_bf16d8_m<1>(a, grid, lds, stream);
+    case 2: return launch_mq_score_bf16d8_m<2>(a, grid, lds, stream);
+    case 3: return launch_mq_score_bf16d8_m<3>(a, grid, lds, stream);
+    case 4: return launch_mq_score_bf16d8_m<4>(a, grid, lds, stream);
+    case 5: return launch_mq_score_bf16d8_m<5>(a, grid, lds, stream);
+    case 6: return launch_mq_score_bf16d8_m<6>(a, grid, lds, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+#endif  // SZG_MQ_PART == 108
 
 #if SZG_MQ_PART == 1 || SZG_MQ_PART == 2
 namespace {

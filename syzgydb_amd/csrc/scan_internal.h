@@ -175,6 +175,7 @@ struct Ctx {
     bool timed_part = false;
     int timed_part_n = 0;
     hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr, ev_all0 = nullptr, ev_all1 = nullptr;
+    float mq_qsum[128] = {};             // bfloat16 sweep of 8-bit rows: -255 x the sum of each staged query's rounded image values
     hipEvent_t ev_scan_done = nullptr;   // this batch's scans have finished (scan stream)
     hipEvent_t ev_up = nullptr;          // this batch's uploads have finished (ctx stream)
     // pinned host staging, kMaxBatch queries
@@ -386,12 +387,14 @@ szg::RowMap choose_map(int r16, bool tiled = false);
 void prep_query(const szg_index *ix, const double *q, uint8_t *out_sw, QMeta *meta);
 void prep_query_meta(const szg_index *ix, const double *q, QMeta *meta);  // the constants only (shared sweeps)
 double key_eps(const szg_index *ix, double key, const QMeta &m);
-bool mq_uses_i8(const szg_index *ix);
-bool mq_uses_bf16(const szg_index *ix);
+// (radius: the batch is a radius batch -- tiled 8-bit rows then stay on the exact int8 sweep: the bfloat16 sweep's
+// band around every radius would collect several times the hits)
+bool mq_uses_i8(const szg_index *ix, bool radius = false);
+bool mq_uses_bf16(const szg_index *ix, bool radius = false);
 uint16_t bf16_rne(float f);
 double mq_int_scale(const szg_index *ix, double m1);
 void prep_mq_int(const szg_index *ix, const double *q, QMeta *meta, int32_t *Qout);
-int mq_blocks(const szg_index *ix, int nq);
+int mq_blocks(const szg_index *ix, int nq, bool radius = false);
 // key threshold of a radius search: surely contains every row with distance <= radius
 float radius_key_threshold(const szg_index *ix, double radius, const QMeta &meta);
 
@@ -441,6 +444,9 @@ int replay_rows_into_heap(szg_index *ix, const double *query, const uint64_t *al
 int search_radius_impl(szg_index *ix, const double *queries, int n_queries, const double *radii,
                        const uint64_t *const *masks, std::vector<std::vector<HeapItem>> *results);
 
+#ifndef SZG_BF16_8BIT_DEFAULT
+#define SZG_BF16_8BIT_DEFAULT 1  // tiled 8-bit rows take the bfloat16 sweep for top-k batches (SZG_BF16_8BIT=0: the int8 sweep)
+#endif
 // ---- scan_mq.cpp
 // the shard's resident row norms are complete (16-bit rows; no-op otherwise): called before a shared sweep is enqueued
 int ensure_row_norms(szg_index *ix, Shard *sh);

@@ -15,15 +15,29 @@ void build_image_bf16(const szg_index *ix, Ctx *c, int nq, int nb)
         const double *src = c->h_q64 + (size_t)q * dim;
         const double m1 = c->meta[q].m1;
         double scale = m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0;
-        if (ix->metric != SZG_COSINE) scale = ix->bits == 16 ? 65535.0 : 1.0;  // maxInt * q against rows decoded to n
+        if (ix->metric != SZG_COSINE) scale = ix->bits == 16 ? 65535.0 : (ix->bits == 8 ? 255.0 : 1.0);  // maxInt * q against rows decoded to n
         const int b = q / 16, qi = q % 16;
+        // (8-bit rows: n = 2v - 255 -- the sweep multiplies the codes v and adds -255 sum g, over the ROUNDED image values)
+        const bool want_sum = ix->bits == 8;
+        double gs[4] = {0.0, 0.0, 0.0, 0.0};
         // runs of 8 consecutive elements are contiguous in the image (one lane's 16 bytes)
         for (int e0 = 0; e0 < dim; e0 += 8) {
             const int S = e0 >> 5, kg = (e0 & 31) >> 3;
             uint16_t *dst = im + ((((size_t)S * nb + b) * 64) + kg * 16 + qi) * 8;
             const int cnt = std::min(8, dim - e0);
             for (int i = 0; i < cnt; i++) dst[i] = bf16_rne((float)(src[e0 + i] * scale));
+            if (want_sum) {
+                for (int i = 0; i < cnt; i++) {
+                    const uint32_t u = (uint32_t)dst[i] << 16;
+                    float f;
+                    memcpy(&f, &u, 4);
+                    gs[i & 3] += (double)f;
+                }
+            }
         }
+        const double gsum = (gs[0] + gs[1]) + (gs[2] + gs[3]);
+        static const bool signed8 = getenv("SZG_MQD8_SIGNED") != nullptr;  // (A/B with a -DSZG_MQD8_SIGNED kernel build)
+        c->mq_qsum[q] = (float)(signed8 ? gsum : -255.0 * gsum);
     }
 }
 
@@ -195,7 +209,7 @@ int mq_buffers(szg_index *ix, Ctx *c, const MqPlan &p, int nq, int n_out)
         for (int q = 0; q < nq; q++) {
             const double m1 = c->meta[q].m1;
             c->h_qscale[q] = ix->metric == SZG_COSINE ? (m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0)
-                                                      : (ix->bits == 16 ? 65535.0 : 1.0);  // euclid: the prepared query, maxInt * q
+                                                      : (ix->bits == 16 ? 65535.0 : (ix->bits == 8 ? 255.0 : 1.0));  // euclid: the prepared query, maxInt * q
             c->h_qscale[128 + q] = c->meta[q].qnorm2;
         }
         HIPCHK(hipMemcpyAsync(c->d_qscale, c->h_qscale, sizeof(double) * 256, hipMemcpyHostToDevice, c->stream));
@@ -244,7 +258,10 @@ static szg::MqArgs mq_args_base(const szg_index *ix, const Shard *sh, const Ctx 
     a.shape_kernels = ix->shape_kernels;
     a.group_stride = (uint32_t)group_stride;
     a.metric = ix->metric;
-    for (int q = 0; q < nq && q < szg::kMqMaxQueries; q++) a.qnorm2[q] = (float)c->meta[q].qnorm2;
+    for (int q = 0; q < nq && q < szg::kMqMaxQueries; q++) {
+        a.qnorm2[q] = (float)c->meta[q].qnorm2;
+        a.qsum[q] = c->mq_qsum[q];
+    }
     a.zero16 = sh->zero16;
     a.norm_bias = (float)ix->norm_bias;
     a.row_norm = row_norms_apply(ix) && sh->row_norm && sh->norm_valid >= sh->n_rows ? sh->row_norm : nullptr;
@@ -347,13 +364,13 @@ int enqueue_topk_mq(szg_index *ix, Shard *sh, Ctx *c, int kp, int kp_wide, int n
         uint64_t *src = c->d_lists_a;
         if (p.refine) {
             const int mode = !p.stage2 ? 0 : (ix->metric == SZG_COSINE ? 1 : 2);
-            HIPCHK(szg::launch_cand_refine(mode, sh->rows, ix->pitch, ix->dim, c->d_q64, c->d_qscale,
+            HIPCHK(szg::launch_cand_refine(mode, sh->rows, ix->layout, ix->dim, c->d_q64, c->d_qscale,
                                            c->d_qscale ? c->d_qscale + 128 : nullptr, c->d_cand, c->d_cand_count,
                                            p.cand_cap, kp, nq, merge_sent ? c->d_sent : nullptr, merge_sent ? n_sent : 0,
                                            c->d_lists_a, c->d_thr + 128, ix->bits, tail));
         } else if (p.fused) {
             if (p.stage2)
-                HIPCHK(szg::launch_cand_rescore(ix->metric, sh->rows, ix->pitch, ix->dim, c->d_q64, c->d_qscale, c->d_cand,
+                HIPCHK(szg::launch_cand_rescore(ix->metric, sh->rows, ix->layout, ix->dim, c->d_q64, c->d_qscale, c->d_cand,
                                                 c->d_cand_count, p.cand_cap, nq, ix->bits, tail));
             HIPCHK(szg::launch_cand_select(c->d_cand, c->d_cand_count, p.cand_cap, kp, nq, c->d_lists_a, tail));
         } else {
@@ -410,7 +427,7 @@ int enqueue_collect_mq(szg_index *ix, Shard *sh, Ctx *c, int nq, int nb, bool ha
     int rc_norm = ensure_row_norms(ix, sh);
     if (rc_norm) return rc_norm;
     const int r16 = ix->map.r16;
-    const bool i8 = mq_uses_i8(ix), bf16 = mq_uses_bf16(ix);
+    const bool i8 = mq_uses_i8(ix, true), bf16 = mq_uses_bf16(ix, true);
     const int groups = i8 ? (nq + 16 * nb - 1) / (16 * nb) : 1;
     if (nq > szg::kMqMaxQueries || groups > 2 || (groups == 2 && nb != 3))
         return fail(SZG_E_INVALID, "shared radius sweep: batch too large for the image");

@@ -202,7 +202,7 @@ int RadiusCall::stage(RadiusTicket &t)
     }
     const double t0 = now_us();
     Ctx *c0 = nullptr;
-    const bool int_planes = t.nb > 0 && mq_uses_i8(ix);
+    const bool int_planes = t.nb > 0 && mq_uses_i8(ix, true);
     for (size_t s = 0; s < n_sh; s++) {
         Ctx *c = t.ctx[s];
         if (!c) continue;
@@ -227,7 +227,7 @@ int RadiusCall::stage(RadiusTicket &t)
                     if (int_planes) prep_mq_int(ix, q + (size_t)j * ix->dim, &c->meta[j], c->h_mqQ + (size_t)j * ix->dim);
                     QMeta m2 = c->meta[j];
                     m2.mq = !int_planes;
-                    m2.mq_bf16 = mq_uses_bf16(ix);
+                    m2.mq_bf16 = mq_uses_bf16(ix, true);
                     t.thr[j] = radius_key_threshold(ix, radii[t.first + j], m2);
                 }
             }
@@ -373,9 +373,9 @@ int RadiusCall::run()
         const int edge = std::max(1, std::min(qpl, ix->first_batch > 0 ? ix->first_batch : qpl));
         t.nq = std::min(qpl, left);
         // two or more queries left: they share one sweep of the corpus (up to 96 per pass), as top-k batches do
-        t.nb = ix->radius_mq && left >= 2 ? mq_blocks(ix, left) : 0;
+        t.nb = ix->radius_mq && left >= 2 ? mq_blocks(ix, left, true) : 0;
         if (t.nb > 0) {
-            const int groups = t.nb == 3 && mq_uses_i8(ix) && ix->mq_i8_groups > 1 && left > 48 &&
+            const int groups = t.nb == 3 && mq_uses_i8(ix, true) && ix->mq_i8_groups > 1 && left > 48 &&
                                        szg::mq_i8_lds_bytes(ix->bits, ix->map.r16, 3, 2) <= 160u * 1024u
                                    ? 2 : 1;
             t.nq = std::min(left, 16 * t.nb * groups);

@@ -343,7 +343,8 @@ def test_int8_sweep_two_query_groups_per_launch(bits, metric):
         check(ix, rows, dim, Q, 10, allow=allow, bits=bits, metric=metric)
         st = ix.stats()
         if DEFAULT_TUNABLES:
-            assert st["mq_queries"] == 140 and st["mq_launches"] == 4   # 2 calls x (48 + 22)
+            # 2 calls x (48 + 22); 8-bit rows in whole 64-byte steps take the bfloat16 sweep, 70 queries in ONE pass
+            assert st["mq_queries"] == 140 and st["mq_launches"] == (2 if st["mq_bf16_sweeps"] else 4)
         ix.set_option("force_matrix", 1)                                # the score-matrix form
         check(ix, rows, dim, Q, 10, bits=bits, metric=metric)
         ix.set_option("force_matrix", 0)
@@ -479,3 +480,43 @@ def test_resident_row_norms_follow_mutations(bits, dim):
             assert ix.stats()["mq_queries"] > 0
         ix.load(rows[:1000])                                                 # a reload starts the norms over
         check(ix, rows[:1000].reshape(-1), dim, Q, 10, bits=bits)
+
+
+@pytest.mark.parametrize("metric", [SZG_COSINE, SZG_EUCLIDEAN])
+@pytest.mark.parametrize("dim,n", [(768, 3000), (384, 4000), (128, 9000), (64, 2000), (100, 3000), (37, 1500)])
+def test_8bit_rows_through_the_bf16_sweep(metric, dim, n):
+    """8-bit rows whose pitch is a whole number of 64-byte steps (the tiled layout) share ONE bfloat16 pass per 96
+    queries: the codes are exact in bfloat16, only the query is rounded; the band is re-scored in float32 and everything
+    re-ranked in float64 -- ids and distances are the reference loop's.  Other 8-bit shapes and every radius batch
+    stay on the exact int8 sweep."""
+    rows = orc.synth_rows(8800 + dim, 0, n, dim, 8)
+    Q = orc.synth_vectors(8801 + dim, 0, 96, dim)
+    allow = np.arange(n) % 6 != 1
+    tiled = dim % 64 == 0
+    with ScanIndex(dim, 8, metric) as ix:
+        ix.load(rows)
+        check(ix, rows, dim, Q, 10, bits=8, metric=metric)
+        st = ix.stats()
+        if DEFAULT_TUNABLES and not os.environ.get("SZG_BF16_8BIT") and not os.environ.get("SZG_NO_ROW_NORMS"):
+            assert (st["mq_bf16_sweeps"] > 0) == tiled
+            assert st["mq_launches"] == (1 if tiled else 2)
+        check(ix, rows, dim, Q[:40], 7, allow=allow, bits=8, metric=metric)
+        check(ix, rows, dim, Q[:20], 100, bits=8, metric=metric)          # kp beyond the band's usual size
+        ix.tombstone(5)
+        ix.append(rows[:50].reshape(50, -1))                             # duplicates of the first rows: ties at the top
+        rows2 = np.concatenate([rows.reshape(n, -1), rows.reshape(n, -1)[:50]])
+        live = np.ones(n + 50, dtype=bool)
+        live[5] = False
+        r, d, c = ix.search_topk(Q[:30], 10)
+        for qi in range(30):
+            o_rows, o_dist, _ = orc.search_exact(rows2.reshape(-1), dim, 8, metric, Q[qi], k=10, allow=live.astype(np.uint8))
+            assert [int(x) for x in r[qi, : c[qi]]] == [int(x) for x in o_rows], qi
+            assert (d[qi, : c[qi]] == o_dist).all(), qi
+        ix.reset_stats()
+        radii = [float(d[qi, 5]) for qi in range(30)]
+        hits = ix.search_radius_batch(Q[:30], radii)
+        for qi in range(30):
+            w_r, w_d, _ = orc.search_exact(rows2.reshape(-1), dim, 8, metric, Q[qi], radius=radii[qi], allow=live.astype(np.uint8))
+            assert [int(x) for x in hits[qi][0]] == [int(x) for x in w_r] and (np.asarray(hits[qi][1]) == w_d).all(), qi
+        if DEFAULT_TUNABLES:
+            assert ix.stats()["mq_bf16_sweeps"] == 0                      # radius batches: the exact int8 sweep
