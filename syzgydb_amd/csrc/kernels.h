@@ -167,7 +167,7 @@ struct MqArgs {
     int metric;               // kCosine: image = q/|q|, key = -cos.  kEuclidean: image = the scan's
                               // prepared query (maxInt*q for quantized rows), key = |n - image|^2
     float qnorm2[kMqMaxQueries];  // euclid: |image_q|^2 per query
-    float qsum[kMqMaxQueries];    // 8-bit rows through the bfloat16 sweep: -255 x the sum of the query's (rounded) image values
+    float qsum[kMqMaxQueries];    // 8-bit rows through the bfloat16 sweep: the sum of the query's (rounded) image values
     float norm_bias;          // integer sweep: turns 4*(sum v'^2 + sum v') into sum n^2 of the real elements
     float *keys;              // out: [n_queries][key_stride] ranking keys
     size_t key_stride;        // floats, multiple of 4, >= n_rows

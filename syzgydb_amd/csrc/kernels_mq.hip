@@ -793,16 +793,16 @@ __global__ __launch_bounds__(kMqdThreads) void mq_score_bf16d_kernel(const MqArg
 #if SZG_MQ_PART == 108
 // ---- 8-bit rows through the bfloat16 matrix instruction: 96 queries per pass -----------------------------------------
 //
-// An 8-bit code is EXACT in bfloat16: v = 0..255 has eight significant bits.  So the rows need no digit planes and no
+// An 8-bit code is EXACT in bfloat16: v - 128 = -128..127 has eight significant bits.  So the rows need no digit planes and no
 // integer arithmetic to be multiplied exactly -- only the QUERY is rounded (to bfloat16, as for float rows), which the
 // bfloat16 path's second stage (float32 re-score of the band, §4.2a) and bounds already cover.  What that buys: the
 // image of 96 queries is 6 KiB per 32 elements instead of the int8 sweep's 2 planes x 3 KiB per 48 queries, i.e. ONE
 // pass of the rows per 96 queries where the int8 sweep makes two, for the same number of matrix instructions.
 // The row operand: lane (row = lane & 15, c = lane >> 4) loads its 16 bytes of the 64-byte step of a TILED row (one
 // contiguous KiB per wave instruction) = 16 codes = its share of TWO B operands (codes 0-7 and 8-15); the A operands
-// are the natural image at the permuted addresses of mq_score_bf16d_kernel.  With n = 2v - 255:
-// sum g n = 2 sum g v - 255 sum g; -255 sum g (over the ROUNDED image) is a per-query constant staged beside the
-// thresholds (MqArgs::qsum).
+// are the natural image at the permuted addresses of mq_score_bf16d_kernel.  With v' = v - 128, n = 2v' + 1:
+// sum g n = 2 sum g v' + sum g; sum g (over the ROUNDED image) is a per-query constant staged beside the thresholds
+// (MqArgs::qsum).
 // Norms: the resident array (launch_row_norms, the int8 formula = sum n^2 of the real elements).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(kMqd8Threads) void mq_score_bf16d8_kernel(const MqA
         const uint4 *src = reinterpret_cast<const uint4 *>(a.queries);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         stage_image(dst, src, n16, tid, blockDim.x);
-        // table: [0, 96) thresholds, [96, 192) |g|^2, [192, 288) -255 sum g
+        // table: [0, 96) thresholds, [96, 192) |g|^2, [192, 288) sum g
         float *tab = reinterpret_cast<float *>(smem + (size_t)n16 * 16);
         if (COLLECT && tid < kMqMaxQueries) tab[tid] = tid < a.n_queries ? a.thr[tid] : -3.0e38f;
         if (tid >= 128 && tid < 128 + kMqMaxQueries) tab[tid - 32] = a.qnorm2[tid - 128];
@@ -876,29 +876,20 @@ __global__ __launch_bounds__(kMqd8Threads) void mq_score_bf16d8_kernel(const MqA
         }                                                                                \
     }
 
-    // one operand: two dwords = eight codes v (0..255: exact in bfloat16) -> float (v_cvt_f32_ubyteN) -> bfloat16 pairs,
-    // NB matrix instructions.  (The signed form v - 128 cost a sign extension per code: 44 instead of 24 vector
-    // instructions per KiB.)
-#ifdef SZG_MQD8_SIGNED
+    // one operand: two dwords = eight codes -> v - 128 as float -> bfloat16 pairs (exact), NB matrix instructions
+// The codes are multiplied as v' = v - 128 (one xor per dword, then a sign-extending byte convert), NOT as v: with
+// n = 2v' + 1 the accumulator holds sum g v' -- small when the row is (a zero vector is all codes 128) -- whereas
+// sum g v - 127.5 sum g would cancel two numbers 128 x larger than their difference inside the matrix core's float32
+// sums, an error key_eps' bfloat16 branch has no term for.  (The unsigned form measured 2 % faster.)
 #define MQ8_PK(a_, b_) (int)__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{(float)(a_), (float)(b_)}, bf16x2))
 #define MQ8_DECODE(w0_, w1_)                                                             \
         {                                                                                \
-            const int s0_ = (int)((w0_) ^ 0x80808080u), s1_ = (int)((w1_) ^ 0x80808080u); \
-            bop_[0] = MQ8_PK((s0_ << 24) >> 24, (s0_ << 16) >> 24);                      \
-            bop_[1] = MQ8_PK((s0_ << 8) >> 24, s0_ >> 24);                               \
-            bop_[2] = MQ8_PK((s1_ << 24) >> 24, (s1_ << 16) >> 24);                      \
-            bop_[3] = MQ8_PK((s1_ << 8) >> 24, s1_ >> 24);                               \
+            const uint32_t s0_ = (w0_) ^ 0x80808080u, s1_ = (w1_) ^ 0x80808080u;         \
+            bop_[0] = MQ8_PK((int8_t)s0_, (int8_t)(s0_ >> 8));                           \
+            bop_[1] = MQ8_PK((int8_t)(s0_ >> 16), (int8_t)(s0_ >> 24));                  \
+            bop_[2] = MQ8_PK((int8_t)s1_, (int8_t)(s1_ >> 8));                           \
+            bop_[3] = MQ8_PK((int8_t)(s1_ >> 16), (int8_t)(s1_ >> 24));                  \
         }
-#else
-#define MQ8_PK(a_, b_) (int)__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{(float)(a_), (float)(b_)}, bf16x2))
-#define MQ8_DECODE(w0_, w1_)                                                             \
-        {                                                                                \
-            bop_[0] = MQ8_PK((w0_) & 0xFFu, ((w0_) >> 8) & 0xFFu);                       \
-            bop_[1] = MQ8_PK(((w0_) >> 16) & 0xFFu, (w0_) >> 24);                        \
-            bop_[2] = MQ8_PK((w1_) & 0xFFu, ((w1_) >> 8) & 0xFFu);                       \
-            bop_[3] = MQ8_PK(((w1_) >> 16) & 0xFFu, (w1_) >> 24);                        \
-        }
-#endif
 #define MQ8_HALF(w0_, w1_, h_)                                                           \
     {                                                                                    \
         v4i32b bop_;                                                                     \
@@ -944,7 +935,7 @@ __global__ __launch_bounds__(kMqd8Threads) void mq_score_bf16d8_kernel(const MqA
                 const float qsv[4] = {qs4.x, qs4.y, qs4.z, qs4.w};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float dotn = fmaf(2.0f, acc[b][r], qsv[r]);  // sum g n = 2 sum g v - 255 sum g
+                    const float dotn = fmaf(2.0f, acc[b][r], qsv[r]);  // sum g n = 2 sum g v' + sum g
                     float key = METRIC == kCosine ? -dotn * inv : fmaf(-2.0f, dotn, nrm + qnv[r]);
                     key = fminf(key, 3.0e38f);  // NaN, +inf -> 3e38
                     keys[b][r] = key;

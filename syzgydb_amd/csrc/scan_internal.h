@@ -175,7 +175,7 @@ struct Ctx {
     bool timed_part = false;
     int timed_part_n = 0;
     hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr, ev_all0 = nullptr, ev_all1 = nullptr;
-    float mq_qsum[128] = {};             // bfloat16 sweep of 8-bit rows: -255 x the sum of each staged query's rounded image values
+    float mq_qsum[128] = {};             // bfloat16 sweep of 8-bit rows: the sum of each staged query's rounded image values
     hipEvent_t ev_scan_done = nullptr;   // this batch's scans have finished (scan stream)
     hipEvent_t ev_up = nullptr;          // this batch's uploads have finished (ctx stream)
     // pinned host staging, kMaxBatch queries

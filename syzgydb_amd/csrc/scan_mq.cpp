@@ -17,7 +17,7 @@ void build_image_bf16(const szg_index *ix, Ctx *c, int nq, int nb)
         double scale = m1 > 0 ? 1.0 / std::sqrt(m1) : 0.0;
         if (ix->metric != SZG_COSINE) scale = ix->bits == 16 ? 65535.0 : (ix->bits == 8 ? 255.0 : 1.0);  // maxInt * q against rows decoded to n
         const int b = q / 16, qi = q % 16;
-        // (8-bit rows: n = 2v - 255 -- the sweep multiplies the codes v and adds -255 sum g, over the ROUNDED image values)
+        // (8-bit rows: n = 2v' + 1, v' = v - 128 -- the sweep multiplies v' and adds sum g, over the ROUNDED image values)
         const bool want_sum = ix->bits == 8;
         double gs[4] = {0.0, 0.0, 0.0, 0.0};
         // runs of 8 consecutive elements are contiguous in the image (one lane's 16 bytes)
@@ -36,8 +36,7 @@ void build_image_bf16(const szg_index *ix, Ctx *c, int nq, int nb)
             }
         }
         const double gsum = (gs[0] + gs[1]) + (gs[2] + gs[3]);
-        static const bool signed8 = getenv("SZG_MQD8_SIGNED") != nullptr;  // (A/B with a -DSZG_MQD8_SIGNED kernel build)
-        c->mq_qsum[q] = (float)(signed8 ? gsum : -255.0 * gsum);
+        c->mq_qsum[q] = (float)gsum;
     }
 }
 
