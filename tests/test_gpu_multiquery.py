@@ -483,7 +483,8 @@ def test_resident_row_norms_follow_mutations(bits, dim):
 
 
 @pytest.mark.parametrize("metric", [SZG_COSINE, SZG_EUCLIDEAN])
-@pytest.mark.parametrize("dim,n", [(768, 3000), (384, 4000), (128, 9000), (64, 2000), (100, 3000), (37, 1500)])
+@pytest.mark.parametrize("dim,n", [(768, 3000), (384, 4000), (128, 9000), (64, 2000), (120, 2500), (500, 2000), (100, 3000),
+                                   (37, 1500)])
 def test_8bit_rows_through_the_bf16_sweep(metric, dim, n):
     """8-bit rows whose pitch is a whole number of 64-byte steps (the tiled layout) share ONE bfloat16 pass per 96
     queries: the codes are exact in bfloat16, only the query is rounded; the band is re-scored in float32 and everything
@@ -492,7 +493,7 @@ def test_8bit_rows_through_the_bf16_sweep(metric, dim, n):
     rows = orc.synth_rows(8800 + dim, 0, n, dim, 8)
     Q = orc.synth_vectors(8801 + dim, 0, 96, dim)
     allow = np.arange(n) % 6 != 1
-    tiled = dim % 64 == 0
+    tiled = ((dim + 15) // 16 * 16) % 64 == 0   # the row pitch (16-byte pieces) is a whole number of 64-byte steps: 120 and 500 pad
     with ScanIndex(dim, 8, metric) as ix:
         ix.load(rows)
         check(ix, rows, dim, Q, 10, bits=8, metric=metric)
