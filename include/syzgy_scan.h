@@ -308,8 +308,9 @@ typedef struct szg_stats {
     double host_enqueue_us;
     uint64_t sketch_queries;   /* top-k queries answered through the 8-bit sketch pre-pass ("sketch" option) */
     uint64_t sketch_fallbacks; /* ... that it could not settle and handed to the full-precision path */
-    uint64_t mq_bf16_sweeps;   /* shared sweeps that ran on the bfloat16 matrix cores (32- / 16-bit rows; their candidates
-                                  are re-scored in float32 and re-ranked in float64 like every other path's) */
+    uint64_t mq_bf16_sweeps;   /* shared sweeps that ran on the bfloat16 matrix cores (64- / 32- / 16-bit rows, top-k batches
+                                  on 8-bit rows in whole 64-byte steps; their candidates are re-scored in float32 and
+                                  re-ranked in float64 like every other path's) */
 } szg_stats;
 
 /* HIP-event timing on the library's own streams (off by default): 1 = events around the scan
@@ -352,8 +353,10 @@ int szg_reset_stats(szg_index *ix);
  *     multi_query         1   batches of >= mq_min queries share ONE sweep of the corpus, the dot products on the
  *                             matrix cores: 64- / 32- / 16-bit rows on bfloat16 roundings (v_mfma_f32_16x16x32_bf16,
  *                             up to 96 queries per pass; candidates scored again in float32, certified against the
- *                             bfloat16 bound), 8- / 4-bit rows in exact integer arithmetic (v_mfma_i32_16x16x64_i8, 48
- *                             per pass, two passes per launch); 0 = one sweep per query
+ *                             bfloat16 bound) -- and top-k batches on 8-bit rows in whole 64-byte steps, whose codes
+ *                             are exact in bfloat16 (only the query is rounded) --, 4-bit rows, the other 8-bit
+ *                             shapes and every radius batch on 8-bit rows in exact integer arithmetic
+ *                             (v_mfma_i32_16x16x64_i8, 48 per pass, two passes per launch); 0 = one sweep per query
  *     mq_min              2   smallest batch worth a shared sweep
  *     mq_hits             1024 candidates per query the threshold from the prefix pass aims at
  *     coalesce            1   concurrent szg_search_topk calls with ONE query each -- the reference's Searches under
