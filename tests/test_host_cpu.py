@@ -241,8 +241,8 @@ def test_bench_compact_line_keeps_the_contract_fields_and_one_short_object_per_l
     assert c["batched"]["kernel"] == "szg::k<6>" and c["batched"]["end_to_end_hbm_frac"] == 0.6
     assert c["lone_call"] == {"ms": 0.5, "queries_per_s": 2000.0, "hbm_frac": 0.77}
     assert c["spread"] == {"min": 1.0, "max": 1.1, "repeats": 5}
-    assert c["batched_quantized"]["8bit"] == {"value": 3.0, "avg_pass_ms": 0.12, "roofline": bench._rf(rf),
-                                              "identical_to_single_query_path": True}
+    assert c["batched_quantized"]["8bit"] == {"value": 3.0, "avg_pass_ms": 0.12, "queries_per_pass": None,
+                                              "roofline": bench._rf(rf), "identical_to_single_query_path": True}
     assert c["batched_quantized"]["4bit"] == {"error": "RuntimeError: x"}
     assert c["other_workloads"]["cfg5"]["batched_96_queries_per_s"] == 50000.0
     assert c["other_workloads"]["cfg5"]["identical_to_oracle"] == "2/2" and c["other_workloads"]["cfg2"] == {"error": "boom"}
