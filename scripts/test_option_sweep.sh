@@ -16,7 +16,8 @@ run() {  # $1 = label, rest = pytest arguments
 # (tie_mode=1 changes the contract -- any valid top-k among equal distances -- and has its own test,
 # tests/test_gpu_parity.py::test_tie_mode_1_returns_a_valid_topk.)
 # SWEEP_SETS="a=1 b=2,c=3" restricts the first loop to those sets (re-checking a fix)
-# SWEEP_SKIP_MAIN=1 skips this loop (a box allows 20 minutes per call and this loop takes 19 of them: first call
+# SWEEP_SKIP_MAIN=1 skips this loop (a box allows 20 minutes per call and this loop takes 21 of them by now: give the
+# first call ten of the sets through SWEEP_SETS, the second the eleventh and everything below; formerly: first call
 # `SWEEP_MQ_SETS="" SWEEP_SKIP_NORMS=1`, second call `SWEEP_SKIP_MAIN=1`)
 [ -n "$SWEEP_SKIP_MAIN" ] || for opts in ${SWEEP_SETS:-serialize_scans=0 queries_per_launch=1 queries_per_launch=3,query_batch=5 \
             force_matrix=1 multi_query=0 contexts=1,mask_dense=0,coalesce=0 mq_min=8,mq_hits=256 \
