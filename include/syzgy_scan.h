@@ -353,7 +353,7 @@ int szg_reset_stats(szg_index *ix);
  *     multi_query         1   batches of >= mq_min queries share ONE sweep of the corpus, the dot products on the
  *                             matrix cores: 64- / 32- / 16-bit rows on bfloat16 roundings (v_mfma_f32_16x16x32_bf16,
  *                             up to 96 queries per pass; candidates scored again in float32, certified against the
- *                             bfloat16 bound) -- and top-k batches on 8-bit rows in whole 64-byte steps, whose codes
+ *                             bfloat16 bound) -- and top-k batches of more than 48 queries on 8-bit rows in whole 64-byte steps, whose codes
  *                             are exact in bfloat16 (only the query is rounded) --, 4-bit rows, the other 8-bit
  *                             shapes and every radius batch on 8-bit rows in exact integer arithmetic
  *                             (v_mfma_i32_16x16x64_i8, 48 per pass, two passes per launch); 0 = one sweep per query

@@ -157,8 +157,8 @@ MqPlan mq_plan(const szg_index *ix, const Shard *sh, int kp, int kp_wide, int nq
 {
     MqPlan p;
     const int r16 = ix->map.r16;
-    p.i8 = mq_uses_i8(ix);
-    p.bf16 = mq_uses_bf16(ix);
+    p.i8 = mq_uses_i8(ix, false, nq);
+    p.bf16 = mq_uses_bf16(ix, false, nq);
     p.groups = p.i8 ? (nq + 16 * nb - 1) / (16 * nb) : 1;
     p.group_stride = p.i8 ? ((szg::mq_i8_image_bytes(ix->bits, r16, nb) + 3 * 48 * sizeof(float) + 255) & ~(size_t)255) : 0;
     p.img = p.bf16 ? szg::mq_bf16_image_bytes(ix->bits, r16, nb) : p.group_stride * p.groups;

@@ -226,9 +226,9 @@ double key_eps(const szg_index *ix, double key, const QMeta &m)
 
 // 8-bit rows in whole 64-byte steps (the tiled layout) through the bfloat16 sweep -- their codes are exact in bfloat16,
 // 96 queries share a pass instead of 48 (kernels_mq.hip, part 108).  SZG_BF16_8BIT=0 keeps them on the int8 sweep.
-static bool bf16_takes_8bit(const szg_index *ix, bool radius)
+static bool bf16_takes_8bit(const szg_index *ix, bool radius, int nq)
 {
-    if (radius) return false;  // (a radius IS the threshold: the band of the rounded query would be collected too)
+    if (radius || nq <= 48) return false;  // (a radius IS the threshold: the band of the rounded query would be collected too)
     static const bool on = []() {
         const char *e = getenv("SZG_BF16_8BIT");
         if (getenv("SZG_NO_ROW_NORMS")) return false;  // (the kernel takes the rows' norms from the resident array)
@@ -236,15 +236,15 @@ static bool bf16_takes_8bit(const szg_index *ix, bool radius)
     }();
     return on && ix->bits == 8 && ix->layout.tiled && ix->mq_bf16;
 }
-bool mq_uses_i8(const szg_index *ix, bool radius)
+bool mq_uses_i8(const szg_index *ix, bool radius, int nq)
 {
-    return (ix->bits == 8 || ix->bits == 4) && ix->mq_i8 && !bf16_takes_8bit(ix, radius);
+    return (ix->bits == 8 || ix->bits == 4) && ix->mq_i8 && !bf16_takes_8bit(ix, radius, nq);
 }
 // the bfloat16 sweep: 64-, 32- and 16-bit rows of any dimension (not the experimental tiled layout of wide rows), and
 // tiled 8-bit rows
-bool mq_uses_bf16(const szg_index *ix, bool radius)
+bool mq_uses_bf16(const szg_index *ix, bool radius, int nq)
 {
-    if (bf16_takes_8bit(ix, radius)) return true;
+    if (bf16_takes_8bit(ix, radius, nq)) return true;
     if (!ix->mq_bf16 || ix->layout.tiled) return false;
     return ix->bits == 64 || ix->bits == 32 || ix->bits == 16;
 }
@@ -289,7 +289,7 @@ void prep_mq_int(const szg_index *ix, const double *q, QMeta *meta, int32_t *Qou
 int mq_blocks(const szg_index *ix, int nq, bool radius)
 {   // query blocks of 16 the batch gets (nq = the queries left in the call), or 0 when the shared sweep does not apply
     if (!ix->multi_query || nq < ix->mq_min) return 0;
-    const bool bf16 = mq_uses_bf16(ix, radius), i8 = mq_uses_i8(ix, radius);
+    const bool bf16 = mq_uses_bf16(ix, radius, nq), i8 = mq_uses_i8(ix, radius, nq);
     if (!bf16 && !i8) return 0;  // (switched off, or the experimental tiled layout of wide rows): one sweep per query
     int nb = std::min((nq + 15) / 16, std::min(ix->mq_blocks_max, bf16 ? 6 : 3));
     auto fits = [&](int n) {  // the image (+ tables, hit buffers, staging) must fit LDS

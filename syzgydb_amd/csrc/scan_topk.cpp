@@ -626,7 +626,7 @@ int TopkCall::stage(Ticket &t, int nb, bool bf16_sweep)
     const uint64_t *const *mptr = t.any_mask ? masks.data() : nullptr;
     const double t_prep0 = now_us();
     Ctx *c0 = nullptr;
-    const bool int_planes = nb > 0 && mq_uses_i8(ix);
+    const bool int_planes = nb > 0 && mq_uses_i8(ix, false, t.nq);
     t.lazy_single = nb > 0 && !replay_all;
     for (size_t s = 0; s < n_sh && rc == SZG_OK; s++) {
         if (ix->shards[s]->n_rows == 0) continue;
@@ -644,7 +644,7 @@ int TopkCall::stage(Ticket &t, int nb, bool bf16_sweep)
                 // (a shared sweep stages its own image; the single-query form is built if a query escalates)
                 if (t.lazy_single) prep_query_meta(ix, q + (size_t)j * ix->dim, &t.meta[j]);
                 else prep_query(ix, q + (size_t)j * ix->dim, cx->h_qsw + (size_t)j * ix->qsw_bytes, &t.meta[j]);
-                t.meta[j].mq = nb > 0 && !mq_uses_i8(ix);  // the integer sweeps keep the integer bound
+                t.meta[j].mq = nb > 0 && !mq_uses_i8(ix, false, t.nq);  // the integer sweeps keep the integer bound
                 t.meta[j].mq_bf16 = bf16_sweep;
                 if (int_planes) prep_mq_int(ix, q + (size_t)j * ix->dim, &t.meta[j], cx->h_mqQ + (size_t)j * ix->dim);
                 cx->meta[j] = t.meta[j];
@@ -1001,7 +1001,7 @@ int TopkCall::run()
     bool threaded = false;
     {
         const int nb0 = replay_all ? 0 : mq_blocks(ix, n_queries);
-        threaded = ix->finish_thread && nb0 > 0 && n_queries > 2 * 16 * nb0 * (mq_uses_i8(ix) ? 2 : 1);
+        threaded = ix->finish_thread && nb0 > 0 && n_queries > 2 * 16 * nb0 * (mq_uses_i8(ix, false, n_queries) ? 2 : 1);
     }
     if (threaded) {
         try {
@@ -1046,7 +1046,7 @@ int TopkCall::run()
         const int left = n_queries - q0;
         const int nb = replay_all ? 0 : mq_blocks(ix, left);  // > 0: the batch shares one sweep
         // (int8 sweeps: two groups of 48 per launch when that many queries are waiting and both images fit LDS)
-        const int groups = nb == 3 && mq_uses_i8(ix) && ix->mq_i8_groups > 1 && left > 48 &&
+        const int groups = nb == 3 && mq_uses_i8(ix, false, left) && ix->mq_i8_groups > 1 && left > 48 &&
                                    szg::mq_i8_lds_bytes(ix->bits, ix->map.r16, 3, 2) <= 160u * 1024u
                                ? 2 : 1;
         t.nq = nb ? std::min(left, 16 * nb * groups) : std::min(B1, left);
@@ -1069,7 +1069,7 @@ int TopkCall::run()
             if (q0 == 0) t.nq = std::min(t.nq, ix->first_batch);
             else if (left <= B1 + ix->first_batch) t.nq = left - ix->first_batch;
         }
-        const bool bf16_sweep = nb > 0 && mq_uses_bf16(ix);
+        const bool bf16_sweep = nb > 0 && mq_uses_bf16(ix, false, t.nq);
         t.kp = kp;
         // lists of bfloat16-sweep keys (matrix form): the error band holds more rows than the float32 one's, keep
         // enough candidates for the k-th result to clear it
