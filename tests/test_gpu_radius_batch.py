@@ -129,9 +129,11 @@ def test_concurrent_radius_callers_are_coalesced():
         radii = dd[:, 59]
         out = [None] * len(Q)
         errs = []
+        gate = threading.Barrier(len(Q))   # all callers at once (threads started one after the other may never meet)
 
         def work(i):
             try:
+                gate.wait()
                 if i % 6 == 5:
                     out[i] = ix.search_topk(Q[i], 7)
                 else:
